@@ -1,0 +1,94 @@
+/*
+ * oracle/ref_shim.c -> oracle/_ref/libcpucodecs.so
+ *
+ * Thin C shim over the third-party CPU codecs the reference itself uses as its
+ * interoperability pin and CPU peer: liblz4 (lz4.h, lz4hc.h: examples/
+ * lz4_cpu_compression.cu:31-33,61-66; examples/lz4_cpu_decompression.cu:143-147)
+ * and snappy (named by BASELINE.json north_star). The libraries are the
+ * container's own (/opt/conda: lz4 1.9.3, snappy 1.1.8); nothing from
+ * /root/reference is compiled or copied here because the reference ships no
+ * codec source (README.md:10) -- its codec path is "unbuildable" and these
+ * libraries are the published implementations of the same wire formats.
+ *
+ * TEST INFRASTRUCTURE ONLY: used to pin the oracle sources, to make golden vectors
+ * (scripts/make_golden.py), to prepare CPU-compressed inputs for tests and
+ * bench.py, and as bench.py's cpu_baseline ("reference" kind).
+ */
+#include <lz4.h>
+#include <lz4hc.h>
+#include <snappy-c.h>
+
+#include "batch.h"
+
+int ref_lz4_version(void) { return LZ4_versionNumber(); }
+size_t ref_lz4_bound(size_t n) { return (size_t)LZ4_compressBound((int)n); }
+size_t ref_snappy_bound(size_t n) { return snappy_max_compressed_length(n); }
+
+static int hc_level = 12;
+
+static int r_lz4_dec(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out)
+{
+  if (n == 0) {
+    *out = 0;
+    return 0;
+  }
+  const int r = LZ4_decompress_safe((const char*)s, (char*)d, (int)n, (int)cap);
+  *out = r < 0 ? 0 : (size_t)r;
+  return r < 0;
+}
+static int r_lz4_enc(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out)
+{
+  const int r = LZ4_compress_default((const char*)s, (char*)d, (int)n, (int)cap);
+  *out = (size_t)r;
+  return r <= 0 && n != 0;
+}
+static int r_lz4_enc_hc(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out)
+{
+  const int r = LZ4_compress_HC((const char*)s, (char*)d, (int)n, (int)cap, hc_level);
+  *out = (size_t)r;
+  return r <= 0 && n != 0;
+}
+static int r_snappy_dec(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out)
+{
+  size_t len = cap;
+  const snappy_status st = snappy_uncompress((const char*)s, n, (char*)d, &len);
+  *out = st == SNAPPY_OK ? len : 0;
+  return st != SNAPPY_OK;
+}
+static int r_snappy_enc(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out)
+{
+  size_t len = cap;
+  const snappy_status st = snappy_compress((const char*)s, n, (char*)d, &len);
+  *out = st == SNAPPY_OK ? len : 0;
+  return st != SNAPPY_OK;
+}
+
+/* single-chunk entry points (return 0 on success) */
+int ref_lz4_decompress(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out) { return r_lz4_dec(s, n, d, cap, out); }
+int ref_lz4_compress(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out) { return r_lz4_enc(s, n, d, cap, out); }
+int ref_lz4_compress_hc(const uint8_t* s, size_t n, uint8_t* d, size_t cap, int level, size_t* out)
+{
+  const int r = LZ4_compress_HC((const char*)s, (char*)d, (int)n, (int)cap, level);
+  *out = (size_t)r;
+  return r <= 0 && n != 0;
+}
+int ref_snappy_decompress(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out) { return r_snappy_dec(s, n, d, cap, out); }
+int ref_snappy_compress(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out) { return r_snappy_enc(s, n, d, cap, out); }
+int ref_snappy_uncompressed_length(const uint8_t* s, size_t n, size_t* out)
+{
+  return snappy_uncompressed_length((const char*)s, n, out) != SNAPPY_OK;
+}
+
+/* codec: 0 lz4 dec, 1 snappy dec, 2 lz4 enc (default), 3 snappy enc, 4 lz4 enc HC level 12 */
+double ref_batch_run(
+    int codec, int threads, int repeats, size_t n_chunks,
+    const uint8_t* const* in_ptrs, const size_t* in_sizes,
+    uint8_t* const* out_ptrs, const size_t* out_caps, size_t* out_sizes, int* errors)
+{
+  static const batch_codec_fn table[5] = {r_lz4_dec, r_snappy_dec, r_lz4_enc, r_snappy_enc, r_lz4_enc_hc};
+  if (codec < 0 || codec > 4) {
+    return -1.0;
+  }
+  return batch_run_generic(
+      table[codec], threads, repeats, n_chunks, in_ptrs, in_sizes, out_ptrs, out_caps, out_sizes, errors);
+}
