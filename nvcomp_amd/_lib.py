@@ -1,0 +1,107 @@
+"""ctypes binding of libnvcomp.so (the C ABI declared in include/nvcomp/*.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnvcomp.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+
+class NvcompStatus(enum.IntEnum):
+    Success = 0
+    ErrorInvalidValue = 10
+    ErrorNotSupported = 11
+    ErrorCannotDecompress = 12
+    ErrorBadChecksum = 13
+    ErrorCannotVerifyChecksums = 14
+    ErrorOutputBufferTooSmall = 15
+    ErrorWrongHeaderLength = 16
+    ErrorAlignment = 17
+    ErrorChunkSizeTooLarge = 18
+    ErrorCudaError = 1000
+    ErrorInternal = 10000
+
+
+class NvcompType(enum.IntEnum):
+    CHAR = 0
+    UCHAR = 1
+    SHORT = 2
+    USHORT = 3
+    INT = 4
+    UINT = 5
+    LONGLONG = 6
+    ULONGLONG = 7
+    BITS = 0xFF
+
+
+class LZ4Opts(C.Structure):
+    _fields_ = [("data_type", C.c_int)]
+
+
+class SnappyOpts(C.Structure):
+    _fields_ = [("reserved", C.c_int)]
+
+
+class CascadedOpts(C.Structure):
+    _fields_ = [("chunk_size", C.c_size_t), ("type", C.c_int), ("num_RLEs", C.c_int), ("num_deltas", C.c_int),
+                ("use_bp", C.c_int)]
+
+
+OPTS = {"LZ4": LZ4Opts, "Snappy": SnappyOpts, "Cascaded": CascadedOpts}
+
+# Every symbol include/nvcomp/{lz4,snappy,cascaded}.h declares, per format.
+ENTRY_POINTS = (
+    "CompressGetTempSize",
+    "CompressGetMaxOutputChunkSize",
+    "CompressAsync",
+    "DecompressGetTempSize",
+    "DecompressAsync",
+    "GetDecompressSizeAsync",
+)
+EXTRA_ENTRY_POINTS = {
+    "LZ4": ("CompressGetTempSizeEx", "DecompressGetTempSizeEx"),
+    "Snappy": ("CompressGetTempSizeEx", "DecompressGetTempSizeEx"),
+    "Cascaded": (),
+}
+
+
+def build_library(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into nvcomp_amd/lib/libnvcomp.so (hipcc; no GPU needed)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.run(["make", "-C", CSRC, "-j8"], check=True, stdout=out)
+    return LIB_PATH
+
+
+def declare(lib: C.CDLL, formats=("LZ4", "Snappy", "Cascaded")) -> C.CDLL:
+    """Attach argtypes/restype for the formats the library exports."""
+    vp, sz, szp = C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)
+    for fmt in formats:
+        opts = OPTS[fmt]
+        pre = "nvcompBatched" + fmt
+        if not hasattr(lib, pre + "DecompressAsync"):
+            continue
+        getattr(lib, pre + "CompressGetTempSize").argtypes = [sz, sz, opts, szp]
+        getattr(lib, pre + "CompressGetMaxOutputChunkSize").argtypes = [sz, opts, szp]
+        getattr(lib, pre + "CompressAsync").argtypes = [vp, vp, sz, sz, vp, sz, vp, vp, opts, vp]
+        getattr(lib, pre + "DecompressGetTempSize").argtypes = [sz, sz, szp]
+        getattr(lib, pre + "DecompressAsync").argtypes = [vp, vp, vp, vp, sz, vp, sz, vp, vp, vp]
+        getattr(lib, pre + "GetDecompressSizeAsync").argtypes = [vp, vp, vp, sz, vp]
+        for name in ENTRY_POINTS + EXTRA_ENTRY_POINTS[fmt]:
+            getattr(lib, pre + name).restype = C.c_int
+        if "CompressGetTempSizeEx" in EXTRA_ENTRY_POINTS[fmt]:
+            getattr(lib, pre + "CompressGetTempSizeEx").argtypes = [sz, sz, opts, szp, sz]
+            getattr(lib, pre + "DecompressGetTempSizeEx").argtypes = [sz, sz, szp, sz]
+    return lib
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    """Load the HIP library. Raises if it has not been built: there is no fallback."""
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). nvcomp_amd has no CPU fallback.")
+    return declare(C.CDLL(path))

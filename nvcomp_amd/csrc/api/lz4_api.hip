@@ -1,0 +1,278 @@
+/*
+ * api/lz4_api.hip -- C ABI of the batched LZ4 codec (include/nvcomp/lz4.h) and
+ * the kernels it launches. Host side does argument checks and one launch per
+ * *Async call on the caller's stream; nothing here allocates or synchronises.
+ */
+#include <hip/hip_runtime.h>
+
+#include <stdlib.h>
+
+#include "nvcomp/lz4.h"
+
+#include "lz4/lz4_decode.hip.h"
+#include "lz4/lz4_encode.hip.h"
+
+namespace {
+
+constexpr unsigned kWavesPerBlock = 4; /* 256-thread workgroups, one chunk per wave */
+constexpr uint32_t kMaxOutCap = 1u << 26;
+
+/* Kernel variant switch for A/B measurements (bench.py --variant):
+ * NVCOMP_AMD_LZ4_DECODE=serial selects the one-sequence-per-step baseline. */
+int lz4_decode_variant()
+{
+  static const int v = [] {
+    const char* e = getenv("NVCOMP_AMD_LZ4_DECODE");
+    return (e != nullptr && e[0] == 's') ? 1 : 0;
+  }();
+  return v;
+}
+
+template <bool CHECKED, bool LANE_PARALLEL>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) lz4_decompress_kernel(
+    const void* const* __restrict__ comp_ptrs,
+    const size_t* __restrict__ comp_bytes,
+    const size_t* out_caps,
+    size_t* actual_bytes,
+    size_t batch_size,
+    void* const* __restrict__ out_ptrs,
+    nvcompStatus_t* statuses)
+{
+  const size_t chunk = (size_t)blockIdx.x * kWavesPerBlock + wave::uniform(threadIdx.x >> 6);
+  if (chunk >= batch_size) {
+    return;
+  }
+  const uint8_t* in = wave::uniform_ptr((const uint8_t*)comp_ptrs[chunk]);
+  uint8_t* out = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
+  const size_t in_len64 = wave::uniform64(comp_bytes[chunk]);
+  size_t cap64 = wave::uniform64(out_caps[chunk]);
+  if (cap64 > kMaxOutCap) {
+    cap64 = kMaxOutCap;
+  }
+  uint32_t err = lz::kErrNone;
+  uint32_t produced = 0;
+  if (in_len64 > 0xffffffffull - 8) {
+    err = lz::kErrInput;
+  } else {
+    produced = lz4::decode_chunk<CHECKED, LANE_PARALLEL, false>(in, (uint32_t)in_len64, out, (uint32_t)cap64, err);
+  }
+  if (wave::lane_id() == 0) {
+    if (actual_bytes != nullptr) {
+      actual_bytes[chunk] = err ? 0 : produced;
+    }
+    if (CHECKED) {
+      statuses[chunk] = err ? nvcompErrorCannotDecompress : nvcompSuccess;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64 * kWavesPerBlock) lz4_decompress_size_kernel(
+    const void* const* __restrict__ comp_ptrs,
+    const size_t* __restrict__ comp_bytes,
+    size_t* uncompressed_bytes,
+    size_t batch_size)
+{
+  const size_t chunk = (size_t)blockIdx.x * kWavesPerBlock + wave::uniform(threadIdx.x >> 6);
+  if (chunk >= batch_size) {
+    return;
+  }
+  const uint8_t* in = wave::uniform_ptr((const uint8_t*)comp_ptrs[chunk]);
+  const size_t in_len64 = wave::uniform64(comp_bytes[chunk]);
+  uint32_t err = lz::kErrNone;
+  uint32_t produced = 0;
+  if (in_len64 <= 0xffffffffull - 8) {
+    produced = lz4::decode_chunk<false, true, true>(in, (uint32_t)in_len64, nullptr, 0, err);
+  }
+  if (wave::lane_id() == 0) {
+    uncompressed_bytes[chunk] = err ? 0 : produced;
+  }
+}
+
+__global__ void __launch_bounds__(64 * kWavesPerBlock) lz4_compress_kernel(
+    const void* const* __restrict__ in_ptrs,
+    const size_t* __restrict__ in_bytes,
+    size_t batch_size,
+    void* const* __restrict__ out_ptrs,
+    size_t* out_bytes)
+{
+  __shared__ uint16_t tables[kWavesPerBlock][lzm::kHashSize];
+  const uint32_t w = wave::uniform(threadIdx.x >> 6);
+  const size_t chunk = (size_t)blockIdx.x * kWavesPerBlock + w;
+  if (chunk >= batch_size) {
+    return;
+  }
+  const uint8_t* src = wave::uniform_ptr((const uint8_t*)in_ptrs[chunk]);
+  uint8_t* dst = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
+  const uint32_t n = (uint32_t)wave::uniform64(in_bytes[chunk]);
+  const uint32_t produced = lz4::encode_chunk(src, n, dst, tables[w]);
+  if (wave::lane_id() == 0) {
+    out_bytes[chunk] = produced;
+  }
+}
+
+nvcompStatus_t launch_status()
+{
+  return hipGetLastError() == hipSuccess ? nvcompSuccess : nvcompErrorCudaError;
+}
+
+unsigned grid_for(size_t batch_size)
+{
+  return (unsigned)((batch_size + kWavesPerBlock - 1) / kWavesPerBlock);
+}
+
+bool lz4_type_ok(nvcompType_t t)
+{
+  return (t >= NVCOMP_TYPE_CHAR && t <= NVCOMP_TYPE_UINT) || t == NVCOMP_TYPE_BITS;
+}
+
+} // namespace
+
+extern "C" {
+
+nvcompStatus_t nvcompBatchedLZ4DecompressGetTempSize(
+    size_t /*num_chunks*/, size_t /*max_uncompressed_chunk_bytes*/, size_t* temp_bytes)
+{
+  if (temp_bytes == nullptr) {
+    return nvcompErrorInvalidValue;
+  }
+  *temp_bytes = 0; /* the decoder keeps all state in registers */
+  return nvcompSuccess;
+}
+
+nvcompStatus_t nvcompBatchedLZ4DecompressGetTempSizeEx(
+    size_t num_chunks, size_t max_uncompressed_chunk_bytes, size_t* temp_bytes, size_t /*max_total_uncompressed_bytes*/)
+{
+  return nvcompBatchedLZ4DecompressGetTempSize(num_chunks, max_uncompressed_chunk_bytes, temp_bytes);
+}
+
+nvcompStatus_t nvcompBatchedLZ4DecompressAsync(
+    const void* const* device_compressed_ptrs,
+    const size_t* device_compressed_bytes,
+    const size_t* device_uncompressed_bytes,
+    size_t* device_actual_uncompressed_bytes,
+    size_t batch_size,
+    void* const /*device_temp_ptr*/,
+    size_t /*temp_bytes*/,
+    void* const* device_uncompressed_ptrs,
+    nvcompStatus_t* device_statuses,
+    hipStream_t stream)
+{
+  if (batch_size == 0) {
+    return nvcompSuccess;
+  }
+  if (device_compressed_ptrs == nullptr || device_compressed_bytes == nullptr || device_uncompressed_bytes == nullptr
+      || device_uncompressed_ptrs == nullptr) {
+    return nvcompErrorInvalidValue;
+  }
+  const dim3 grid(grid_for(batch_size));
+  const dim3 block(64 * kWavesPerBlock);
+  const bool checked = device_statuses != nullptr;
+  const bool serial = lz4_decode_variant() == 1;
+#define NVCOMP_LZ4_LAUNCH(C, P)                                                                               \
+  hipLaunchKernelGGL((lz4_decompress_kernel<C, P>), grid, block, 0, stream, device_compressed_ptrs,           \
+                     device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,   \
+                     batch_size, device_uncompressed_ptrs, device_statuses)
+  if (checked) {
+    if (serial) {
+      NVCOMP_LZ4_LAUNCH(true, false);
+    } else {
+      NVCOMP_LZ4_LAUNCH(true, true);
+    }
+  } else {
+    if (serial) {
+      NVCOMP_LZ4_LAUNCH(false, false);
+    } else {
+      NVCOMP_LZ4_LAUNCH(false, true);
+    }
+  }
+#undef NVCOMP_LZ4_LAUNCH
+  return launch_status();
+}
+
+nvcompStatus_t nvcompBatchedLZ4GetDecompressSizeAsync(
+    const void* const* device_compressed_ptrs,
+    const size_t* device_compressed_bytes,
+    size_t* device_uncompressed_bytes,
+    size_t batch_size,
+    hipStream_t stream)
+{
+  if (batch_size == 0) {
+    return nvcompSuccess;
+  }
+  if (device_compressed_ptrs == nullptr || device_compressed_bytes == nullptr || device_uncompressed_bytes == nullptr) {
+    return nvcompErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(lz4_decompress_size_kernel, dim3(grid_for(batch_size)), dim3(64 * kWavesPerBlock), 0, stream,
+                     device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes, batch_size);
+  return launch_status();
+}
+
+nvcompStatus_t nvcompBatchedLZ4CompressGetTempSize(
+    size_t /*batch_size*/, size_t max_uncompressed_chunk_bytes, nvcompBatchedLZ4Opts_t format_opts, size_t* temp_bytes)
+{
+  if (temp_bytes == nullptr || !lz4_type_ok(format_opts.data_type)) {
+    return nvcompErrorInvalidValue;
+  }
+  if (max_uncompressed_chunk_bytes > nvcompLZ4CompressionMaxAllowedChunkSize) {
+    return nvcompErrorChunkSizeTooLarge;
+  }
+  *temp_bytes = 0; /* the per-chunk hash tables live in LDS */
+  return nvcompSuccess;
+}
+
+nvcompStatus_t nvcompBatchedLZ4CompressGetTempSizeEx(
+    size_t batch_size,
+    size_t max_uncompressed_chunk_bytes,
+    nvcompBatchedLZ4Opts_t format_opts,
+    size_t* temp_bytes,
+    const size_t /*max_total_uncompressed_bytes*/)
+{
+  return nvcompBatchedLZ4CompressGetTempSize(batch_size, max_uncompressed_chunk_bytes, format_opts, temp_bytes);
+}
+
+nvcompStatus_t nvcompBatchedLZ4CompressGetMaxOutputChunkSize(
+    size_t max_uncompressed_chunk_bytes, nvcompBatchedLZ4Opts_t format_opts, size_t* max_compressed_bytes)
+{
+  if (max_compressed_bytes == nullptr || !lz4_type_ok(format_opts.data_type)) {
+    return nvcompErrorInvalidValue;
+  }
+  if (max_uncompressed_chunk_bytes > nvcompLZ4CompressionMaxAllowedChunkSize) {
+    return nvcompErrorChunkSizeTooLarge;
+  }
+  /* worst case of the block format: one length byte per 255 literals + token + slack */
+  *max_compressed_bytes = max_uncompressed_chunk_bytes + max_uncompressed_chunk_bytes / 255 + 16;
+  return nvcompSuccess;
+}
+
+nvcompStatus_t nvcompBatchedLZ4CompressAsync(
+    const void* const* device_uncompressed_ptrs,
+    const size_t* device_uncompressed_bytes,
+    size_t max_uncompressed_chunk_bytes,
+    size_t batch_size,
+    void* /*device_temp_ptr*/,
+    size_t /*temp_bytes*/,
+    void* const* device_compressed_ptrs,
+    size_t* device_compressed_bytes,
+    nvcompBatchedLZ4Opts_t format_opts,
+    hipStream_t stream)
+{
+  if (!lz4_type_ok(format_opts.data_type)) {
+    return nvcompErrorInvalidValue;
+  }
+  if (max_uncompressed_chunk_bytes > nvcompLZ4CompressionMaxAllowedChunkSize) {
+    return nvcompErrorChunkSizeTooLarge;
+  }
+  if (batch_size == 0) {
+    return nvcompSuccess;
+  }
+  if (device_uncompressed_ptrs == nullptr || device_uncompressed_bytes == nullptr || device_compressed_ptrs == nullptr
+      || device_compressed_bytes == nullptr) {
+    return nvcompErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(lz4_compress_kernel, dim3(grid_for(batch_size)), dim3(64 * kWavesPerBlock), 0, stream,
+                     device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
+                     device_compressed_bytes);
+  return launch_status();
+}
+
+} // extern "C"

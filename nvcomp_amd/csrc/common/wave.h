@@ -1,0 +1,127 @@
+/*
+ * common/wave.h -- wave64 cross-lane primitives for gfx950 (CDNA4).
+ *
+ * Every codec kernel in this library runs "one wavefront per chunk": the 64
+ * lanes of a wave cooperate through the operations below and never through
+ * __syncthreads(). All of them assume full 64-wide wavefronts and must be
+ * called from wave-uniform control flow.
+ */
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wave {
+
+constexpr int kSize = 64;
+
+__device__ __forceinline__ int lane_id()
+{
+  return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+/* 64-bit mask of lanes whose predicate is true. */
+__device__ __forceinline__ uint64_t ballot(bool pred)
+{
+  return __builtin_amdgcn_ballot_w64(pred);
+}
+
+/* Value of lane `lane` (wave-uniform index) broadcast to the scalar unit. */
+__device__ __forceinline__ uint32_t read_lane(uint32_t v, uint32_t lane)
+{
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane);
+}
+
+/* Tell the compiler a value is wave-uniform (it moves to an SGPR). */
+__device__ __forceinline__ uint32_t uniform(uint32_t v)
+{
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)
+{
+  const uint32_t lo = uniform((uint32_t)v);
+  const uint32_t hi = uniform((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p)
+{
+  return (T*)uniform64((uint64_t)p);
+}
+
+/* `vec` with lane `lane` (wave-uniform) replaced by the uniform value `val`. */
+__device__ __forceinline__ uint32_t write_lane(uint32_t vec, uint32_t val, uint32_t lane)
+{
+  return ((uint32_t)lane_id() == lane) ? val : vec;
+}
+
+/* Per-lane gather: lane i receives v of lane src_lane(i) (ds_bpermute_b32). */
+__device__ __forceinline__ uint32_t shuffle(uint32_t v, uint32_t src_lane)
+{
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
+}
+
+/* Inclusive prefix sum across the wave: 4 row_shr steps inside each row of 16
+ * lanes, then row_bcast:15 / row_bcast:31 to carry across rows (DPP, no LDS). */
+__device__ __forceinline__ uint32_t scan_add_inclusive(uint32_t v)
+{
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); /* row_shr:1 */
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); /* row_shr:2 */
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); /* row_shr:4 */
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); /* row_shr:8 */
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); /* row_bcast:15 */
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); /* row_bcast:31 */
+  return v;
+}
+
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b)
+{
+  return a > b ? a : b;
+}
+
+/* Wave-wide unsigned maximum, returned as a uniform value. Same DPP ladder as
+ * the scan; lane 63 ends up holding the reduction. */
+__device__ __forceinline__ uint32_t reduce_max(uint32_t v)
+{
+  v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+  v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+  v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+  v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+  v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+  v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+  return read_lane(v, 63);
+}
+
+__device__ __forceinline__ uint32_t reduce_add(uint32_t v)
+{
+  return read_lane(scan_add_inclusive(v), 63);
+}
+
+/*
+ * Order this wave's earlier memory writes (LDS or global) before its later
+ * reads, across lanes. One wave's LDS and vector-memory operations are served
+ * in issue order by the CU's LDS and L1, so no s_waitcnt is needed for a
+ * same-wave cross-lane read-after-write; what has to be stopped is the
+ * compiler moving a load above a store it believes cannot alias.
+ */
+__device__ __forceinline__ void sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+/* Trailing-zero / popcount helpers on ballots. */
+__device__ __forceinline__ uint32_t ctz64(uint64_t m)
+{
+  return (uint32_t)__builtin_ctzll(m);
+}
+
+__device__ __forceinline__ uint32_t popc64(uint64_t m)
+{
+  return (uint32_t)__builtin_popcountll(m);
+}
+
+} // namespace wave

@@ -1,0 +1,90 @@
+/*
+ * lz4/lz4_encode.hip.h -- batched LZ4 block-format compressor for gfx950.
+ *
+ * Replaces the device side of nvcompBatchedLZ4CompressAsync (reference call
+ * sites: benchmarks/benchmark_template_chunked.cuh:441-451,
+ * examples/lz4_cpu_decompression.cu:94-104). The output must be accepted by
+ * liblz4's LZ4_decompress_safe (examples/lz4_cpu_decompression.cu:142-157), so
+ * the end-of-block rules of the format are honoured: the last 5 bytes are
+ * literals, the last match starts at least 12 bytes before the end, chunks
+ * shorter than 13 bytes are stored as literals.
+ *
+ * One wavefront per chunk; the match finder is common/lz_match.hip.h, this file
+ * is the LZ4 sequence emitter.
+ */
+#pragma once
+
+#include "common/lz_match.hip.h"
+
+namespace lz4 {
+
+constexpr uint32_t kMinMatch = 4;
+constexpr uint32_t kMfLimit = 12;     /* last match must start this far before the end */
+constexpr uint32_t kLastLiterals = 5; /* and the last 5 bytes are always literals */
+
+/* Length-extension bytes for value v (15 already subtracted by the caller):
+ * v / 255 + 1 bytes, all 255 except the last which is v % 255. */
+__device__ __forceinline__ void put_extension(uint8_t* dst, uint32_t v)
+{
+  const uint32_t count = v / 255 + 1;
+  for (uint32_t i = (uint32_t)wave::lane_id(); i < count; i += 64) {
+    dst[i] = (i + 1 < count) ? (uint8_t)255 : (uint8_t)(v % 255);
+  }
+}
+
+/* Emit one sequence; returns the number of bytes written. match_len == 0 emits
+ * the final literal-only sequence. */
+__device__ __forceinline__ uint32_t emit_sequence(
+    uint8_t* dst, const uint8_t* lit, uint32_t lit_len, uint32_t offset, uint32_t match_len)
+{
+  const uint32_t ml = match_len ? match_len - kMinMatch : 0;
+  const uint32_t tok = ((lit_len < 15 ? lit_len : 15u) << 4) | (ml < 15 ? ml : 15u);
+  uint32_t pos = 1;
+  if (wave::lane_id() == 0) {
+    dst[0] = (uint8_t)tok;
+  }
+  if (lit_len >= 15) {
+    put_extension(dst + pos, lit_len - 15);
+    pos += (lit_len - 15) / 255 + 1;
+  }
+  lz::wave_copy(dst + pos, lit, lit_len);
+  pos += lit_len;
+  if (match_len) {
+    if (wave::lane_id() == 0) {
+      dst[pos] = (uint8_t)(offset & 255u);
+      dst[pos + 1] = (uint8_t)(offset >> 8);
+    }
+    pos += 2;
+    if (ml >= 15) {
+      put_extension(dst + pos, ml - 15);
+      pos += (ml - 15) / 255 + 1;
+    }
+  }
+  return pos;
+}
+
+struct Emitter
+{
+  static __device__ __forceinline__ uint32_t match(
+      uint8_t* dst, const uint8_t* lit, uint32_t lit_len, uint32_t offset, uint32_t match_len)
+  {
+    return emit_sequence(dst, lit, lit_len, offset, match_len);
+  }
+  static __device__ __forceinline__ uint32_t tail(uint8_t* dst, const uint8_t* lit, uint32_t lit_len)
+  {
+    return emit_sequence(dst, lit, lit_len, 0, 0);
+  }
+};
+
+/* Compress src[0,n) into dst (capacity >= n + n/255 + 16) with the calling
+ * wave; `table` is this wave's lzm::kHashSize x uint16 LDS hash table. Returns
+ * the compressed size. */
+__device__ __forceinline__ uint32_t encode_chunk(
+    const uint8_t* __restrict__ src, uint32_t n, uint8_t* dst, uint16_t* table)
+{
+  const bool any = n > kMfLimit;
+  return lzm::encode_chunk<Emitter>(
+      src, n, dst, table, any ? n - kMfLimit : 0, any ? n - kLastLiterals : 0, any);
+}
+
+} // namespace lz4

@@ -1,0 +1,122 @@
+/*
+ * snappy/snappy_encode.hip.h -- batched Snappy raw-format compressor for gfx950.
+ *
+ * Replaces the device side of nvcompBatchedSnappyCompressAsync (reference call
+ * sites: benchmarks/benchmark_snappy_synth.cpp:163-173,
+ * benchmarks/benchmark_template_chunked.cuh:441-451). One wavefront per chunk;
+ * the match finder is common/lz_match.hip.h, this file is the element emitter.
+ * Output decodes with snappy::RawUncompress (tests) and never exceeds
+ * 32 + n + n/6 bytes.
+ */
+#pragma once
+
+#include "common/lz_match.hip.h"
+
+namespace snappy {
+
+/* literal element: tag (+1..4 length bytes) + bytes. Returns bytes written. */
+__device__ __forceinline__ uint32_t emit_literal(uint8_t* dst, const uint8_t* lit, uint32_t len)
+{
+  if (len == 0) {
+    return 0;
+  }
+  const uint32_t n = len - 1;
+  uint32_t hdr = 1;
+  if (n < 60) {
+    if (wave::lane_id() == 0) {
+      dst[0] = (uint8_t)(n << 2);
+    }
+  } else {
+    const uint32_t nb = n < (1u << 8) ? 1u : n < (1u << 16) ? 2u : n < (1u << 24) ? 3u : 4u;
+    if (wave::lane_id() == 0) {
+      dst[0] = (uint8_t)((59 + nb) << 2);
+      for (uint32_t i = 0; i < nb; ++i) {
+        dst[1 + i] = (uint8_t)(n >> (8 * i));
+      }
+    }
+    hdr += nb;
+  }
+  lz::wave_copy(dst + hdr, lit, len);
+  return hdr + len;
+}
+
+/* One copy element of length 1..64 (lane 0 writes). Returns bytes written. */
+__device__ __forceinline__ uint32_t emit_copy_piece(uint8_t* dst, uint32_t offset, uint32_t len)
+{
+  const bool short_form = len >= 4 && len < 12 && offset < 2048;
+  if (wave::lane_id() == 0) {
+    if (short_form) {
+      dst[0] = (uint8_t)(1u | ((len - 4) << 2) | ((offset >> 8) << 5));
+      dst[1] = (uint8_t)(offset & 255u);
+    } else {
+      dst[0] = (uint8_t)(2u | ((len - 1) << 2));
+      dst[1] = (uint8_t)(offset & 255u);
+      dst[2] = (uint8_t)(offset >> 8);
+    }
+  }
+  return short_form ? 2u : 3u;
+}
+
+/* A match of any length as copy elements: 64-byte pieces while >= 68 remain
+ * (written in parallel, one piece per lane), one 60-byte piece if > 64 remain
+ * (so the last piece is never shorter than 4), then the rest. */
+__device__ __forceinline__ uint32_t emit_copy(uint8_t* dst, uint32_t offset, uint32_t len)
+{
+  uint32_t pos = 0;
+  if (len >= 68) {
+    const uint32_t full = (len - 68) / 64 + 1;
+    for (uint32_t i = (uint32_t)wave::lane_id(); i < full; i += 64) {
+      dst[3 * i] = (uint8_t)(2u | (63u << 2));
+      dst[3 * i + 1] = (uint8_t)(offset & 255u);
+      dst[3 * i + 2] = (uint8_t)(offset >> 8);
+    }
+    pos = 3 * full;
+    len -= 64 * full;
+  }
+  if (len > 64) {
+    pos += emit_copy_piece(dst + pos, offset, 60);
+    len -= 60;
+  }
+  pos += emit_copy_piece(dst + pos, offset, len);
+  return pos;
+}
+
+struct Emitter
+{
+  static __device__ __forceinline__ uint32_t match(
+      uint8_t* dst, const uint8_t* lit, uint32_t lit_len, uint32_t offset, uint32_t match_len)
+  {
+    const uint32_t a = emit_literal(dst, lit, lit_len);
+    return a + emit_copy(dst + a, offset, match_len);
+  }
+  static __device__ __forceinline__ uint32_t tail(uint8_t* dst, const uint8_t* lit, uint32_t lit_len)
+  {
+    return emit_literal(dst, lit, lit_len);
+  }
+};
+
+/* Compress src[0,n) into dst (capacity >= 32 + n + n/6). Returns compressed size. */
+__device__ __forceinline__ uint32_t encode_chunk(
+    const uint8_t* __restrict__ src, uint32_t n, uint8_t* dst, uint16_t* table)
+{
+  /* preamble: varint32 of n */
+  uint32_t hdr = 0;
+  {
+    uint32_t v = n;
+    uint8_t bytes[5];
+    do {
+      bytes[hdr] = (uint8_t)((v & 127u) | (v >= 128 ? 128u : 0u));
+      v >>= 7;
+      ++hdr;
+    } while (v);
+    if (wave::lane_id() == 0) {
+      for (uint32_t i = 0; i < hdr; ++i) {
+        dst[i] = bytes[i];
+      }
+    }
+  }
+  const bool any = n >= 8;
+  return hdr + lzm::encode_chunk<Emitter>(src, n, dst + hdr, table, any ? n - 4 : 0, n, any);
+}
+
+} // namespace snappy

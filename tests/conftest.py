@@ -1,0 +1,95 @@
+"""Test scaffolding.
+
+Two backends run the SAME tests through the SAME C ABI:
+  * ``gpu``  -- nvcomp_amd/lib/libnvcomp.so on a real MI355X (marked ``gpu``);
+  * ``emu``  -- tests/emu/libnvcomp_emu.so: the library's kernel sources compiled
+    for the host against tests/emu (lanes as coroutines). CPU-only debugging aid,
+    test infrastructure; it is not a fallback of the product.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "slow: long-running CPU test")
+
+
+class HostDevice:
+    """numpy-backed stand-in for TorchDevice used with the emulation library."""
+
+    def empty(self, nbytes):
+        return np.zeros(max(int(nbytes), 1), dtype=np.uint8)
+
+    def upload(self, host):
+        return np.ascontiguousarray(host).view(np.uint8).reshape(-1).copy()
+
+    def download(self, buf, nbytes=None):
+        return buf[: buf.size if nbytes is None else int(nbytes)].copy()
+
+    def ptr(self, buf):
+        return buf.ctypes.data
+
+    def stream(self):
+        return None
+
+    def synchronize(self):
+        pass
+
+
+_emu_lib = None
+
+
+def emu_library():
+    global _emu_lib
+    if _emu_lib is None:
+        from nvcomp_amd import _lib
+
+        emu_dir = os.path.join(REPO, "tests", "emu")
+        subprocess.run(["make", "-C", emu_dir, "-j8"], check=True, stdout=subprocess.DEVNULL)
+        _emu_lib = _lib.declare(C.CDLL(os.path.join(emu_dir, "libnvcomp_emu.so")))
+    return _emu_lib
+
+
+class Backend:
+    def __init__(self, name, lib, dev):
+        self.name, self.lib, self.dev = name, lib, dev
+
+    def codec(self, fmt="LZ4", opts=None):
+        from nvcomp_amd.batched import BatchedCodec
+
+        return BatchedCodec(self.lib, self.dev, fmt, opts)
+
+
+@pytest.fixture(scope="session")
+def emu():
+    return Backend("emu", emu_library(), HostDevice())
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    import nvcomp_amd
+
+    return Backend("gpu", nvcomp_amd.load_library(), nvcomp_amd.TorchDevice("cuda:0"))
+
+
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def backend(request):
+    return request.getfixturevalue(request.param)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle_py
+
+    oracle_py.build()
+    return oracle_py

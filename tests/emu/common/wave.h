@@ -1,0 +1,128 @@
+/*
+ * tests/emu/common/wave.h -- TEST INFRASTRUCTURE ONLY.
+ * CPU stand-in for nvcomp_amd/csrc/common/wave.h: same function set, each
+ * cross-lane operation implemented as a rendezvous of the emulated wave's lanes
+ * (see tests/emu/hip/hip_runtime.h).
+ */
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wave {
+
+constexpr int kSize = 64;
+
+enum OpId { kBallot = 1, kReadLane, kUniform, kShuffle, kScan, kMax, kSync };
+
+inline int lane_id() { return emu::cur()->lane; }
+
+inline uint64_t ballot(bool pred)
+{
+  emu::wave_rendezvous(kBallot, pred ? 1 : 0, 0);
+  uint64_t m = 0;
+  const uint64_t live = emu::live_mask();
+  for (int i = 0; i < 64; ++i) {
+    if (((live >> i) & 1) && emu::peer(i).a) {
+      m |= 1ull << i;
+    }
+  }
+  return m;
+}
+
+inline uint32_t read_lane(uint32_t v, uint32_t lane)
+{
+  emu::wave_rendezvous(kReadLane, v, lane);
+  const uint64_t live = emu::live_mask();
+  for (int i = 0; i < 64; ++i) {
+    if (((live >> i) & 1) && emu::peer(i).b != lane) {
+      fprintf(stderr, "emu: read_lane with a non-uniform lane index\n");
+      abort();
+    }
+  }
+  return (uint32_t)emu::peer((int)lane).a;
+}
+
+inline uint32_t uniform(uint32_t v)
+{
+  emu::wave_rendezvous(kUniform, v, 0);
+  const uint64_t live = emu::live_mask();
+  const int first = __builtin_ctzll(live);
+  for (int i = 0; i < 64; ++i) {
+    if (((live >> i) & 1) && emu::peer(i).a != emu::peer(first).a) {
+      fprintf(stderr, "emu: uniform() of a value that differs between lanes\n");
+      abort();
+    }
+  }
+  return (uint32_t)emu::peer(first).a;
+}
+
+inline uint64_t uniform64(uint64_t v)
+{
+  emu::wave_rendezvous(kUniform, v, 0);
+  const uint64_t live = emu::live_mask();
+  const int first = __builtin_ctzll(live);
+  for (int i = 0; i < 64; ++i) {
+    if (((live >> i) & 1) && emu::peer(i).a != emu::peer(first).a) {
+      fprintf(stderr, "emu: uniform64() of a value that differs between lanes\n");
+      abort();
+    }
+  }
+  return emu::peer(first).a;
+}
+
+template <typename T>
+inline T* uniform_ptr(T* p)
+{
+  return (T*)uniform64((uint64_t)p);
+}
+
+inline uint32_t write_lane(uint32_t vec, uint32_t val, uint32_t lane)
+{
+  return ((uint32_t)lane_id() == lane) ? val : vec;
+}
+
+inline uint32_t shuffle(uint32_t v, uint32_t src_lane)
+{
+  emu::wave_rendezvous(kShuffle, v, src_lane);
+  return (uint32_t)emu::peer((int)(src_lane & 63)).a;
+}
+
+inline uint32_t scan_add_inclusive(uint32_t v)
+{
+  emu::wave_rendezvous(kScan, v, 0);
+  uint32_t s = 0;
+  for (int i = 0; i <= lane_id(); ++i) {
+    s += (uint32_t)emu::peer(i).a;
+  }
+  return s;
+}
+
+inline uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
+inline uint32_t reduce_max(uint32_t v)
+{
+  emu::wave_rendezvous(kMax, v, 0);
+  uint32_t m = 0;
+  for (int i = 0; i < 64; ++i) {
+    m = umax(m, (uint32_t)emu::peer(i).a);
+  }
+  return m;
+}
+
+inline uint32_t reduce_add(uint32_t v)
+{
+  emu::wave_rendezvous(kScan, v, 0);
+  uint32_t s = 0;
+  for (int i = 0; i < 64; ++i) {
+    s += (uint32_t)emu::peer(i).a;
+  }
+  return s;
+}
+
+inline void sync() { emu::wave_rendezvous(kSync, 0, 0); }
+
+inline uint32_t ctz64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
+inline uint32_t popc64(uint64_t m) { return (uint32_t)__builtin_popcountll(m); }
+
+} // namespace wave

@@ -1,0 +1,134 @@
+"""LZ4 batched decompress parity: HIP path (or its host emulation) vs the CPU oracle.
+
+Mirrors the reference's own format pin examples/lz4_cpu_compression.cu:59-74,137
+(CPU-compressed chunks -> nvcompBatchedLZ4DecompressAsync -> byte compare) and the
+round-trip checks of benchmarks/benchmark_template_chunked.cuh:553-584
+(status == nvcompSuccess, actual size == original size, bytes identical).
+"""
+import numpy as np
+import pytest
+
+from nvcomp_amd import datasets
+from nvcomp_amd._lib import NvcompStatus
+
+
+def cpu_compress(oracle, chunks, hc=0):
+    if oracle.have_ref():
+        return [oracle.ref_lz4_compress(c, hc) for c in chunks]
+    return [oracle.lz4_compress(c) for c in chunks]
+
+
+def check_roundtrip(backend, oracle, chunks, comp, **kw):
+    codec = backend.codec("LZ4")
+    caps = [c.size for c in chunks]
+    outs, actual, status = codec.decompress(comp, caps, **kw)
+    if status is not None:
+        assert (status == NvcompStatus.Success).all(), status
+    if actual is not None:
+        assert actual.tolist() == caps
+    for i, (o, c) in enumerate(zip(outs, chunks)):
+        assert np.array_equal(o, c), f"chunk {i} differs"
+    # the oracle agrees on every chunk
+    for cc, c in zip(comp, chunks):
+        rc, ref = oracle.lz4_decompress(cc, c.size)
+        assert rc == 0 and np.array_equal(ref, c)
+
+
+@pytest.mark.parametrize("name", ["text", "table", "float_csv", "float32", "int32", "lowcard", "zeros", "noise"])
+def test_classes_small(backend, oracle, name):
+    size = 3 * 65536 + 1234 if backend.name == "gpu" else 65536 + 777
+    data = datasets.CLASSES[name](size, 1)
+    chunks = datasets.split_chunks(data)
+    check_roundtrip(backend, oracle, chunks, cpu_compress(oracle, chunks))
+
+
+def test_hc_compressed_input(backend, oracle):
+    if not oracle.have_ref():
+        pytest.skip("liblz4 not available")
+    data = datasets.table_rows(2 * 65536, 3)
+    chunks = datasets.split_chunks(data)
+    check_roundtrip(backend, oracle, chunks, cpu_compress(oracle, chunks, hc=12))
+
+
+@pytest.mark.parametrize("checked,want_actual", [(True, True), (False, True), (True, False), (False, False)])
+def test_nullable_outputs(backend, oracle, checked, want_actual):
+    data = datasets.text(40000, 5)
+    chunks = datasets.split_chunks(data, 16384)
+    check_roundtrip(backend, oracle, chunks, cpu_compress(oracle, chunks), checked=checked, want_actual=want_actual)
+
+
+def test_ragged_and_tiny_chunks(backend, oracle):
+    rng = np.random.RandomState(7)
+    sizes = [0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 31, 63, 64, 65, 255, 256, 257, 1000, 4095, 4097]
+    base = datasets.text(8192, 9)
+    chunks = [base[rng.randint(0, 2000):][:s].copy() for s in sizes]
+    comp = cpu_compress(oracle, chunks)
+    # liblz4 turns an empty input into a 1-byte block; also feed a true 0-byte chunk
+    check_roundtrip(backend, oracle, chunks, comp)
+    chunks2 = [np.zeros(0, np.uint8), base[:100].copy()]
+    comp2 = [np.zeros(0, np.uint8), comp[0][:0]]
+    comp2[1] = cpu_compress(oracle, [chunks2[1]])[0]
+    check_roundtrip(backend, oracle, chunks2, comp2)
+
+
+def test_unaligned_everything(backend, oracle):
+    data = datasets.table_rows(30000, 11)
+    chunks = datasets.split_chunks(data, 5000)
+    comp = cpu_compress(oracle, chunks)
+    for mis in (1, 2, 3):
+        check_roundtrip(backend, oracle, chunks, comp, base_misalign=mis)
+
+
+def test_long_matches_and_overlaps(backend, oracle):
+    # periods 1..70 and a few long ones exercise the pattern-doubling match copy
+    parts = []
+    rng = np.random.RandomState(13)
+    for period in list(range(1, 71)) + [100, 255, 256, 257, 1000, 1024, 1025, 3000]:
+        pat = rng.randint(0, 256, size=period).astype(np.uint8)
+        reps = max(2, (rng.randint(50, 3000) // period) + 2)
+        parts.append(np.tile(pat, reps))
+        parts.append(rng.randint(0, 256, size=rng.randint(1, 40)).astype(np.uint8))
+    data = np.concatenate(parts)
+    chunks = datasets.split_chunks(data)
+    check_roundtrip(backend, oracle, chunks, cpu_compress(oracle, chunks))
+
+
+def test_corrupt_streams_do_not_escape(backend, oracle):
+    """Invalid input -> status != success and size 0 (CHANGELOG.md:160-164); never a write
+    outside the output slot (canaries) and, where the oracle accepts, identical bytes."""
+    rng = np.random.RandomState(17)
+    data = datasets.text(20000, 21)
+    chunks = datasets.split_chunks(data, 4096)
+    comp = cpu_compress(oracle, chunks)
+    bad, caps = [], []
+    for c, raw in zip(comp, chunks):
+        b = c.copy()
+        kind = rng.randint(0, 4)
+        if kind == 0:
+            b = b[: rng.randint(1, b.size)]                      # truncated
+        elif kind == 1:
+            b[rng.randint(0, b.size)] ^= 1 << rng.randint(0, 8)  # bit flip
+        elif kind == 2:
+            b = np.concatenate([b, rng.randint(0, 256, size=5).astype(np.uint8)])  # trailing junk
+        else:
+            pass                                                 # valid, but capacity too small
+        bad.append(b)
+        caps.append(raw.size if kind != 3 else raw.size - 1)
+    codec = backend.codec("LZ4")
+    outs, actual, status = codec.decompress(bad, caps)
+    for i, (b, cap) in enumerate(zip(bad, caps)):
+        rc, ref = oracle.lz4_decompress(b, cap)
+        if rc == 0:
+            assert status[i] == NvcompStatus.Success and actual[i] == ref.size
+            assert np.array_equal(outs[i][: ref.size], ref)
+        else:
+            assert status[i] != NvcompStatus.Success and actual[i] == 0
+
+
+def test_get_decompress_size(backend, oracle):
+    data = datasets.silesia_style(4 * 65536, 2, chunk=16384)
+    chunks = datasets.split_chunks(data, 16384) + [np.zeros(0, np.uint8)]
+    comp = cpu_compress(oracle, chunks)
+    sizes = backend.codec("LZ4").get_decompress_size(comp)
+    assert sizes.tolist() == [c.size for c in chunks]
+    assert sizes.tolist() == [oracle.lz4_decompressed_size(c) for c in comp]

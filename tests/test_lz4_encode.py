@@ -1,0 +1,63 @@
+"""LZ4 batched compress parity. The reference pins the compressor only through
+decodability by liblz4 (examples/lz4_cpu_decompression.cu:142-157) and the round
+trip of benchmarks/benchmark_template_chunked.cuh:553-584; both are checked, plus
+the declared worst-case bound and a ratio sanity check against the CPU "fast" class."""
+import numpy as np
+import pytest
+
+from nvcomp_amd import datasets
+
+
+def decode_all(oracle, comp, chunks):
+    for i, (cc, c) in enumerate(zip(comp, chunks)):
+        rc, out = oracle.lz4_decompress(cc, c.size)
+        assert rc == 0 and np.array_equal(out, c), f"oracle rejects chunk {i}"
+        if oracle.have_ref():
+            rc, out = oracle.ref_lz4_decompress(cc, c.size)  # LZ4_decompress_safe
+            assert rc == 0 and np.array_equal(out, c), f"liblz4 rejects chunk {i}"
+
+
+@pytest.mark.parametrize("name", ["text", "table", "float_csv", "float32", "int32", "lowcard", "zeros", "noise"])
+def test_compress_decodes_on_cpu(backend, oracle, name):
+    size = 2 * 65536 + 999 if backend.name == "gpu" else 65536 + 999
+    chunks = datasets.split_chunks(datasets.CLASSES[name](size, 4))
+    codec = backend.codec("LZ4")
+    comp = codec.compress(chunks)
+    decode_all(oracle, comp, chunks)
+    bound = codec.max_compressed_size(65536)
+    assert bound == 65536 + 65536 // 255 + 16
+    assert all(c.size <= bound for c in comp)
+    ours = sum(c.size for c in comp)
+    cpu = sum(oracle.lz4_compress(c).size for c in chunks)
+    assert ours <= cpu * 1.35 + 64, (ours, cpu)
+
+
+def test_compress_tiny_and_ragged(backend, oracle):
+    rng = np.random.RandomState(3)
+    base = datasets.table_rows(9000, 5)
+    sizes = [0, 1, 2, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 63, 64, 65, 66, 127, 128, 129, 300, 4096, 8191]
+    chunks = [base[rng.randint(0, 500):][:s].copy() for s in sizes]
+    comp = backend.codec("LZ4").compress(chunks, in_align=1)
+    decode_all(oracle, comp, chunks)
+
+
+def test_gpu_roundtrip(backend, oracle):
+    chunks = datasets.split_chunks(datasets.silesia_style(6 * 16384, 8, chunk=16384), 16384)
+    codec = backend.codec("LZ4")
+    comp = codec.compress(chunks)
+    outs, actual, status = codec.decompress(comp, [c.size for c in chunks])
+    assert (status == 0).all() and actual.tolist() == [c.size for c in chunks]
+    for o, c in zip(outs, chunks):
+        assert np.array_equal(o, c)
+
+
+def test_opts_validation(backend):
+    import ctypes as C
+
+    from nvcomp_amd._lib import LZ4Opts, NvcompStatus
+
+    lib = backend.lib
+    out = C.c_size_t(0)
+    assert lib.nvcompBatchedLZ4CompressGetMaxOutputChunkSize(65536, LZ4Opts(7), C.byref(out)) == NvcompStatus.ErrorInvalidValue
+    assert lib.nvcompBatchedLZ4CompressGetMaxOutputChunkSize(65536, LZ4Opts(0xFF), C.byref(out)) == NvcompStatus.Success
+    assert lib.nvcompBatchedLZ4CompressGetTempSize(10, 1 << 25, LZ4Opts(0), C.byref(out)) == NvcompStatus.ErrorChunkSizeTooLarge

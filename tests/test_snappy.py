@@ -1,0 +1,199 @@
+"""Snappy batched codec parity: HIP path (or its host emulation) vs the CPU oracle
+and libsnappy. The reference only round-trips Snappy
+(benchmarks/benchmark_snappy_synth.cpp:286-295); BASELINE.json's north_star adds
+bit-exactness against the snappy CPU decoder, and CHANGELOG.md:182-184 requires
+that legal streams its own compressor never emits still decode."""
+import numpy as np
+import pytest
+
+from nvcomp_amd import datasets
+from nvcomp_amd._lib import NvcompStatus
+
+
+def cpu_compress(oracle, chunks):
+    if oracle.have_ref():
+        return [oracle.ref_snappy_compress(c) for c in chunks]
+    return [oracle.snappy_compress(c) for c in chunks]
+
+
+def check_decode(backend, oracle, chunks, comp, **kw):
+    codec = backend.codec("Snappy")
+    caps = [c.size for c in chunks]
+    outs, actual, status = codec.decompress(comp, caps, **kw)
+    if status is not None:
+        assert (status == NvcompStatus.Success).all(), status
+    if actual is not None:
+        assert actual.tolist() == caps
+    for i, (o, c, cc) in enumerate(zip(outs, chunks, comp)):
+        assert np.array_equal(o, c), f"chunk {i} differs"
+        rc, ref = oracle.snappy_decompress(cc, c.size)
+        assert rc == 0 and np.array_equal(ref, c)
+
+
+@pytest.mark.parametrize("name", ["text", "table", "float_csv", "float32", "int32", "lowcard", "zeros", "noise"])
+def test_decode_classes(backend, oracle, name):
+    size = 3 * 65536 + 4321 if backend.name == "gpu" else 65536 + 321
+    chunks = datasets.split_chunks(datasets.CLASSES[name](size, 2))
+    check_decode(backend, oracle, chunks, cpu_compress(oracle, chunks))
+
+
+def test_reference_synth_workload(backend, oracle):
+    """benchmark_snappy_synth: 64 KiB chunks of uniform bytes in [0,3], the same device array
+    passed as capacity and as actual-size output (benchmarks/benchmark_snappy_synth.cpp:244-245)."""
+    n = 8 if backend.name == "gpu" else 2
+    chunks = datasets.split_chunks(datasets.gen_data(3, n * 65536, 0))
+    comp = cpu_compress(oracle, chunks)
+    from nvcomp_amd.batched import empty_batch, make_batch, read_batch
+
+    d = backend.dev
+    codec = backend.codec("Snappy")
+    cb = make_batch(d, comp, align=1)
+    ob = empty_batch(d, [65536] * n, stride=65536)
+    statuses = d.upload(np.full(n, -1, dtype=np.int32).view(np.uint8))
+    rc = codec.decompress_async(cb, ob, ob.sizes, statuses, None, 0)  # actual aliases capacities
+    d.synchronize()
+    assert rc == 0
+    assert (d.download(statuses).view(np.int32)[:n] == 0).all()
+    assert d.download(ob.sizes).view(np.uint64)[:n].tolist() == [65536] * n
+    for o, c in zip(read_batch(d, ob), chunks):
+        assert np.array_equal(o, c)
+
+
+def _lit(data):
+    n = len(data) - 1
+    if n < 60:
+        return bytes([n << 2]) + bytes(data)
+    nb = (n.bit_length() + 7) // 8
+    return bytes([(59 + nb) << 2]) + n.to_bytes(nb, "little") + bytes(data)
+
+
+def _varint(v):
+    out = b""
+    while v >= 128:
+        out += bytes([(v & 127) | 128])
+        v >>= 7
+    return out + bytes([v])
+
+
+def test_every_element_kind(backend, oracle):
+    """Hand-built legal streams: copy-1, copy-2, copy-4, 1..4-byte literal lengths,
+    overlapping copies with offsets 1, 2, 3, copies of length 1..3 (copy-2 form)."""
+    rng = np.random.RandomState(5)
+    streams, raws = [], []
+    # A: literal + copy1 + copy2 + copy4 + overlaps
+    lit = rng.randint(0, 256, size=100).astype(np.uint8).tobytes()
+    body = _lit(lit)
+    raw = bytearray(lit)
+
+    def copy(kind, off, ln):
+        nonlocal body
+        if kind == 1:
+            assert 4 <= ln <= 11 and off < 2048
+            body += bytes([1 | ((ln - 4) << 2) | ((off >> 8) << 5), off & 255])
+        elif kind == 2:
+            body += bytes([2 | ((ln - 1) << 2)]) + off.to_bytes(2, "little")
+        else:
+            body += bytes([3 | ((ln - 1) << 2)]) + off.to_bytes(4, "little")
+        for _ in range(ln):
+            raw.append(raw[-off])
+
+    copy(1, 10, 7)
+    copy(2, 50, 64)
+    copy(3, 100, 33)
+    copy(2, 1, 64)   # run of one byte
+    copy(2, 2, 63)
+    copy(2, 3, 5)
+    copy(2, 7, 1)
+    copy(2, 9, 2)
+    copy(2, 11, 3)
+    copy(1, 4, 11)
+    body += _lit(b"xyz")
+    raw += b"xyz"
+    copy(3, len(raw), 64)  # offset == everything produced so far
+    streams.append(_varint(len(raw)) + body)
+    raws.append(bytes(raw))
+    # B: literals with 1-, 2- and 3-byte length fields
+    parts, raw2 = b"", b""
+    for ln in (60, 61, 255, 256, 257, 4000, 70000):
+        blk = rng.randint(0, 256, size=ln).astype(np.uint8).tobytes()
+        parts += _lit(blk)
+        raw2 += blk
+    streams.append(_varint(len(raw2)) + parts)
+    raws.append(raw2)
+    # C: 4-byte literal length field, written non-minimally (legal)
+    blk = rng.randint(0, 256, size=300).astype(np.uint8).tobytes()
+    streams.append(_varint(300) + bytes([63 << 2]) + (299).to_bytes(4, "little") + blk)
+    raws.append(blk)
+    # D: empty buffer = preamble only
+    streams.append(_varint(0))
+    raws.append(b"")
+    chunks = [np.frombuffer(r, dtype=np.uint8) for r in raws]
+    comp = [np.frombuffer(s, dtype=np.uint8) for s in streams]
+    if oracle.have_ref():
+        for s, r in zip(comp, chunks):
+            rc, out = oracle.ref_snappy_decompress(s, max(r.size, 1))
+            assert rc == 0 and np.array_equal(out, r), "hand-built stream is not legal snappy"
+    check_decode(backend, oracle, chunks, comp)
+    sizes = backend.codec("Snappy").get_decompress_size(comp)
+    assert sizes.tolist() == [c.size for c in chunks]
+
+
+def test_corrupt_streams(backend, oracle):
+    rng = np.random.RandomState(23)
+    chunks = datasets.split_chunks(datasets.table_rows(24000, 4), 4000)
+    comp = cpu_compress(oracle, chunks)
+    bad, caps = [], []
+    for c, raw in zip(comp, chunks):
+        b = c.copy()
+        kind = rng.randint(0, 5)
+        if kind == 0:
+            b = b[: rng.randint(1, b.size)]
+        elif kind == 1:
+            b[rng.randint(0, b.size)] ^= 1 << rng.randint(0, 8)
+        elif kind == 2:
+            b = np.concatenate([b, rng.randint(0, 256, size=3).astype(np.uint8)])
+        elif kind == 3:
+            b[0] ^= 1  # preamble disagrees with the elements
+        bad.append(b)
+        caps.append(raw.size if kind != 4 else raw.size - 1)
+    outs, actual, status = backend.codec("Snappy").decompress(bad, caps)
+    for i, (b, cap) in enumerate(zip(bad, caps)):
+        rc, ref = oracle.snappy_decompress(b, cap)
+        if rc == 0:
+            assert status[i] == NvcompStatus.Success and actual[i] == ref.size
+            assert np.array_equal(outs[i][: ref.size], ref)
+        else:
+            assert status[i] != NvcompStatus.Success and actual[i] == 0
+
+
+@pytest.mark.parametrize("name", ["text", "table", "float_csv", "float32", "int32", "lowcard", "zeros", "noise"])
+def test_compress_decodes_on_cpu(backend, oracle, name):
+    size = 2 * 65536 + 77 if backend.name == "gpu" else 65536 + 77
+    chunks = datasets.split_chunks(datasets.CLASSES[name](size, 6))
+    codec = backend.codec("Snappy")
+    comp = codec.compress(chunks)
+    bound = codec.max_compressed_size(65536)
+    assert bound == 32 + 65536 + 65536 // 6
+    for cc, c in zip(comp, chunks):
+        assert cc.size <= bound
+        rc, out = oracle.snappy_decompress(cc, c.size)
+        assert rc == 0 and np.array_equal(out, c)
+        if oracle.have_ref():
+            rc, out = oracle.ref_snappy_decompress(cc, c.size)  # snappy::RawUncompress
+            assert rc == 0 and np.array_equal(out, c)
+    ours = sum(c.size for c in comp)
+    cpu = sum(oracle.snappy_compress(c).size for c in chunks)
+    assert ours <= cpu * 1.35 + 64, (ours, cpu)
+
+
+def test_roundtrip_ragged(backend, oracle):
+    rng = np.random.RandomState(9)
+    base = datasets.text(9000, 3)
+    sizes = [0, 1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 127, 128, 1000, 8000]
+    chunks = [base[rng.randint(0, 500):][:s].copy() for s in sizes]
+    codec = backend.codec("Snappy")
+    comp = codec.compress(chunks, in_align=1)
+    outs, actual, status = codec.decompress(comp, [max(c.size, 0) for c in chunks])
+    assert (status == 0).all() and actual.tolist() == [c.size for c in chunks]
+    for o, c in zip(outs, chunks):
+        assert np.array_equal(o, c)
