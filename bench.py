@@ -1,0 +1,369 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path's headline metric on MI355X.
+
+One "step" = one nvcompBatched<Algo>DecompressAsync call over the whole batch,
+issued exactly as the reference's harness does it
+(benchmarks/benchmark_template_chunked.cuh:519-536: events around a single
+*Async call, statuses and actual sizes non-null) with the inputs already
+resident in HBM. Throughput = uncompressed bytes / time
+(benchmark_template_chunked.cuh:603-607).
+
+Workload at N=1 = BASELINE.json configs[1]: "LZ4 batched decompress on
+1xMI355X: CPU-compressed 64 KiB chunks": a Silesia-style synthetic mix
+(nvcomp_amd/datasets.py), cut into 64 KiB chunks, compressed on the host with
+liblz4's LZ4_compress_HC level 12 (the producer the reference's own example
+uses, examples/lz4_cpu_compression.cu:61-66), `--unique-mib` MiB of unique data
+replicated into distinct device memory up to `--mib-per-gpu` (the reference's
+-x duplication, benchmark_template_chunked.cuh:340-353).
+
+N>1: one process per GPU (torch.distributed / RCCL only for the barrier and the
+max-over-ranks); every rank decodes its own shard of the batch, no data-path
+collective: weak scaling. `--allgather` adds the benchmark_allgather.cpp
+exchange (compress shard -> all-gather compressed bytes -> decode remote shards).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling is ~6300
+CHUNK = 1 << 16
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--algo", choices=["lz4", "snappy"], default="lz4")
+    p.add_argument("--mib-per-gpu", type=int, default=1024, help="uncompressed MiB decoded per GPU per step")
+    p.add_argument("--unique-mib", type=int, default=64, help="unique MiB generated + CPU-compressed per rank")
+    p.add_argument("--dataset", default="silesia_style")
+    p.add_argument("--producer", choices=["hc", "fast", "port"], default="hc",
+                   help="CPU compressor making the inputs: liblz4 HC-12 / liblz4 default / oracle port")
+    p.add_argument("--unchecked", action="store_true", help="statuses=NULL fast path (reported separately)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extras", action="store_true", help="skip the GPU compress leg (ratio / compress GB/s)")
+    p.add_argument("--allgather", action="store_true", help="benchmark_allgather.cpp path (N >= 2)")
+    p.add_argument("--dry-run-emu", action="store_true",
+                   help="CPU-only self-test of this script's plumbing against tests/emu (prints value=null)")
+    return p.parse_args()
+
+
+def cpu_compress(oracle, algo, chunks, producer, threads):
+    """Host-side producer of the compressed inputs (outside every timed region)."""
+    caps = None
+    if producer != "port" and oracle.have_ref():
+        if algo == "lz4":
+            codec = oracle.LZ4_ENC_HC if producer == "hc" else oracle.LZ4_ENC
+            caps = [oracle.lz4_bound(c.size) + 64 for c in chunks]
+        else:
+            codec = oracle.SNAPPY_ENC
+            caps = [oracle.snappy_bound(c.size) + 64 for c in chunks]
+        _, outs, errs = oracle.batch_run(codec, chunks, caps, threads=threads, use_ref=True)
+        assert errs == 0
+        return [o.copy() for o in outs], ("liblz4 LZ4_compress_HC(12)" if codec == oracle.LZ4_ENC_HC else
+                                          "liblz4 LZ4_compress_default" if algo == "lz4" else "libsnappy")
+    codec = oracle.LZ4_ENC if algo == "lz4" else oracle.SNAPPY_ENC
+    bound = oracle.lz4_bound if algo == "lz4" else oracle.snappy_bound
+    _, outs, errs = oracle.batch_run(codec, chunks, [bound(c.size) for c in chunks], threads=threads)
+    assert errs == 0
+    return [o.copy() for o in outs], "oracle port (greedy)"
+
+
+class TorchRuntime:
+    """Streams, events, barrier and max-over-ranks on the real GPU(s)."""
+
+    def __init__(self, torch, dist, dev):
+        self.torch, self.dist, self.dev = torch, dist, dev
+
+    def repeat(self, buf, k):
+        return buf.repeat(k)
+
+    def event(self):
+        return self.torch.cuda.Event(enable_timing=True)
+
+    def barrier_sync(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        if self.dist is None:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.dev.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def equal(self, a, b):
+        return bool(self.torch.equal(a, b))
+
+    def shutdown(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+class EmuRuntime:
+    """--dry-run-emu only: wall-clock 'events', numpy buffers."""
+
+    class _Event:
+        def record(self):
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+
+    def repeat(self, buf, k):
+        return np.tile(buf, k)
+
+    def event(self):
+        return EmuRuntime._Event()
+
+    def barrier_sync(self):
+        pass
+
+    def max_over_ranks(self, seconds):
+        return seconds
+
+    def equal(self, a, b):
+        return bool(np.array_equal(a, b))
+
+    def shutdown(self):
+        pass
+
+
+def setup_runtime(args):
+    """Process-wide state: ranks, device, library. Returns a context dict."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    import nvcomp_amd
+    from nvcomp_amd import datasets
+    from nvcomp_amd.batched import DeviceBatch
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.dry_run_emu:
+        # plumbing self-test only: numpy "device", kernels compiled for the host (tests/emu)
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        import conftest as emu_conftest
+
+        lib, dev = emu_conftest.emu_library(), emu_conftest.HostDevice()
+        rt = EmuRuntime()
+    else:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", rank=rank, world_size=world)
+        lib = nvcomp_amd.load_library()  # raises when the HIP library is missing
+        dev = nvcomp_amd.TorchDevice(f"cuda:{local_rank}")
+        rt = TorchRuntime(torch, dist if world > 1 else None, dev)
+    return {"rank": rank, "world": world, "lib": lib, "dev": dev, "rt": rt}
+
+
+def run_case(args, ctx):
+    """Build the batch, time `steps` decompress calls, verify, return the result dict (rank 0: full)."""
+    import nvcomp_amd
+    from nvcomp_amd import datasets
+    from nvcomp_amd.batched import DeviceBatch
+
+    rank, world, lib, dev, rt = ctx["rank"], ctx["world"], ctx["lib"], ctx["dev"], ctx["rt"]
+    fmt = "LZ4" if args.algo == "lz4" else "Snappy"
+    codec = nvcomp_amd.BatchedCodec(lib, dev, fmt)
+    threads = len(os.sched_getaffinity(0))
+
+    # ---- build the batch (untimed) ----
+    from oracle import oracle_py as oracle  # producer of inputs + cpu_baseline checker only
+
+    oracle.build()
+    unique = args.unique_mib << 20
+    gen = getattr(datasets, args.dataset) if hasattr(datasets, args.dataset) else datasets.CLASSES[args.dataset]
+    data = gen(unique, rank)
+    chunks = datasets.split_chunks(data, CHUNK)
+    comp, producer = cpu_compress(oracle, args.algo, chunks, args.producer, threads)
+    n_unique = len(chunks)
+    replicas = max(1, (args.mib_per_gpu << 20) // unique)
+    n = n_unique * replicas
+    comp_sizes = np.array([c.size for c in comp], dtype=np.uint64)
+    comp_offs = np.zeros(n_unique, dtype=np.uint64)
+    comp_offs[1:] = np.cumsum(comp_sizes)[:-1]  # tight-packed, unaligned (examples/BatchData.h:97-103)
+    comp_total = int(comp_sizes.sum())
+    comp_host = np.concatenate(comp)
+    raw_sizes = np.array([c.size for c in chunks], dtype=np.uint64)
+    raw_offs = np.arange(n_unique, dtype=np.uint64) * np.uint64(CHUNK)
+
+    comp_slab = rt.repeat(dev.upload(comp_host), replicas)  # distinct device memory per replica
+    out_slab = dev.empty(unique * replicas)
+    base_dev = dev.upload(data)
+
+    def tile(offs, stride_bytes, base_ptr):
+        rep = (np.arange(replicas, dtype=np.uint64) * np.uint64(stride_bytes))[:, None]
+        return (offs[None, :] + rep + np.uint64(base_ptr)).reshape(-1)
+
+    comp_batch = DeviceBatch(
+        comp_slab, dev.upload(tile(comp_offs, comp_total, dev.ptr(comp_slab)).view(np.uint8)),
+        dev.upload(np.tile(comp_sizes, replicas).view(np.uint8)), None, np.tile(comp_sizes, replicas), n)
+    out_batch = DeviceBatch(
+        out_slab, dev.upload(tile(raw_offs, unique, dev.ptr(out_slab)).view(np.uint8)),
+        dev.upload(np.tile(raw_sizes, replicas).view(np.uint8)), None, np.tile(raw_sizes, replicas), n)
+    actual = dev.upload(np.zeros(n, dtype=np.uint64).view(np.uint8))
+    statuses = None if args.unchecked else dev.upload(np.full(n, -1, dtype=np.int32).view(np.uint8))
+    tb = codec.decompress_temp_size(n, CHUNK)
+    temp = dev.empty(tb) if tb else None
+
+    def step():
+        rc = codec.decompress_async(comp_batch, out_batch, actual, statuses, temp, tb)
+        if rc != 0:
+            raise RuntimeError(f"nvcompBatched{fmt}DecompressAsync returned {rc}")
+
+    # ---- timed region ----
+    for _ in range(args.warmup):
+        step()
+    rt.barrier_sync()
+    ev0, ev1 = rt.event(), rt.event()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    rt.barrier_sync()
+    elapsed = rt.max_over_ranks(time.perf_counter() - t0)
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
+
+    # ---- verification (untimed): statuses, sizes, every output byte ----
+    if statuses is not None:
+        st = dev.download(statuses).view(np.int32)[:n]
+        assert (st == 0).all(), f"{int((st != 0).sum())} chunks failed"
+    act = dev.download(actual).view(np.uint64)[:n]
+    assert (act == np.tile(raw_sizes, replicas)).all(), "actual sizes differ from the originals"
+    for r in range(replicas):
+        assert rt.equal(out_slab[r * unique: (r + 1) * unique], base_dev[:unique]), f"replica {r} differs"
+
+    total_raw = unique * replicas
+    total_comp = comp_total * replicas
+    value = world * total_raw * args.steps / elapsed / 1e9
+    algorithmic = total_comp + total_raw + 44 * n  # C + U + 44 B of metadata per chunk
+    achieved = algorithmic / (kernel_ms * 1e-3) / 1e9
+
+    result = {
+        "metric": f"decompress GB/s ({args.algo}, 64 KiB chunks)",
+        "value": round(value, 3),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{fmt} batched decompress, CPU-compressed 64 KiB chunks (BASELINE.json configs[1])",
+            "dataset": args.dataset,
+            "producer": producer,
+            "chunk_bytes": CHUNK,
+            "chunks_per_gpu": n,
+            "uncompressed_bytes_per_gpu": total_raw,
+            "compressed_bytes_per_gpu": total_comp,
+            "ratio": round(total_raw / total_comp, 4),
+            "unique_bytes": unique,
+            "statuses": "checked" if statuses is not None else "null (unchecked fast path)",
+            "sharding": "chunks partitioned across ranks, no collective" if world > 1 else "single GPU",
+        },
+    }
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                rec = json.load(open(tpath))
+                if rec.get("algo") == args.algo and rec.get("chunks_per_gpu") == n and rec.get("dataset") == args.dataset:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result["roofline"] = {
+            "bound": "hbm",
+            "kernel": f"{args.algo}_decompress_kernel",
+            "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "algorithmic_bytes_per_launch": int(algorithmic),
+            "kernel_ms": round(kernel_ms, 4),
+            "traffic": traffic,
+        }
+    if rank == 0 and world == 1 and not args.no_extras:
+        # compress leg on the GPU (ratio + compress GB/s of the metric string); not part of `value`
+        from nvcomp_amd.batched import empty_batch
+
+        max_out = codec.max_compressed_size(CHUNK)
+        k = min(n, 4096)
+        src = DeviceBatch(out_slab, out_batch.ptrs, out_batch.sizes, None, out_batch.host_sizes[:k], k)
+        dst = empty_batch(dev, [max_out] * k, stride=max_out)
+        ctb = codec.compress_temp_size(k, CHUNK)
+        ctemp = dev.empty(ctb) if ctb else None
+        codec.compress_async(src, dst, CHUNK, ctemp, ctb)
+        rt.barrier_sync()
+        c0, c1 = rt.event(), rt.event()
+        c0.record()
+        for _ in range(5):
+            codec.compress_async(src, dst, CHUNK, ctemp, ctb)
+        c1.record()
+        rt.barrier_sync()
+        csz = dev.download(dst.sizes).view(np.uint64)[:k]
+        raw_k = int(out_batch.host_sizes[:k].sum())
+        result["extras"] = {
+            "gpu_compress_GBps": round(raw_k * 5 / (c0.elapsed_time(c1) * 1e-3) / 1e9, 3),
+            "gpu_compress_ratio": round(raw_k / int(csz.sum()), 4),
+            "gpu_compress_chunks": k,
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # The reference's CPU path (liblz4 / snappy decoders) on this box's host cores over a
+        # bounded sample of the same chunk arrays: the unique set, best of 5.
+        use_ref = oracle.have_ref()
+        code = oracle.LZ4_DEC if args.algo == "lz4" else oracle.SNAPPY_DEC
+        secs, outs, errs = oracle.batch_run(code, comp, [c.size for c in chunks], threads=threads, repeats=5,
+                                            use_ref=use_ref)
+        assert errs == 0 and all(o.size == c.size for o, c in zip(outs, chunks))
+        result["cpu_baseline"] = {
+            "value": round(unique / secs / 1e9, 3),
+            "unit": "GB/s",
+            "cores": threads,
+            "kind": "reference" if use_ref else "port",
+            "sample": f"{unique >> 20} MiB ({n_unique} chunks) of the same workload, best of 5, "
+                      + ("liblz4 LZ4_decompress_safe" if (use_ref and args.algo == "lz4") else
+                         "libsnappy RawUncompress" if use_ref else "oracle/ C port"),
+        }
+    if args.dry_run_emu:
+        result["value"] = None
+        result["data"] = "DRY RUN on the CPU emulation of the kernels: not a measurement"
+    return result
+
+
+def main():
+    args = parse_args()
+    ctx = setup_runtime(args)
+    result = run_case(args, ctx)
+    if ctx["rank"] == 0:
+        print(json.dumps(result), flush=True)
+    ctx["rt"].shutdown()
+
+
+if __name__ == "__main__":
+    main()
