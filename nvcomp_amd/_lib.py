@@ -104,4 +104,11 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         raise RuntimeError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). nvcomp_amd has no CPU fallback.")
+    # The torch wheel bundles its own HIP runtime (torch/lib/libamdhip64.so). Device
+    # pointers and streams handed to libnvcomp.so come from torch, so torch's runtime
+    # must be the one already resident when libnvcomp.so resolves its libamdhip64
+    # dependency; loading in the other order puts two runtimes in one process and
+    # every launch on a torch stream fails (seen on MI355X as hipError -> status 1000).
+    import torch  # noqa: F401
+
     return declare(C.CDLL(path))

@@ -110,6 +110,14 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lz4_compress_kernel(
   }
 }
 
+/* hipGetLastError() is sticky per host thread: an unrelated earlier runtime call
+ * of the application (e.g. a failed pointer-attribute query) must not be
+ * reported as this launch's failure, so the slate is cleared before launching. */
+void clear_stale_error()
+{
+  (void)hipGetLastError();
+}
+
 nvcompStatus_t launch_status()
 {
   return hipGetLastError() == hipSuccess ? nvcompSuccess : nvcompErrorCudaError;
@@ -164,11 +172,13 @@ nvcompStatus_t nvcompBatchedLZ4DecompressAsync(
       || device_uncompressed_ptrs == nullptr) {
     return nvcompErrorInvalidValue;
   }
+  clear_stale_error();
   const dim3 grid(grid_for(batch_size));
   const dim3 block(64 * kWavesPerBlock);
   const bool checked = device_statuses != nullptr;
   const bool serial = lz4_decode_variant() == 1;
 #define NVCOMP_LZ4_LAUNCH(C, P)                                                                               \
+  clear_stale_error();
   hipLaunchKernelGGL((lz4_decompress_kernel<C, P>), grid, block, 0, stream, device_compressed_ptrs,           \
                      device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,   \
                      batch_size, device_uncompressed_ptrs, device_statuses)
@@ -202,6 +212,7 @@ nvcompStatus_t nvcompBatchedLZ4GetDecompressSizeAsync(
   if (device_compressed_ptrs == nullptr || device_compressed_bytes == nullptr || device_uncompressed_bytes == nullptr) {
     return nvcompErrorInvalidValue;
   }
+  clear_stale_error();
   hipLaunchKernelGGL(lz4_decompress_size_kernel, dim3(grid_for(batch_size)), dim3(64 * kWavesPerBlock), 0, stream,
                      device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes, batch_size);
   return launch_status();
@@ -269,6 +280,7 @@ nvcompStatus_t nvcompBatchedLZ4CompressAsync(
       || device_compressed_bytes == nullptr) {
     return nvcompErrorInvalidValue;
   }
+  clear_stale_error();
   hipLaunchKernelGGL(lz4_compress_kernel, dim3(grid_for(batch_size)), dim3(64 * kWavesPerBlock), 0, stream,
                      device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
                      device_compressed_bytes);

@@ -47,6 +47,7 @@ __global__ void __launch_bounds__(64) wave_selftest_kernel(const uint32_t* in, u
 extern "C" nvcompStatus_t nvcompAmdSelfTestWave(const uint32_t* device_in64, uint32_t* device_out640,
                                                  uint8_t* device_scratch4096, hipStream_t stream)
 {
+  (void)hipGetLastError(); /* drop stale sticky errors of earlier, unrelated runtime calls */
   hipLaunchKernelGGL(wave_selftest_kernel, dim3(1), dim3(64), 0, stream, device_in64, device_out640,
                      device_scratch4096);
   return hipGetLastError() == hipSuccess ? nvcompSuccess : nvcompErrorCudaError;

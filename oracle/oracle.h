@@ -32,6 +32,12 @@ int oracle_snappy_decompressed_size(const uint8_t* src, size_t src_len, size_t* 
 size_t oracle_snappy_compress_bound(size_t n);
 size_t oracle_snappy_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t dst_cap);
 
+/* Cascaded (oracle/cascaded_ref.c; own container, parity unpinned) */
+size_t oracle_cascaded_max_compressed(size_t n_bytes, size_t sub_chunk_bytes, int type);
+size_t oracle_cascaded_compress(const uint8_t* src, size_t n_bytes, uint8_t* dst, size_t dst_cap, size_t sub_chunk_bytes,
+                                int type, int num_rles, int num_deltas, int use_bp);
+int oracle_cascaded_decompress(const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_cap, size_t* out_len);
+
 /* Batched, threaded drivers used for the cpu_baseline timing (oracle/batch.c).
  * codec: 0 = lz4 decompress, 1 = snappy decompress, 2 = lz4 compress, 3 = snappy compress.
  * Returns wall seconds of the best of `repeats` runs; per-chunk result sizes in out_sizes. */

@@ -175,6 +175,25 @@ def snappy_bound(n: int) -> int:
     return int(lib().port.oracle_snappy_compress_bound(n))
 
 
+def cascaded_compress(raw, sub_chunk: int = 4096, type_: int = 4, num_rles: int = 2, num_deltas: int = 1,
+                      use_bp: int = 1) -> np.ndarray:
+    p = lib().port
+    src = _as_u8(raw)
+    cap = int(p.oracle_cascaded_max_compressed(src.size, sub_chunk, type_))
+    dst = np.zeros(max(cap, 1), dtype=np.uint8)
+    n = p.oracle_cascaded_compress(_ptr(src), src.size, _ptr(dst), cap, sub_chunk, type_, num_rles, num_deltas, use_bp)
+    assert n > 0, "oracle_cascaded_compress rejected its arguments"
+    return dst[:n].copy()
+
+
+def cascaded_decompress(comp, cap: int) -> Tuple[int, np.ndarray]:
+    return _dec(lib().port.oracle_cascaded_decompress, comp, cap)
+
+
+def cascaded_bound(n: int, sub_chunk: int = 4096, type_: int = 4) -> int:
+    return int(lib().port.oracle_cascaded_max_compressed(n, sub_chunk, type_))
+
+
 # ------------------------------------------------- liblz4 / libsnappy ("reference")
 
 def ref_lz4_decompress(comp, cap: int) -> Tuple[int, np.ndarray]:
