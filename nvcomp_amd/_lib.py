@@ -99,7 +99,9 @@ def declare(lib: C.CDLL, formats=("LZ4", "Snappy", "Cascaded")) -> C.CDLL:
 
 
 def load_library(path: str = LIB_PATH) -> C.CDLL:
-    """Load the HIP library. Raises if it has not been built: there is no fallback."""
+    """Load the HIP library. Raises if it has not been built: there is no fallback.
+    NVCOMP_AMD_LIB selects an alternative build of the same HIP library (A/B tuning builds)."""
+    path = os.environ.get("NVCOMP_AMD_LIB", path)
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -10,6 +10,7 @@
 #include "nvcomp/snappy.h"
 
 #include "snappy/snappy_decode.hip.h"
+#include "snappy/snappy_decode_window.hip.h"
 #include "snappy/snappy_encode.hip.h"
 
 namespace {
@@ -17,15 +18,60 @@ namespace {
 constexpr unsigned kWavesPerBlock = 4; /* 256-thread workgroups, one chunk per wave */
 constexpr uint32_t kMaxOutCap = 1u << 26;
 
-/* Kernel variant switch for A/B measurements (bench.py --variant):
- * NVCOMP_AMD_SNAPPY_DECODE=serial selects the one-sequence-per-step baseline. */
+/* Kernel variant switch for A/B measurements: NVCOMP_AMD_SNAPPY_DECODE =
+ *   window (default) LDS-staged sequence-parallel decoder (snappy_decode_window.hip.h)
+ *   direct           sequence-parallel, decoding straight to HBM (snappy_decode.hip.h)
+ *   serial           one sequence per step, whole-wave copies (ablation baseline) */
 int snappy_decode_variant()
 {
   static const int v = [] {
     const char* e = getenv("NVCOMP_AMD_SNAPPY_DECODE");
-    return (e != nullptr && e[0] == 's') ? 1 : 0;
+    if (e == nullptr) {
+      return 0;
+    }
+    return e[0] == 'd' ? 1 : e[0] == 's' ? 2 : 0;
   }();
   return v;
+}
+
+template <bool CHECKED>
+__global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZW_WAVES_PER_SIMD) snappy_decompress_window_kernel(
+    const void* const* __restrict__ comp_ptrs,
+    const size_t* __restrict__ comp_bytes,
+    const size_t* out_caps,
+    size_t* actual_bytes,
+    size_t batch_size,
+    void* const* __restrict__ out_ptrs,
+    nvcompStatus_t* statuses)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][lzw::kLdsPerWave];
+  const uint32_t w = wave::uniform(threadIdx.x >> 6);
+  const size_t chunk = (size_t)blockIdx.x * kWavesPerBlock + w;
+  if (chunk >= batch_size) {
+    return;
+  }
+  const uint8_t* in = wave::uniform_ptr((const uint8_t*)comp_ptrs[chunk]);
+  uint8_t* out = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
+  const size_t in_len64 = wave::uniform64(comp_bytes[chunk]);
+  size_t cap64 = wave::uniform64(out_caps[chunk]);
+  if (cap64 > kMaxOutCap) {
+    cap64 = kMaxOutCap;
+  }
+  uint32_t err = lz::kErrNone;
+  uint32_t produced = 0;
+  if (in_len64 > 0xffffffffull - 64) {
+    err = lz::kErrInput;
+  } else {
+    produced = snappyw::decode_chunk<CHECKED>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds[w], err);
+  }
+  if (wave::lane_id() == 0) {
+    if (actual_bytes != nullptr) {
+      actual_bytes[chunk] = err ? 0 : produced;
+    }
+    if (CHECKED) {
+      statuses[chunk] = err ? nvcompErrorCannotDecompress : nvcompSuccess;
+    }
+  }
 }
 
 template <bool CHECKED, bool LANE_PARALLEL>
@@ -176,9 +222,21 @@ nvcompStatus_t nvcompBatchedSnappyDecompressAsync(
   const dim3 grid(grid_for(batch_size));
   const dim3 block(64 * kWavesPerBlock);
   const bool checked = device_statuses != nullptr;
-  const bool serial = snappy_decode_variant() == 1;
+  const int variant = snappy_decode_variant();
+  const bool serial = variant == 2;
+  if (variant == 0) {
+    if (checked) {
+      hipLaunchKernelGGL((snappy_decompress_window_kernel<true>), grid, block, 0, stream, device_compressed_ptrs,
+                         device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,
+                         batch_size, device_uncompressed_ptrs, device_statuses);
+    } else {
+      hipLaunchKernelGGL((snappy_decompress_window_kernel<false>), grid, block, 0, stream, device_compressed_ptrs,
+                         device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,
+                         batch_size, device_uncompressed_ptrs, device_statuses);
+    }
+    return launch_status();
+  }
 #define NVCOMP_SNAPPY_LAUNCH(C, P)                                                                               \
-  clear_stale_error();
   hipLaunchKernelGGL((snappy_decompress_kernel<C, P>), grid, block, 0, stream, device_compressed_ptrs,           \
                      device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,   \
                      batch_size, device_uncompressed_ptrs, device_statuses)

@@ -1,0 +1,532 @@
+/*
+ * common/lz_window.hip.h -- LDS-staged, sequence-parallel LZ77 batch executor
+ * shared by the LZ4 and Snappy decoders (one wavefront per chunk).
+ *
+ * Measured on MI355X (profiles/r01_v1_direct_pmc.json): decoding straight to
+ * HBM leaves a wave waiting on memory 62 % of its cycles -- every literal/match
+ * step is a dependent global load->store round trip -- and reads 10x the
+ * algorithmic bytes (partial-line writes and far match sources miss the L2).
+ * So everything a sequence can depend on is kept in the CU's LDS:
+ *
+ *   input ring   (kInRing bytes)  the compressed stream, loaded from HBM in
+ *                1 KiB blocks of 16-byte lane loads, ahead of the token chase;
+ *   output window (kOutWin bytes) a linear window over the most recent output.
+ *                Literals and matches are assembled here; a match whose source
+ *                is still inside the window never touches HBM. After every
+ *                batch the new bytes are flushed to HBM with 16-byte aligned,
+ *                fully coalesced stores, and when the window fills up its last
+ *                kKeep bytes slide to the front.
+ *
+ * Only matches that reach further back than the window ("far") read HBM, all of
+ * a batch's far reads being issued together before the LDS work starts.
+ */
+#pragma once
+
+#include "common/lz_common.hip.h"
+
+namespace lzw {
+
+/* Tunables (overridable with -D for the A/B builds of scripts/build_variants.sh). */
+#ifndef NVCOMP_LZW_OUTWIN
+#define NVCOMP_LZW_OUTWIN 8192
+#endif
+#ifndef NVCOMP_LZW_BATCHMAX
+#define NVCOMP_LZW_BATCHMAX (NVCOMP_LZW_OUTWIN / 4)
+#endif
+#ifndef NVCOMP_LZW_KEEP
+#define NVCOMP_LZW_KEEP (NVCOMP_LZW_OUTWIN / 2)
+#endif
+#ifndef NVCOMP_LZW_INRING
+#define NVCOMP_LZW_INRING 4096
+#endif
+#ifndef NVCOMP_LZW_WAVES_PER_SIMD
+#define NVCOMP_LZW_WAVES_PER_SIMD 3
+#endif
+
+constexpr uint32_t kOutWin = NVCOMP_LZW_OUTWIN;     /* bytes of output window per wave */
+constexpr uint32_t kBatchMax = NVCOMP_LZW_BATCHMAX; /* most output bytes one batch may produce */
+constexpr uint32_t kKeep = NVCOMP_LZW_KEEP;         /* history kept when the window slides */
+constexpr uint32_t kInRing = NVCOMP_LZW_INRING;     /* bytes of compressed-stream ring per wave */
+constexpr uint32_t kInBlock = 1024;  /* ring refill granule: 64 lanes x 16 bytes */
+constexpr uint32_t kOutLds = kOutWin + 32;
+constexpr uint32_t kInLds = kInRing + 16; /* first 16 bytes mirrored after the end */
+constexpr uint32_t kLdsPerWave = kOutLds + kInLds;
+
+constexpr uint32_t kLitShort = 32;   /* lane-parallel literal runs: up to 8 dwords */
+constexpr uint32_t kMatchShort = 32; /* lane-parallel matches:      up to 8 dwords */
+
+/* ---- compressed-stream ring ------------------------------------------------ */
+
+struct InRing
+{
+  const uint8_t* base; /* chunk pointer rounded down to 16 bytes (uniform) */
+  uint8_t* ring;       /* LDS, kInLds bytes, 16-byte aligned */
+  uint32_t vbeg;       /* virtual position of the first chunk byte: chunk & 15 */
+  uint32_t vend;       /* vbeg + chunk length */
+  uint32_t lo, hi;     /* resident virtual range [lo, hi): multiples of kInBlock */
+};
+
+__device__ __forceinline__ void in_init(InRing& r, const uint8_t* in, uint32_t in_len, uint8_t* lds)
+{
+  const uint32_t a = (uint32_t)((uintptr_t)in & 15u);
+  r.base = in - a;
+  r.ring = lds;
+  r.vbeg = a;
+  r.vend = a + in_len;
+  r.lo = 0;
+  r.hi = 0;
+}
+
+/* Load the 1 KiB block starting at virtual position vb (multiple of kInBlock)
+ * into the ring. Bytes outside the chunk are never fetched (read as zero). */
+__device__ __forceinline__ void in_load_block(InRing& r, uint32_t vb)
+{
+  const uint32_t v = vb + 16u * (uint32_t)wave::lane_id();
+  lz::Bytes16 x = {{0, 0, 0, 0}};
+  if (v >= r.vbeg && v + 16 <= r.vend) {
+    x = *(const lz::Bytes16*)(r.base + v); /* 16-byte aligned */
+  } else if (v + 16 > r.vbeg && v < r.vend) {
+#pragma unroll
+    for (uint32_t j = 0; j < 16; ++j) {
+      if (v + j >= r.vbeg && v + j < r.vend) {
+        x.w[j >> 2] |= (uint32_t)r.base[v + j] << (8 * (j & 3));
+      }
+    }
+  }
+  const uint32_t idx = v & (kInRing - 1);
+  *(lz::Bytes16*)(r.ring + idx) = x;
+  if (idx == 0) {
+    *(lz::Bytes16*)(r.ring + kInRing) = x; /* mirror: 4-byte reads may run past the end */
+  }
+}
+
+/* Make [q, want_hi) resident as far as the ring allows, keeping everything from
+ * q's block on. q must be >= the oldest position still needed. */
+__device__ __forceinline__ void in_ensure(InRing& r, uint32_t q, uint32_t want_hi)
+{
+  const uint32_t qb = q & ~(kInBlock - 1);
+  if (qb >= r.hi || qb < r.lo) { /* nothing useful resident: restart at q's block */
+    r.lo = qb;
+    r.hi = qb;
+  } else {
+    r.lo = qb;
+  }
+  bool loaded = false;
+  while (r.hi < want_hi && r.hi < r.vend && r.hi - r.lo < kInRing) {
+    in_load_block(r, r.hi);
+    r.hi += kInBlock;
+    loaded = true;
+  }
+  if (loaded) {
+    wave::sync();
+  }
+}
+
+__device__ __forceinline__ bool in_resident(const InRing& r, uint32_t v_lo, uint32_t v_hi)
+{
+  return v_lo >= r.lo && v_hi <= r.hi;
+}
+
+/* Byte at virtual position v (per lane): LDS when resident, HBM otherwise. */
+__device__ __forceinline__ uint32_t in_byte(const InRing& r, uint32_t v)
+{
+  if (v >= r.lo && v < r.hi) {
+    return r.ring[v & (kInRing - 1)];
+  }
+  return r.base[v];
+}
+
+/* Same for a wave-uniform position; the result is uniform. */
+__device__ __forceinline__ uint32_t in_byte_uniform(const InRing& r, uint32_t v)
+{
+  return wave::uniform(in_byte(r, v));
+}
+
+/* ---- output window --------------------------------------------------------- */
+
+struct OutWindow
+{
+  uint8_t* win;      /* LDS, kOutLds bytes, 16-byte aligned */
+  uint8_t* out;      /* chunk output pointer in HBM (uniform) */
+  uint32_t align;    /* out & 15: window index = position - wbase + align */
+  uint32_t wbase;    /* output position of window index `align` (multiple of 16) */
+  uint32_t valid_lo; /* positions >= valid_lo (and < op) are present in the window */
+};
+
+__device__ __forceinline__ void out_init(OutWindow& w, uint8_t* out, uint8_t* lds)
+{
+  w.win = lds;
+  w.out = out;
+  w.align = (uint32_t)((uintptr_t)out & 15u);
+  w.wbase = 0;
+  w.valid_lo = 0;
+}
+
+__device__ __forceinline__ uint8_t* out_at(const OutWindow& w, uint32_t pos)
+{
+  return w.win + (pos - w.wbase + w.align);
+}
+
+/* Slide the window so that at least kBatchMax bytes fit after position op. */
+__device__ __forceinline__ void out_make_room(OutWindow& w, uint32_t op)
+{
+  if (op - w.wbase + w.align + kBatchMax <= kOutWin) {
+    return;
+  }
+  uint32_t keep_from = op > kKeep ? op - kKeep : 0;
+  if (keep_from < w.valid_lo) {
+    keep_from = w.valid_lo;
+  }
+  /* wbase stays a multiple of 16 so that window index and HBM address agree mod 16 */
+  const uint32_t new_base = keep_from & ~15u;
+  const uint32_t shift = new_base - w.wbase; /* multiple of 16 */
+  if (shift == 0) {
+    return;
+  }
+  const uint32_t len = op - new_base + w.align; /* window bytes still needed, from index 0 */
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  for (uint32_t base = 0; base < len; base += 1024) {
+    const uint32_t i = base + lane * 16;
+    lz::Bytes16 t = {{0, 0, 0, 0}};
+    if (i < len) {
+      t = *(const lz::Bytes16*)(w.win + shift + i);
+    }
+    wave::sync(); /* every lane has read before any lane overwrites */
+    if (i < len) {
+      *(lz::Bytes16*)(w.win + i) = t;
+    }
+    wave::sync();
+  }
+  w.wbase = new_base;
+  if (w.valid_lo < new_base) {
+    w.valid_lo = new_base;
+  }
+}
+
+/* Flush window bytes of output positions [from, to) to HBM: byte stores up to
+ * the first 16-byte boundary, aligned 16-byte lane stores, byte stores for the tail. */
+__device__ __forceinline__ void out_flush(const OutWindow& w, uint32_t from, uint32_t to)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t a_from = from + w.align; /* absolute-address-congruent coordinates */
+  const uint32_t a_to = to + w.align;
+  uint32_t body_lo = (a_from + 15u) & ~15u;
+  uint32_t body_hi = a_to & ~15u;
+  if (body_lo > body_hi) { /* everything inside one 16-byte block */
+    body_lo = a_to;
+    body_hi = a_to;
+  }
+  uint8_t* gout = w.out - w.align;            /* so that gout + a == out + pos */
+  const uint8_t* lwin = w.win - w.wbase;      /* so that lwin + a == win + (pos - wbase + align) */
+  if (lane < body_lo - a_from) {
+    gout[a_from + lane] = lwin[a_from + lane];
+  }
+  for (uint32_t a = body_lo + lane * 16; a < body_hi; a += 1024) {
+    *(lz::Bytes16*)(gout + a) = *(const lz::Bytes16*)(lwin + a);
+  }
+  if (lane < a_to - body_hi) {
+    gout[body_hi + lane] = lwin[body_hi + lane];
+  }
+}
+
+/* ---- LDS copies ------------------------------------------------------------ */
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p)
+{
+  return lz::ld_u32(p);
+}
+
+/* Number of 4-byte steps (2, 4 or 8) that cover the longest participating run:
+ * two ballots instead of a wave-wide max reduction. */
+__device__ __forceinline__ uint32_t steps_for(bool participates, uint32_t len)
+{
+  if (wave::ballot(participates && len > 16)) {
+    return 8;
+  }
+  return wave::ballot(participates && len > 8) ? 4u : 2u;
+}
+
+/* Per-lane copy of len (4..32) bytes in `steps` dword moves whose offsets are
+ * clamped to len-4: the last moves simply repeat the final dword, so there is no
+ * tail handling and no per-step predication. Byte-serial semantics hold for
+ * overlapping LDS ranges as long as the distance is >= 4. */
+template <uint32_t STEPS>
+__device__ __forceinline__ void copy_dwords_clamped(uint8_t* dst, const uint8_t* src, uint32_t len)
+{
+  const uint32_t last = len - 4;
+#pragma unroll
+  for (uint32_t i = 0; i < STEPS; ++i) {
+    const uint32_t o = 4 * i < last ? 4 * i : last;
+    lz::st_u32(dst + o, lz::ld_u32(src + o));
+  }
+}
+
+/* Same, for sources that must all be fetched before anything is written
+ * (HBM gathers: one round trip for the whole batch). */
+template <uint32_t STEPS>
+__device__ __forceinline__ void load_dwords_clamped(uint32_t (&buf)[8], const uint8_t* src, uint32_t len)
+{
+  const uint32_t last = len - 4;
+#pragma unroll
+  for (uint32_t i = 0; i < STEPS; ++i) {
+    const uint32_t o = 4 * i < last ? 4 * i : last;
+    buf[i] = lz::ld_u32(src + o);
+  }
+}
+
+template <uint32_t STEPS>
+__device__ __forceinline__ void store_dwords_clamped(uint8_t* dst, const uint32_t (&buf)[8], uint32_t len)
+{
+  const uint32_t last = len - 4;
+#pragma unroll
+  for (uint32_t i = 0; i < STEPS; ++i) {
+    const uint32_t o = 4 * i < last ? 4 * i : last;
+    lz::st_u32(dst + o, buf[i]);
+  }
+}
+
+/* 1..3 byte runs (Snappy copies, short literal runs). */
+__device__ __forceinline__ void copy_tiny(uint8_t* dst, const uint8_t* src, uint32_t len)
+{
+  dst[0] = src[0];
+  if (len > 1) {
+    dst[1] = src[1];
+  }
+  if (len > 2) {
+    dst[2] = src[2];
+  }
+}
+
+/* Match copy inside the window with byte-serial semantics: d[i] = d[i - off].
+ * Same pattern-doubling scheme as lz::wave_match_copy, on LDS. */
+__device__ __forceinline__ void lds_match_copy(uint8_t* d, uint32_t off, uint32_t len)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  uint32_t done = 0;
+  uint32_t E = off;
+  while (done < len) {
+    while (E < 256 && 2 * E <= done + off) {
+      E *= 2;
+    }
+    const uint32_t rem = len - done;
+    if (E >= 256 && rem >= 256) {
+      uint8_t* t = d + done + lane * 4;
+      lz::st_u32(t, ld32(t - E));
+      done += 256;
+    } else {
+      uint32_t n = E < 64 ? E : 64;
+      n = n < rem ? n : rem;
+      if (lane < n) {
+        uint8_t* t = d + done + lane;
+        *t = *(t - E);
+      }
+      done += n;
+    }
+    wave::sync();
+  }
+}
+
+/* dst (LDS) <- src (HBM or LDS), non-overlapping, whole wave, any alignment. */
+__device__ __forceinline__ void copy_to_lds(uint8_t* dst, const uint8_t* src, uint32_t len)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  uint32_t base = 0;
+  for (; base + 256 <= len; base += 256) {
+    lz::st_u32(dst + base + lane * 4, lz::ld_u32(src + base + lane * 4));
+  }
+  for (uint32_t i = base + lane; i < len; i += 64) {
+    dst[i] = src[i];
+  }
+}
+
+/*
+ * Execute the first sequences of a parsed batch inside the window. Lane k owns
+ * sequence k (k < n); lit positions are virtual positions in the input ring's
+ * coordinate system. Consumes as many leading sequences as fit kBatchMax output
+ * bytes (at least one unless the first one alone is larger: then `big` is set
+ * and nothing is consumed). Returns the number of sequences consumed and adds
+ * the bytes produced to op.
+ */
+template <bool CHECKED>
+__device__ __forceinline__ uint32_t execute_window_batch(
+    InRing& ir, OutWindow& ow, uint32_t out_cap, uint32_t& op, uint32_t n, const lz::Seq& s, uint32_t& err, bool& big)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  const bool active = lane < n;
+  const uint32_t lit_len = active ? s.lit_len : 0;
+  const uint32_t match_len = active ? s.match_len : 0;
+  const uint32_t len = lit_len + match_len;
+  const uint32_t incl = wave::scan_add_inclusive(len);
+  big = false;
+
+  /* leading sequences whose cumulative output fits one batch */
+  const uint64_t over = wave::ballot(active && incl > kBatchMax) | (n < 64 ? (~0ull << n) : 0ull);
+  const uint32_t take = over ? wave::ctz64(over) : 64u;
+  if (take == 0) {
+    big = true;
+    return 0;
+  }
+  const bool mine = lane < take;
+  const uint32_t total = wave::read_lane(incl, take - 1);
+  const uint32_t lit_dst = op + incl - len;
+  const uint32_t match_dst = lit_dst + lit_len;
+  const uint32_t my_lit = mine ? lit_len : 0;
+  const uint32_t my_match = mine ? match_len : 0;
+
+  if (CHECKED) {
+    const bool bad_out = mine && ((uint64_t)op + incl > out_cap);
+    const bool bad_off = my_match != 0 && (s.match_off == 0 || s.match_off > match_dst);
+    const uint64_t any_out = wave::ballot(bad_out);
+    const uint64_t any_off = wave::ballot(bad_off);
+    if (any_out | any_off) {
+      err |= (any_out ? lz::kErrOutput : 0u) | (any_off ? lz::kErrOffset : 0u);
+      return 0;
+    }
+  }
+
+  LZ_STAT("batches", 1);
+  LZ_STAT("seqs", take);
+  LZ_STAT("bytes", total);
+  out_make_room(ow, op);
+
+  /* ---- far matches: sources older than the window, read from HBM ---- */
+  const uint32_t match_src = match_dst - s.match_off;
+  const bool is_near = my_match != 0 && match_src >= ow.valid_lo;
+  const bool far_lane = my_match >= 4 && !is_near && my_match <= kMatchShort && match_src + my_match <= op;
+  uint32_t far_data[8];
+  const uint32_t far_steps = steps_for(far_lane, my_match);
+  if (far_lane) {
+    const uint8_t* src = ow.out + match_src;
+    if (far_steps == 2) {
+      load_dwords_clamped<2>(far_data, src, my_match);
+    } else if (far_steps == 4) {
+      load_dwords_clamped<4>(far_data, src, my_match);
+    } else {
+      load_dwords_clamped<8>(far_data, src, my_match);
+    }
+  }
+
+  /* ---- literals ---- */
+  {
+    const bool resident = in_resident(ir, s.lit_src, s.lit_src + my_lit);
+    const bool lit_lane = my_lit >= 4 && my_lit <= kLitShort && resident;
+    const bool lit_tiny = my_lit != 0 && my_lit < 4 && resident;
+    /* the ring wraps at kInRing; its 16-byte mirror covers a dword that starts before the end,
+     * and a run crossing the end is split by the modulo per step */
+    uint8_t* dst = out_at(ow, lit_dst);
+    const uint32_t lit_steps = steps_for(lit_lane, my_lit);
+    if (lit_lane) {
+      const uint32_t last = my_lit - 4;
+      uint32_t data[8];
+#pragma unroll
+      for (uint32_t i = 0; i < 8; ++i) {
+        if (i < lit_steps) {
+          const uint32_t o = 4 * i < last ? 4 * i : last;
+          data[i] = ld32(ir.ring + ((s.lit_src + o) & (kInRing - 1)));
+        }
+      }
+#pragma unroll
+      for (uint32_t i = 0; i < 8; ++i) {
+        if (i < lit_steps) {
+          const uint32_t o = 4 * i < last ? 4 * i : last;
+          lz::st_u32(dst + o, data[i]);
+        }
+      }
+    }
+    if (wave::ballot(lit_tiny)) {
+      if (lit_tiny) {
+        dst[0] = ir.ring[s.lit_src & (kInRing - 1)];
+        if (my_lit > 1) {
+          dst[1] = ir.ring[(s.lit_src + 1) & (kInRing - 1)];
+        }
+        if (my_lit > 2) {
+          dst[2] = ir.ring[(s.lit_src + 2) & (kInRing - 1)];
+        }
+      }
+    }
+    uint64_t pending = wave::ballot(my_lit != 0 && !lit_lane && !lit_tiny);
+    LZ_STAT("lit_lanes", wave::popc64(wave::ballot(lit_lane || lit_tiny)));
+    LZ_STAT("lit_coop", wave::popc64(pending));
+    while (pending) {
+      const uint32_t j = wave::ctz64(pending);
+      pending &= pending - 1;
+      const uint32_t jsrc = wave::read_lane(s.lit_src, j);
+      const uint32_t jlen = wave::read_lane(my_lit, j);
+      const uint32_t jdst = wave::read_lane(lit_dst, j);
+      copy_to_lds(out_at(ow, jdst), ir.base + jsrc, jlen);
+    }
+  }
+
+  /* ---- far match data into the window ---- */
+  if (far_lane) {
+    uint8_t* dst = out_at(ow, match_dst);
+    if (far_steps == 2) {
+      store_dwords_clamped<2>(dst, far_data, my_match);
+    } else if (far_steps == 4) {
+      store_dwords_clamped<4>(dst, far_data, my_match);
+    } else {
+      store_dwords_clamped<8>(dst, far_data, my_match);
+    }
+  }
+  wave::sync();
+
+  /* ---- remaining matches, oldest first: multi-round resolution in LDS ---- */
+  {
+    const bool near_lane = is_near && my_match >= 4 && my_match <= kMatchShort && s.match_off >= 4;
+    uint64_t pending = wave::ballot(my_match != 0 && !far_lane);
+    const uint64_t near_mask = wave::ballot(near_lane);
+    const uint64_t lane_bit = 1ull << lane;
+    LZ_STAT("match_far_lanes", wave::popc64(wave::ballot(far_lane)));
+    LZ_STAT("match_near_lanes", wave::popc64(near_mask));
+    LZ_STAT("match_coop", wave::popc64(pending & ~near_mask));
+    while (pending) {
+      const uint32_t f = wave::ctz64(pending);
+      const uint32_t hw = wave::read_lane(match_dst, f); /* every byte below hw is final */
+      if (!((near_mask >> f) & 1)) {
+        /* the oldest pending match is long, has a period < 4, or reaches behind the window */
+        const uint32_t foff = wave::read_lane(s.match_off, f);
+        const uint32_t flen = wave::read_lane(my_match, f);
+        const uint32_t fsrc = hw - foff;
+        if (fsrc >= ow.valid_lo) {
+          lds_match_copy(out_at(ow, hw), foff, flen);
+        } else {
+          /* Source starts behind the window. Output before op is in HBM (flushed);
+           * hw >= op, so at most the first min(flen, op - fsrc) <= foff source bytes
+           * come from HBM and everything after them is already in the window. */
+          const uint32_t n_hbm = fsrc + flen <= op ? flen : op - fsrc;
+          copy_to_lds(out_at(ow, hw), ow.out + fsrc, n_hbm);
+          wave::sync();
+          if (n_hbm < flen) {
+            lds_match_copy(out_at(ow, hw + n_hbm), foff, flen - n_hbm);
+          }
+        }
+        pending &= ~(1ull << f);
+        continue;
+      }
+      const bool ready = near_lane && (pending & lane_bit) && (lane == f || match_src + my_match <= hw);
+      const uint32_t steps = steps_for(ready, my_match);
+      LZ_STAT("mrr_rounds", 1);
+      LZ_STAT("mrr_iters", steps);
+      if (ready) {
+        const uint8_t* src = out_at(ow, match_src);
+        uint8_t* dst = out_at(ow, match_dst);
+        if (steps == 2) {
+          copy_dwords_clamped<2>(dst, src, my_match);
+        } else if (steps == 4) {
+          copy_dwords_clamped<4>(dst, src, my_match);
+        } else {
+          copy_dwords_clamped<8>(dst, src, my_match);
+        }
+      }
+      wave::sync();
+      pending &= ~wave::ballot(ready);
+    }
+  }
+
+  out_flush(ow, op, op + total);
+  wave::sync(); /* later far reads of this wave must see the flushed bytes */
+  op += total;
+  return take;
+}
+
+} // namespace lzw

@@ -125,3 +125,7 @@ __device__ __forceinline__ uint32_t popc64(uint64_t m)
 }
 
 } // namespace wave
+
+/* Algorithm statistics hook (rounds, path counts): compiled out on the device; the
+ * host emulation (tests/emu/common/wave.h) turns it into counters for design studies. */
+#define LZ_STAT(name, n) ((void)0)

@@ -1,0 +1,293 @@
+/*
+ * lz4/lz4_decode_window.hip.h -- LZ4 block decoder on the LDS-staged executor
+ * (common/lz_window.hip.h). Same entry-point contract as lz4_decode.hip.h; this
+ * is the default nvcompBatchedLZ4DecompressAsync path.
+ *
+ * Token chase: the next 256 stream positions are examined in parallel -- lane l
+ * of register j assumes a token starts at position wb + 64 j + l and computes
+ * the distance to the token after it (reading the at most two length-extension
+ * bytes it needs from the input ring). The real chain is then followed with one
+ * v_readlane per sequence. Tokens whose lengths need more than one extension
+ * byte (literal runs >= 270, matches >= 274 bytes) take a scalar slow path.
+ */
+#pragma once
+
+#include "common/lz_window.hip.h"
+
+namespace lz4w {
+
+/* Delta stored for a position whose next token cannot be derived in the parallel
+ * pass (chunk sizes are < 2^28, so position + kUnknown never looks like a position). */
+constexpr uint32_t kUnknown = 1u << 28;
+
+struct Chase
+{
+  uint32_t wb;    /* virtual position of lane 0 of nx[0] */
+  uint32_t nx[4]; /* nx[j] lane l: distance from a token at wb+64j+l to the next token; kUnknown = slow path */
+  uint32_t q;     /* virtual position of the next token */
+};
+
+/* Distance from a (speculative) token at virtual position p to the next token. */
+__device__ __forceinline__ uint32_t token_delta(const lzw::InRing& r, uint32_t p)
+{
+  if (p < r.lo || p + 2 > r.hi || p >= r.vend) {
+    return kUnknown;
+  }
+  const uint8_t* ring = r.ring;
+  const uint32_t t = ring[p & (lzw::kInRing - 1)];
+  uint32_t pos = p + 1;
+  uint32_t lit = t >> 4;
+  if (lit == 15) {
+    const uint32_t e = ring[pos & (lzw::kInRing - 1)];
+    if (e == 255) {
+      return kUnknown;
+    }
+    lit += e;
+    ++pos;
+  }
+  pos += lit;
+  if (pos >= r.vend) {
+    return pos - p; /* literals reach the end of the chunk: the chase stops here */
+  }
+  pos += 2;
+  if ((t & 15u) == 15u) {
+    if (pos >= r.hi) {
+      return kUnknown;
+    }
+    if (pos >= r.vend) {
+      return pos - p;
+    }
+    const uint32_t e = ring[pos & (lzw::kInRing - 1)];
+    if (e == 255) {
+      return kUnknown;
+    }
+    ++pos;
+  }
+  return pos - p;
+}
+
+__device__ __forceinline__ void chase_reload(Chase& c, const lzw::InRing& r)
+{
+  c.wb = c.q;
+  LZ_STAT("chase_reloads", 1);
+  const uint32_t lane = (uint32_t)wave::lane_id();
+#pragma unroll
+  for (uint32_t j = 0; j < 4; ++j) {
+    c.nx[j] = token_delta(r, c.wb + 64 * j + lane);
+  }
+}
+
+/* Scalar walk over one token with multi-byte length extensions. */
+__device__ __forceinline__ uint32_t chase_slow_next(const lzw::InRing& r, uint32_t q)
+{
+  const uint32_t vend = r.vend;
+  const uint32_t t = lzw::in_byte_uniform(r, q);
+  uint32_t pos = q + 1;
+  uint32_t lit = t >> 4;
+  if (lit == 15) {
+    for (;;) {
+      if (pos >= vend) {
+        return vend + 1;
+      }
+      const uint32_t b = lzw::in_byte_uniform(r, pos);
+      ++pos;
+      lit += b;
+      if (b != 255) {
+        break;
+      }
+    }
+  }
+  if (lit >= vend - pos) {
+    return vend + 1;
+  }
+  pos += lit + 2;
+  if ((t & 15u) == 15u) {
+    for (;;) {
+      if (pos >= vend) {
+        return vend + 1;
+      }
+      const uint32_t b = lzw::in_byte_uniform(r, pos);
+      ++pos;
+      if (b != 255) {
+        break;
+      }
+    }
+  }
+  return pos;
+}
+
+/* Append token positions to seqpos lanes [k, 64). Returns the new count.
+ * The inner loop is the serial critical path of the decoder: one s_sub, one
+ * v_readlane, the lane write and two scalar adds per token. Unknown deltas are
+ * stored as kUnknown so that the loop needs no extra test: the position jumps
+ * out of every window and the token is re-examined by the scalar slow path. */
+__device__ __forceinline__ uint32_t chase(Chase& c, const lzw::InRing& r, uint32_t& seqpos, uint32_t k)
+{
+  while (k < 64 && c.q < r.vend) {
+    if (c.q - c.wb >= 256) {
+      chase_reload(c, r);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+      const uint32_t base = c.wb + 64 * j;
+      uint32_t lim = base + 64;
+      lim = lim < r.vend ? lim : r.vend;
+      if (k <= 64 - 22) { /* a 64-byte sub-window holds at most 22 tokens (>= 3 bytes each) */
+        while (c.q < lim) {
+          const uint32_t d = wave::read_lane(c.nx[j], c.q - base);
+          seqpos = wave::write_lane(seqpos, c.q, k);
+          ++k;
+          c.q += d;
+        }
+      } else {
+        while (c.q < lim && k < 64) {
+          const uint32_t d = wave::read_lane(c.nx[j], c.q - base);
+          seqpos = wave::write_lane(seqpos, c.q, k);
+          ++k;
+          c.q += d;
+        }
+      }
+    }
+    if (c.q >= kUnknown) { /* the last recorded token needs the scalar walk */
+      const uint32_t tok = c.q - kUnknown;
+      LZ_STAT("chase_slow", 1);
+      c.q = chase_slow_next(r, tok);
+    }
+  }
+  return k;
+}
+
+/* Lane-parallel field decode of the sequence whose token is at virtual position p. */
+__device__ __forceinline__ void parse(const lzw::InRing& r, uint32_t p, bool active, lz::Seq& s, bool& bad)
+{
+  s.lit_src = 0;
+  s.lit_len = 0;
+  s.match_off = 0;
+  s.match_len = 0;
+  bad = false;
+  if (!active) {
+    return;
+  }
+  const uint32_t vend = r.vend;
+  const uint32_t t = lzw::in_byte(r, p);
+  uint32_t pos = p + 1;
+  uint32_t lit = t >> 4;
+  if (lit == 15) {
+    uint32_t b;
+    do {
+      if (pos >= vend) {
+        bad = true;
+        return;
+      }
+      b = lzw::in_byte(r, pos++);
+      lit += b;
+    } while (b == 255);
+  }
+  if (lit > vend - pos) {
+    bad = true;
+    return;
+  }
+  s.lit_src = pos;
+  s.lit_len = lit;
+  pos += lit;
+  if (pos == vend) {
+    return; /* last sequence: literals only */
+  }
+  if (vend - pos < 2) {
+    bad = true;
+    return;
+  }
+  s.match_off = lzw::in_byte(r, pos) | (lzw::in_byte(r, pos + 1) << 8);
+  pos += 2;
+  uint32_t mlen = t & 15u;
+  if (mlen == 15) {
+    uint32_t b;
+    do {
+      if (pos >= vend) {
+        bad = true;
+        return;
+      }
+      b = lzw::in_byte(r, pos++);
+      mlen += b;
+    } while (b == 255);
+  }
+  if (mlen > 0x40000000u || pos >= vend) { /* a token must follow every match */
+    bad = true;
+    return;
+  }
+  s.match_len = mlen + 4;
+}
+
+/* Decode one chunk with the calling wave; `lds` is this wave's kLdsPerWave bytes. */
+template <bool CHECKED>
+__device__ __forceinline__ uint32_t decode_chunk(
+    const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_cap, uint8_t* lds, uint32_t& err)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  err = lz::kErrNone;
+  if (in_len == 0) {
+    return 0;
+  }
+  lzw::InRing ir;
+  lzw::OutWindow ow;
+  lzw::in_init(ir, in, in_len, lds + lzw::kOutLds);
+  lzw::out_init(ow, out, lds);
+  Chase c;
+  c.q = ir.vbeg;
+  c.wb = c.q - 256; /* forces a reload */
+  uint32_t op = 0;
+  uint32_t seqpos = 0;
+  uint32_t count = 0; /* sequences recorded in seqpos lanes [0, count) and not yet executed */
+  for (;;) {
+    if (count == 0 && c.q >= ir.vend) {
+      break;
+    }
+    /* keep the stream resident from the oldest unexecuted token to well past the chase */
+    const uint32_t oldest = count ? wave::read_lane(seqpos, 0) : c.q;
+    lzw::in_ensure(ir, oldest, (c.q & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
+    const uint32_t before = count;
+    count = chase(c, ir, seqpos, count);
+    (void)before;
+    lz::Seq s;
+    bool bad;
+    parse(ir, seqpos, lane < count, s, bad);
+    if (wave::ballot(bad)) {
+      err |= lz::kErrInput;
+      return 0;
+    }
+    bool big;
+    uint32_t take = lzw::execute_window_batch<CHECKED>(ir, ow, out_cap, op, count, s, err, big);
+    if (CHECKED && err) {
+      return 0;
+    }
+    if (big) {
+      /* sequence 0 alone exceeds a batch: stream it HBM -> HBM and restart the window after it */
+      const uint32_t lsrc = wave::read_lane(s.lit_src, 0);
+      const uint32_t llen = wave::read_lane(s.lit_len, 0);
+      const uint32_t moff = wave::read_lane(s.match_off, 0);
+      const uint32_t mlen = wave::read_lane(s.match_len, 0);
+      if (CHECKED) {
+        const uint64_t end = (uint64_t)op + llen + mlen;
+        if (end > out_cap || (mlen != 0 && (moff == 0 || moff > op + llen))) {
+          err |= end > out_cap ? lz::kErrOutput : lz::kErrOffset;
+          return 0;
+        }
+      }
+      lz::wave_copy(out + op, ir.base + lsrc, llen);
+      wave::sync();
+      if (mlen) {
+        lz::wave_match_copy(out + op + llen, moff, mlen);
+      }
+      op += llen + mlen;
+      ow.wbase = op & ~15u;
+      ow.valid_lo = op;
+      take = 1;
+    }
+    /* drop the executed sequences, keep the rest for the next round */
+    seqpos = wave::shuffle(seqpos, (lane + take) & 63u);
+    count -= take;
+  }
+  return op;
+}
+
+} // namespace lz4w

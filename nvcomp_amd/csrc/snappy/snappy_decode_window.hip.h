@@ -1,0 +1,287 @@
+/*
+ * snappy/snappy_decode_window.hip.h -- Snappy raw-format decoder on the
+ * LDS-staged executor (common/lz_window.hip.h); the default
+ * nvcompBatchedSnappyDecompressAsync path. Element chase as in
+ * lz4_decode_window.hip.h: 256 speculative tag positions per reload, one
+ * v_readlane per element; literals with a multi-byte length field are resolved
+ * in the speculative pass as well (the length bytes sit right behind the tag).
+ */
+#pragma once
+
+#include "common/lz_window.hip.h"
+
+namespace snappyw {
+
+/* Delta stored for a position whose next token cannot be derived in the parallel
+ * pass (chunk sizes are < 2^28, so position + kUnknown never looks like a position). */
+constexpr uint32_t kUnknown = 1u << 28;
+
+struct Chase
+{
+  uint32_t wb;
+  uint32_t nx[4];
+  uint32_t q;
+};
+
+/* Distance from a (speculative) tag at virtual position p to the next tag; kUnknown = unknown. */
+__device__ __forceinline__ uint32_t tag_delta(const lzw::InRing& r, uint32_t p)
+{
+  if (p < r.lo || p + 5 > r.hi || p >= r.vend) {
+    return kUnknown;
+  }
+  const uint8_t* ring = r.ring;
+  const uint32_t t = ring[p & (lzw::kInRing - 1)];
+  const uint32_t kind = t & 3u;
+  if (kind != 0) {
+    return kind == 3 ? 5u : kind + 1;
+  }
+  uint32_t len = t >> 2;
+  uint32_t hdr = 1;
+  if (len >= 60) {
+    const uint32_t nb = len - 59;
+    len = 0;
+    for (uint32_t i = 0; i < nb; ++i) {
+      len |= (uint32_t)ring[(p + 1 + i) & (lzw::kInRing - 1)] << (8 * i);
+    }
+    hdr += nb;
+    if (len >= 0x7fffff00u) {
+      return kUnknown;
+    }
+  }
+  return hdr + len + 1;
+}
+
+__device__ __forceinline__ void chase_reload(Chase& c, const lzw::InRing& r)
+{
+  c.wb = c.q;
+  const uint32_t lane = (uint32_t)wave::lane_id();
+#pragma unroll
+  for (uint32_t j = 0; j < 4; ++j) {
+    c.nx[j] = tag_delta(r, c.wb + 64 * j + lane);
+  }
+}
+
+/* Scalar fallback (tag not resolvable from the ring). */
+__device__ __forceinline__ uint32_t chase_slow_next(const lzw::InRing& r, uint32_t q)
+{
+  const uint32_t vend = r.vend;
+  const uint32_t t = lzw::in_byte_uniform(r, q);
+  const uint32_t kind = t & 3u;
+  if (kind != 0) {
+    return q + (kind == 3 ? 5u : kind + 1);
+  }
+  uint32_t len = t >> 2;
+  uint32_t pos = q + 1;
+  if (len >= 60) {
+    const uint32_t nb = len - 59;
+    if (vend - pos < nb) {
+      return vend + 1;
+    }
+    len = 0;
+    for (uint32_t i = 0; i < nb; ++i) {
+      len |= lzw::in_byte_uniform(r, pos + i) << (8 * i);
+    }
+    pos += nb;
+  }
+  if (len >= vend - pos) {
+    return vend + 1;
+  }
+  return pos + len + 1;
+}
+
+/* Append token positions to seqpos lanes [k, 64). Returns the new count.
+ * The inner loop is the serial critical path of the decoder: one s_sub, one
+ * v_readlane, the lane write and two scalar adds per token. Unknown deltas are
+ * stored as kUnknown so that the loop needs no extra test: the position jumps
+ * out of every window and the token is re-examined by the scalar slow path. */
+__device__ __forceinline__ uint32_t chase(Chase& c, const lzw::InRing& r, uint32_t& seqpos, uint32_t k)
+{
+  while (k < 64 && c.q < r.vend) {
+    if (c.q - c.wb >= 256) {
+      chase_reload(c, r);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+      const uint32_t base = c.wb + 64 * j;
+      uint32_t lim = base + 64;
+      lim = lim < r.vend ? lim : r.vend;
+      if (k <= 64 - 32) { /* a 64-byte sub-window holds at most 32 elements (>= 2 bytes each) */
+        while (c.q < lim) {
+          const uint32_t d = wave::read_lane(c.nx[j], c.q - base);
+          seqpos = wave::write_lane(seqpos, c.q, k);
+          ++k;
+          c.q += d;
+        }
+      } else {
+        while (c.q < lim && k < 64) {
+          const uint32_t d = wave::read_lane(c.nx[j], c.q - base);
+          seqpos = wave::write_lane(seqpos, c.q, k);
+          ++k;
+          c.q += d;
+        }
+      }
+    }
+    if (c.q >= kUnknown) { /* the last recorded token needs the scalar walk */
+      const uint32_t tok = c.q - kUnknown;
+      LZ_STAT("chase_slow", 1);
+      c.q = chase_slow_next(r, tok);
+    }
+  }
+  return k;
+}
+
+__device__ __forceinline__ void parse(const lzw::InRing& r, uint32_t p, bool active, lz::Seq& s, bool& bad)
+{
+  s.lit_src = 0;
+  s.lit_len = 0;
+  s.match_off = 0;
+  s.match_len = 0;
+  bad = false;
+  if (!active) {
+    return;
+  }
+  const uint32_t vend = r.vend;
+  const uint32_t t = lzw::in_byte(r, p);
+  const uint32_t kind = t & 3u;
+  uint32_t pos = p + 1;
+  const uint32_t avail = vend - pos;
+  if (kind == 0) {
+    uint32_t len = t >> 2;
+    if (len >= 60) {
+      const uint32_t nb = len - 59;
+      if (avail < nb) {
+        bad = true;
+        return;
+      }
+      len = 0;
+      for (uint32_t i = 0; i < nb; ++i) {
+        len |= lzw::in_byte(r, pos + i) << (8 * i);
+      }
+      pos += nb;
+    }
+    if (len >= vend - pos) {
+      bad = true;
+      return;
+    }
+    s.lit_src = pos;
+    s.lit_len = len + 1;
+    return;
+  }
+  const uint32_t need = kind == 3 ? 4u : kind;
+  if (avail < need) {
+    bad = true;
+    return;
+  }
+  if (kind == 1) {
+    s.match_len = 4 + ((t >> 2) & 7u);
+    s.match_off = ((t >> 5) << 8) | lzw::in_byte(r, pos);
+  } else if (kind == 2) {
+    s.match_len = 1 + (t >> 2);
+    s.match_off = lzw::in_byte(r, pos) | (lzw::in_byte(r, pos + 1) << 8);
+  } else {
+    s.match_len = 1 + (t >> 2);
+    s.match_off = lzw::in_byte(r, pos) | (lzw::in_byte(r, pos + 1) << 8) | (lzw::in_byte(r, pos + 2) << 16)
+                  | (lzw::in_byte(r, pos + 3) << 24);
+  }
+  if (s.match_off == 0) {
+    bad = true;
+  }
+}
+
+template <bool CHECKED>
+__device__ __forceinline__ uint32_t decode_chunk(
+    const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_cap, uint8_t* lds, uint32_t& err)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  err = lz::kErrNone;
+  if (in_len == 0) {
+    err = lz::kErrInput;
+    return 0;
+  }
+  lzw::InRing ir;
+  lzw::OutWindow ow;
+  lzw::in_init(ir, in, in_len, lds + lzw::kOutLds);
+  lzw::out_init(ow, out, lds);
+  lzw::in_ensure(ir, ir.vbeg, ir.vbeg + lzw::kInBlock);
+  /* varint32 preamble */
+  uint32_t q = ir.vbeg;
+  uint32_t total = 0;
+  {
+    bool ok = false;
+    for (uint32_t shift = 0; shift <= 28 && q < ir.vend; shift += 7) {
+      const uint32_t b = lzw::in_byte_uniform(ir, q);
+      ++q;
+      total |= (b & 127u) << shift;
+      if (!(b & 128u)) {
+        ok = !(shift == 28 && b > 15);
+        break;
+      }
+    }
+    if (!ok) {
+      err = lz::kErrInput;
+      return 0;
+    }
+  }
+  if (CHECKED && total > out_cap) {
+    err = lz::kErrOutput;
+    return 0;
+  }
+  const uint32_t limit = CHECKED ? total : out_cap;
+  Chase c;
+  c.q = q;
+  c.wb = c.q - 256;
+  uint32_t op = 0;
+  uint32_t seqpos = 0;
+  uint32_t count = 0;
+  for (;;) {
+    if (count == 0 && c.q >= ir.vend) {
+      break;
+    }
+    const uint32_t oldest = count ? wave::read_lane(seqpos, 0) : c.q;
+    lzw::in_ensure(ir, oldest, (c.q & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
+    count = chase(c, ir, seqpos, count);
+    lz::Seq s;
+    bool bad;
+    parse(ir, seqpos, lane < count, s, bad);
+    if (wave::ballot(bad)) {
+      err |= lz::kErrInput;
+      return 0;
+    }
+    bool big;
+    uint32_t take = lzw::execute_window_batch<CHECKED>(ir, ow, limit, op, count, s, err, big);
+    if (CHECKED && err) {
+      return 0;
+    }
+    if (big) {
+      const uint32_t lsrc = wave::read_lane(s.lit_src, 0);
+      const uint32_t llen = wave::read_lane(s.lit_len, 0);
+      const uint32_t moff = wave::read_lane(s.match_off, 0);
+      const uint32_t mlen = wave::read_lane(s.match_len, 0);
+      if (CHECKED) {
+        const uint64_t end = (uint64_t)op + llen + mlen;
+        if (end > limit || (mlen != 0 && (moff == 0 || moff > op + llen))) {
+          err |= end > limit ? lz::kErrOutput : lz::kErrOffset;
+          return 0;
+        }
+      }
+      lz::wave_copy(out + op, ir.base + lsrc, llen);
+      wave::sync();
+      if (mlen) {
+        lz::wave_match_copy(out + op + llen, moff, mlen);
+      }
+      op += llen + mlen;
+      ow.wbase = op & ~15u;
+      ow.valid_lo = op;
+      take = 1;
+    }
+    seqpos = wave::shuffle(seqpos, (lane + take) & 63u);
+    count -= take;
+  }
+  if (CHECKED && (op != total || c.q != ir.vend)) {
+    err |= lz::kErrInput;
+    return 0;
+  }
+  return op;
+}
+
+} // namespace snappyw

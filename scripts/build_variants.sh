@@ -1,0 +1,21 @@
+#!/bin/bash
+# A/B builds of the library with different LDS-window tunables -> nvcomp_amd/lib/alt/libnvcomp_<tag>.so
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p nvcomp_amd/lib/alt
+build() { # tag, flags...
+  local tag=$1; shift
+  local objs=""
+  for f in nvcomp_amd/csrc/api/*.hip; do
+    o=/tmp/var_${tag}_$(basename $f .hip).o
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Invcomp_amd/csrc "$@" -c $f -o $o &
+    objs="$objs $o"
+  done
+  wait
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o nvcomp_amd/lib/alt/libnvcomp_${tag}.so $objs
+  echo "built $tag"
+}
+build w8k  -DNVCOMP_LZW_OUTWIN=8192 -DNVCOMP_LZW_INRING=4096 -DNVCOMP_LZW_WAVES_PER_SIMD=3
+build w4k  -DNVCOMP_LZW_OUTWIN=4096 -DNVCOMP_LZW_INRING=2048 -DNVCOMP_LZW_WAVES_PER_SIMD=5
+build w4k6 -DNVCOMP_LZW_OUTWIN=4096 -DNVCOMP_LZW_INRING=2048 -DNVCOMP_LZW_WAVES_PER_SIMD=6
+build w2k  -DNVCOMP_LZW_OUTWIN=2048 -DNVCOMP_LZW_INRING=2048 -DNVCOMP_LZW_WAVES_PER_SIMD=8

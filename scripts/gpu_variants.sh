@@ -1,0 +1,20 @@
+#!/bin/bash
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp
+OUT=gpurun_out/${1:-var}
+mkdir -p "$OUT"
+timeout 900 python -m pytest tests -m gpu -q --timeout 300 -x > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc=$?"; tail -2 "$OUT/pytest_gpu.log"
+for lib in nvcomp_amd/lib/alt/libnvcomp_*.so; do
+  tag=$(basename $lib .so)
+  NVCOMP_AMD_LIB=$PWD/$lib timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/$tag.json" 2> "$OUT/$tag.err"
+  NVCOMP_AMD_LIB=$PWD/$lib timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --dataset text --producer fast --mib-per-gpu 512 --unique-mib 32 > "$OUT/${tag}_text.json" 2>> "$OUT/$tag.err"
+  NVCOMP_AMD_LIB=$PWD/$lib timeout 300 python bench.py --algo snappy --steps 5 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/${tag}_snappy.json" 2>> "$OUT/$tag.err"
+  python - "$OUT/$tag.json" "$OUT/${tag}_text.json" "$OUT/${tag}_snappy.json" <<'PY'
+import json,sys
+for f in sys.argv[1:]:
+    try:
+        r=json.load(open(f)); print(f, r['value'], r['roofline']['kernel_ms'])
+    except Exception as e: print(f,'ERR',e)
+PY
+done

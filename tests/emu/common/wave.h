@@ -126,3 +126,13 @@ inline uint32_t ctz64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
 inline uint32_t popc64(uint64_t m) { return (uint32_t)__builtin_popcountll(m); }
 
 } // namespace wave
+
+/* statistics hook: lane 0 of a wave accumulates named counters (see emu_stats_dump) */
+extern "C" void emu_stat_add(const char* name, unsigned long long n);
+#define LZ_STAT(name, n)                  \
+  do {                                    \
+    const unsigned long long v_ = (n);    \
+    if (emu::cur()->lane == 0) {          \
+      emu_stat_add(name, v_);             \
+    }                                     \
+  } while (0)

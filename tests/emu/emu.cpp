@@ -234,3 +234,18 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block)
 }
 
 } // namespace emu
+
+/* ---- statistics hook --------------------------------------------------------- */
+#include <map>
+#include <string>
+static std::map<std::string, unsigned long long> g_stats;
+extern "C" void emu_stat_add(const char* name, unsigned long long n) { g_stats[name] += n; }
+extern "C" void emu_stats_dump(int reset)
+{
+  for (auto& kv : g_stats) {
+    fprintf(stderr, "stat %-28s %llu\n", kv.first.c_str(), kv.second);
+  }
+  if (reset) {
+    g_stats.clear();
+  }
+}

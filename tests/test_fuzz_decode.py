@@ -1,0 +1,57 @@
+"""Randomised structure fuzz of the LZ4 / Snappy decoders against the oracle:
+mixtures of literal runs, short/long matches at near and far distances, periodic
+data and chunk sizes that are not multiples of anything."""
+import numpy as np
+import pytest
+
+from nvcomp_amd._lib import NvcompStatus
+
+
+def synth(rng, size):
+    """Concatenate randomly chosen segments: noise, repeats of earlier data at a random
+    distance (near or far), short-period runs, and low-entropy bytes."""
+    out = np.empty(size, dtype=np.uint8)
+    pos = 0
+    while pos < size:
+        kind = rng.randint(0, 6)
+        n = int(min(size - pos, rng.choice([3, 7, 20, 60, 200, 700, 3000, 9000])))
+        if kind == 0 or pos < 8:
+            out[pos:pos + n] = rng.randint(0, 256, size=n)
+        elif kind in (1, 2):  # copy from earlier: near (<= 300 back) or anywhere
+            back = rng.randint(1, min(pos, 300) + 1) if kind == 1 else rng.randint(1, pos + 1)
+            for i in range(n):  # byte-serial so that back < n makes a period
+                out[pos + i] = out[pos + i - back]
+        elif kind == 3:
+            period = rng.randint(1, 9)
+            pat = rng.randint(0, 256, size=period).astype(np.uint8)
+            out[pos:pos + n] = np.resize(pat, n)
+        elif kind == 4:
+            out[pos:pos + n] = rng.randint(0, 4, size=n)
+        else:
+            out[pos:pos + n] = rng.randint(97, 123, size=n)
+        pos += n
+    return out
+
+
+@pytest.mark.parametrize("fmt", ["LZ4", "Snappy"])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_fuzz_structures(backend, oracle, fmt, seed):
+    rng = np.random.RandomState(seed * 7919 + (0 if fmt == "LZ4" else 1))
+    n_chunks = 24 if backend.name == "gpu" else 5
+    sizes = [int(rng.choice([100, 1000, 5000, 20000, 65536, 70001, 150000])) for _ in range(n_chunks)]
+    chunks = [synth(rng, s) for s in sizes]
+    if fmt == "LZ4":
+        enc = (lambda c: oracle.ref_lz4_compress(c, int(rng.choice([0, 0, 9])))) if oracle.have_ref() else oracle.lz4_compress
+        dec = oracle.lz4_decompress
+    else:
+        enc = oracle.ref_snappy_compress if oracle.have_ref() else oracle.snappy_compress
+        dec = oracle.snappy_decompress
+    comp = [enc(c) for c in chunks]
+    mis = int(rng.randint(0, 16))
+    outs, actual, status = backend.codec(fmt).decompress(comp, sizes, base_misalign=mis)
+    assert (status == NvcompStatus.Success).all(), status
+    assert actual.tolist() == sizes
+    for i, (o, c, cc) in enumerate(zip(outs, chunks, comp)):
+        rc, ref = dec(cc, c.size)
+        assert rc == 0 and np.array_equal(ref, c)
+        assert np.array_equal(o, c), f"chunk {i} (size {c.size}) differs at {int(np.argmax(o != c))}"
