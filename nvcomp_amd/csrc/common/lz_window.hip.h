@@ -27,20 +27,23 @@
 namespace lzw {
 
 /* Tunables (overridable with -D for the A/B builds of scripts/build_variants.sh). */
+/* Defaults from the MI355X sweep of profiles/r01_window_variants.json: a small
+ * window at full occupancy (8 waves/SIMD, 4 KiB of LDS per wave) beats a large
+ * one -- the decoder is instruction-issue bound, not LDS- or HBM-bound. */
 #ifndef NVCOMP_LZW_OUTWIN
-#define NVCOMP_LZW_OUTWIN 8192
+#define NVCOMP_LZW_OUTWIN 2048
 #endif
 #ifndef NVCOMP_LZW_BATCHMAX
-#define NVCOMP_LZW_BATCHMAX (NVCOMP_LZW_OUTWIN / 4)
+#define NVCOMP_LZW_BATCHMAX (NVCOMP_LZW_OUTWIN / 2)
 #endif
 #ifndef NVCOMP_LZW_KEEP
-#define NVCOMP_LZW_KEEP (NVCOMP_LZW_OUTWIN / 2)
+#define NVCOMP_LZW_KEEP (NVCOMP_LZW_OUTWIN * 3 / 8)
 #endif
 #ifndef NVCOMP_LZW_INRING
-#define NVCOMP_LZW_INRING 4096
+#define NVCOMP_LZW_INRING 2048
 #endif
 #ifndef NVCOMP_LZW_WAVES_PER_SIMD
-#define NVCOMP_LZW_WAVES_PER_SIMD 3
+#define NVCOMP_LZW_WAVES_PER_SIMD 8
 #endif
 
 constexpr uint32_t kOutWin = NVCOMP_LZW_OUTWIN;     /* bytes of output window per wave */
@@ -82,21 +85,26 @@ __device__ __forceinline__ void in_init(InRing& r, const uint8_t* in, uint32_t i
 __device__ __forceinline__ void in_load_block(InRing& r, uint32_t vb)
 {
   const uint32_t v = vb + 16u * (uint32_t)wave::lane_id();
-  lz::Bytes16 x = {{0, 0, 0, 0}};
+  wave::u32x4 x = {0, 0, 0, 0};
   if (v >= r.vbeg && v + 16 <= r.vend) {
-    x = *(const lz::Bytes16*)(r.base + v); /* 16-byte aligned */
+    x = wave::gload_u32x4_aligned(r.base + v);
   } else if (v + 16 > r.vbeg && v < r.vend) {
+    uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
     for (uint32_t j = 0; j < 16; ++j) {
       if (v + j >= r.vbeg && v + j < r.vend) {
-        x.w[j >> 2] |= (uint32_t)r.base[v + j] << (8 * (j & 3));
+        w[j >> 2] |= wave::gload_u8(r.base + v + j) << (8 * (j & 3));
       }
     }
+    x.x = w[0];
+    x.y = w[1];
+    x.z = w[2];
+    x.w = w[3];
   }
   const uint32_t idx = v & (kInRing - 1);
-  *(lz::Bytes16*)(r.ring + idx) = x;
+  *(wave::u32x4*)(r.ring + idx) = x;
   if (idx == 0) {
-    *(lz::Bytes16*)(r.ring + kInRing) = x; /* mirror: 4-byte reads may run past the end */
+    *(wave::u32x4*)(r.ring + kInRing) = x; /* mirror: 4-byte reads may run past the end */
   }
 }
 
@@ -133,7 +141,7 @@ __device__ __forceinline__ uint32_t in_byte(const InRing& r, uint32_t v)
   if (v >= r.lo && v < r.hi) {
     return r.ring[v & (kInRing - 1)];
   }
-  return r.base[v];
+  return wave::gload_u8(r.base + v);
 }
 
 /* Same for a wave-uniform position; the result is uniform. */
@@ -187,13 +195,13 @@ __device__ __forceinline__ void out_make_room(OutWindow& w, uint32_t op)
   const uint32_t lane = (uint32_t)wave::lane_id();
   for (uint32_t base = 0; base < len; base += 1024) {
     const uint32_t i = base + lane * 16;
-    lz::Bytes16 t = {{0, 0, 0, 0}};
+    wave::u32x4 t = {0, 0, 0, 0};
     if (i < len) {
-      t = *(const lz::Bytes16*)(w.win + shift + i);
+      t = *(const wave::u32x4*)(w.win + shift + i);
     }
     wave::sync(); /* every lane has read before any lane overwrites */
     if (i < len) {
-      *(lz::Bytes16*)(w.win + i) = t;
+      *(wave::u32x4*)(w.win + i) = t;
     }
     wave::sync();
   }
@@ -219,13 +227,13 @@ __device__ __forceinline__ void out_flush(const OutWindow& w, uint32_t from, uin
   uint8_t* gout = w.out - w.align;            /* so that gout + a == out + pos */
   const uint8_t* lwin = w.win - w.wbase;      /* so that lwin + a == win + (pos - wbase + align) */
   if (lane < body_lo - a_from) {
-    gout[a_from + lane] = lwin[a_from + lane];
+    wave::gstore_u8(gout + a_from + lane, lwin[a_from + lane]);
   }
   for (uint32_t a = body_lo + lane * 16; a < body_hi; a += 1024) {
-    *(lz::Bytes16*)(gout + a) = *(const lz::Bytes16*)(lwin + a);
+    wave::gstore_u32x4_aligned(gout + a, *(const wave::u32x4*)(lwin + a));
   }
   if (lane < a_to - body_hi) {
-    gout[body_hi + lane] = lwin[body_hi + lane];
+    wave::gstore_u8(gout + body_hi + lane, lwin[body_hi + lane]);
   }
 }
 
@@ -270,7 +278,7 @@ __device__ __forceinline__ void load_dwords_clamped(uint32_t (&buf)[8], const ui
 #pragma unroll
   for (uint32_t i = 0; i < STEPS; ++i) {
     const uint32_t o = 4 * i < last ? 4 * i : last;
-    buf[i] = lz::ld_u32(src + o);
+    buf[i] = wave::gload_u32(src + o);
   }
 }
 
@@ -326,16 +334,16 @@ __device__ __forceinline__ void lds_match_copy(uint8_t* d, uint32_t off, uint32_
   }
 }
 
-/* dst (LDS) <- src (HBM or LDS), non-overlapping, whole wave, any alignment. */
+/* dst (LDS) <- src (HBM), non-overlapping, whole wave, any alignment. */
 __device__ __forceinline__ void copy_to_lds(uint8_t* dst, const uint8_t* src, uint32_t len)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   uint32_t base = 0;
   for (; base + 256 <= len; base += 256) {
-    lz::st_u32(dst + base + lane * 4, lz::ld_u32(src + base + lane * 4));
+    lz::st_u32(dst + base + lane * 4, wave::gload_u32(src + base + lane * 4));
   }
   for (uint32_t i = base + lane; i < len; i += 64) {
-    dst[i] = src[i];
+    dst[i] = (uint8_t)wave::gload_u8(src + i);
   }
 }
 

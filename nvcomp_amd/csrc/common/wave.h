@@ -15,6 +15,43 @@ namespace wave {
 
 constexpr int kSize = 64;
 
+/* 16-byte register quad for naturally aligned LDS / global accesses
+ * (ds_read_b128 / global_load_dwordx4). */
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+/* HBM pointers arrive through pointer arrays, so the compiler cannot prove their
+ * address space and would emit flat_* accesses (which also occupy the LDS
+ * counter). These casts state it: global_load / global_store. */
+#define WAVE_GLOBAL __attribute__((address_space(1)))
+struct __attribute__((packed)) PackedU32
+{
+  uint32_t v;
+};
+struct __attribute__((packed)) PackedU32x4
+{
+  uint32_t v[4];
+};
+__device__ __forceinline__ uint32_t gload_u8(const uint8_t* p)
+{
+  return *(const WAVE_GLOBAL uint8_t*)p;
+}
+__device__ __forceinline__ uint32_t gload_u32(const uint8_t* p) /* any alignment */
+{
+  return ((const WAVE_GLOBAL PackedU32*)p)->v;
+}
+__device__ __forceinline__ u32x4 gload_u32x4_aligned(const uint8_t* p)
+{
+  return *(const WAVE_GLOBAL u32x4*)p;
+}
+__device__ __forceinline__ void gstore_u8(uint8_t* p, uint32_t v)
+{
+  *(WAVE_GLOBAL uint8_t*)p = (uint8_t)v;
+}
+__device__ __forceinline__ void gstore_u32x4_aligned(uint8_t* p, u32x4 v)
+{
+  *(WAVE_GLOBAL u32x4*)p = v;
+}
+
 __device__ __forceinline__ int lane_id()
 {
   return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -55,6 +92,16 @@ __device__ __forceinline__ T* uniform_ptr(T* p)
 __device__ __forceinline__ uint32_t write_lane(uint32_t vec, uint32_t val, uint32_t lane)
 {
   return ((uint32_t)lane_id() == lane) ? val : vec;
+}
+
+/* Same through v_writelane_b32: one VALU op instead of three. A VALU op may read
+ * only one SGPR, so the lane select travels in M0 (SALU write of M0, one wait
+ * state, then the lane write). M0 is a reserved register the compiler only uses
+ * around LDS-DMA / s_movrel / message instructions, none of which this library emits. */
+__device__ __forceinline__ uint32_t write_lane_scalar(uint32_t vec, uint32_t val, uint32_t lane)
+{
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(val), "s"(lane));
+  return vec;
 }
 
 /* Per-lane gather: lane i receives v of lane src_lane(i) (ds_bpermute_b32). */

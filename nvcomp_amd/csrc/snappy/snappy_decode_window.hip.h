@@ -108,14 +108,14 @@ __device__ __forceinline__ uint32_t chase(Chase& c, const lzw::InRing& r, uint32
       if (k <= 64 - 32) { /* a 64-byte sub-window holds at most 32 elements (>= 2 bytes each) */
         while (c.q < lim) {
           const uint32_t d = wave::read_lane(c.nx[j], c.q - base);
-          seqpos = wave::write_lane(seqpos, c.q, k);
+          seqpos = wave::write_lane_scalar(seqpos, c.q, k);
           ++k;
           c.q += d;
         }
       } else {
         while (c.q < lim && k < 64) {
           const uint32_t d = wave::read_lane(c.nx[j], c.q - base);
-          seqpos = wave::write_lane(seqpos, c.q, k);
+          seqpos = wave::write_lane_scalar(seqpos, c.q, k);
           ++k;
           c.q += d;
         }

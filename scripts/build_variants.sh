@@ -15,7 +15,7 @@ build() { # tag, flags...
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o nvcomp_amd/lib/alt/libnvcomp_${tag}.so $objs
   echo "built $tag"
 }
-build w8k  -DNVCOMP_LZW_OUTWIN=8192 -DNVCOMP_LZW_INRING=4096 -DNVCOMP_LZW_WAVES_PER_SIMD=3
-build w4k  -DNVCOMP_LZW_OUTWIN=4096 -DNVCOMP_LZW_INRING=2048 -DNVCOMP_LZW_WAVES_PER_SIMD=5
-build w4k6 -DNVCOMP_LZW_OUTWIN=4096 -DNVCOMP_LZW_INRING=2048 -DNVCOMP_LZW_WAVES_PER_SIMD=6
-build w2k  -DNVCOMP_LZW_OUTWIN=2048 -DNVCOMP_LZW_INRING=2048 -DNVCOMP_LZW_WAVES_PER_SIMD=8
+build w2kb1 -DNVCOMP_LZW_OUTWIN=2048 -DNVCOMP_LZW_BATCHMAX=1024 -DNVCOMP_LZW_KEEP=768 -DNVCOMP_LZW_INRING=2048 -DNVCOMP_LZW_WAVES_PER_SIMD=8
+build w2kb1o6 -DNVCOMP_LZW_OUTWIN=2048 -DNVCOMP_LZW_BATCHMAX=1024 -DNVCOMP_LZW_KEEP=768 -DNVCOMP_LZW_INRING=2048 -DNVCOMP_LZW_WAVES_PER_SIMD=6
+build w3kb1 -DNVCOMP_LZW_OUTWIN=3072 -DNVCOMP_LZW_BATCHMAX=1280 -DNVCOMP_LZW_KEEP=1536 -DNVCOMP_LZW_INRING=2048 -DNVCOMP_LZW_WAVES_PER_SIMD=7
+build w4kb1 -DNVCOMP_LZW_OUTWIN=4096 -DNVCOMP_LZW_BATCHMAX=1536 -DNVCOMP_LZW_KEEP=2048 -DNVCOMP_LZW_INRING=2048 -DNVCOMP_LZW_WAVES_PER_SIMD=6

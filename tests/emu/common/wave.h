@@ -13,6 +13,11 @@ namespace wave {
 
 constexpr int kSize = 64;
 
+struct u32x4
+{
+  uint32_t x, y, z, w;
+};
+
 enum OpId { kBallot = 1, kReadLane, kUniform, kShuffle, kScan, kMax, kSync };
 
 inline int lane_id() { return emu::cur()->lane; }
@@ -81,6 +86,22 @@ inline uint32_t write_lane(uint32_t vec, uint32_t val, uint32_t lane)
 {
   return ((uint32_t)lane_id() == lane) ? val : vec;
 }
+
+inline uint32_t write_lane_scalar(uint32_t vec, uint32_t val, uint32_t lane)
+{
+  return write_lane(vec, val, lane);
+}
+
+inline uint32_t gload_u8(const uint8_t* p) { return *p; }
+inline uint32_t gload_u32(const uint8_t* p)
+{
+  uint32_t v;
+  memcpy(&v, p, 4);
+  return v;
+}
+inline u32x4 gload_u32x4_aligned(const uint8_t* p) { return *(const u32x4*)p; }
+inline void gstore_u8(uint8_t* p, uint32_t v) { *p = (uint8_t)v; }
+inline void gstore_u32x4_aligned(uint8_t* p, u32x4 v) { *(u32x4*)p = v; }
 
 inline uint32_t shuffle(uint32_t v, uint32_t src_lane)
 {
