@@ -1,0 +1,420 @@
+/*
+ * api/cascaded_api.hip -- C ABI of the batched Cascaded codec
+ * (include/nvcomp/cascaded.h) and the kernels it launches.
+ *
+ * Chunk container (little endian, 4-byte aligned; DESIGN.md "Cascaded stream layout"):
+ *   u32 'CASC' | u8 type, num_RLEs, num_deltas, use_bp | u32 uncompressed bytes
+ *   | u32 sub-chunk bytes | u32 num_sub | u32 sub_end[num_sub] | sub-chunk payloads
+ */
+#include <hip/hip_runtime.h>
+
+#include "nvcomp/cascaded.h"
+
+#include "cascaded/cascaded.hip.h"
+
+namespace {
+
+constexpr uint32_t kHeaderBytes = 20;
+constexpr uint32_t kFastBudget = 16 * 1024; /* LDS per wave of the first decode pass (4 waves per workgroup) */
+constexpr uint32_t kBigBudget = 64 * 1024;  /* second pass: one wave per workgroup */
+
+void clear_stale_error()
+{
+  (void)hipGetLastError();
+}
+
+nvcompStatus_t launch_status()
+{
+  return hipGetLastError() == hipSuccess ? nvcompSuccess : nvcompErrorCudaError;
+}
+
+bool opts_ok(const nvcompBatchedCascadedOpts_t& o)
+{
+  if (o.type < NVCOMP_TYPE_CHAR || o.type > NVCOMP_TYPE_ULONGLONG) {
+    return false;
+  }
+  const size_t w = (size_t)1 << ((unsigned)o.type >> 1);
+  return o.num_RLEs >= 0 && o.num_RLEs <= 7 && o.num_deltas >= 0 && o.num_deltas <= 7 && (o.use_bp == 0 || o.use_bp == 1)
+         && o.chunk_size >= 256 && o.chunk_size <= 16384 && o.chunk_size % w == 0;
+}
+
+struct Carve
+{
+  uint8_t* a;
+  uint8_t* b;
+  uint16_t* pool;
+  uint16_t* marks;
+};
+
+__device__ __forceinline__ Carve carve(uint8_t* lds, uint32_t sub_bytes, uint32_t width, uint32_t num_rles)
+{
+  const uint32_t n = sub_bytes / width;
+  const uint32_t vals = (sub_bytes + 15u) & ~15u;
+  const uint32_t rl = num_rles ? num_rles : 1;
+  const uint32_t pool = (2u * n * rl + 15u) & ~15u;
+  Carve c;
+  c.a = lds;
+  c.b = lds + vals;
+  c.pool = (uint16_t*)(lds + 2 * vals);
+  c.marks = (uint16_t*)(lds + 2 * vals + pool);
+  return c;
+}
+
+__global__ void cascaded_compress_kernel(
+    const void* const* __restrict__ in_ptrs,
+    const size_t* __restrict__ in_bytes,
+    size_t batch_size,
+    void* const* __restrict__ out_ptrs,
+    size_t* out_bytes,
+    casc::Params p,
+    uint32_t lds_per_wave,
+    uint32_t waves_per_block)
+{
+  WAVE_DYNAMIC_LDS(lds);
+  const uint32_t wv = wave::uniform(threadIdx.x >> 6);
+  const size_t chunk = (size_t)blockIdx.x * waves_per_block + wv;
+  if (chunk >= batch_size) {
+    return;
+  }
+  const uint8_t* src = wave::uniform_ptr((const uint8_t*)in_ptrs[chunk]);
+  uint8_t* dst = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
+  const uint32_t n_bytes = (uint32_t)wave::uniform64(in_bytes[chunk]);
+  const uint32_t w = casc::type_width(p.type);
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  if (n_bytes % w != 0) { /* contract: chunk sizes are multiples of the element size */
+    if (lane == 0) {
+      out_bytes[chunk] = 0;
+    }
+    return;
+  }
+  const uint32_t num_sub = (n_bytes + p.sub_bytes - 1) / p.sub_bytes;
+  if (lane == 0) {
+    uint32_t* h = (uint32_t*)dst;
+    h[0] = casc::kMagic;
+    h[1] = p.type | (p.num_rles << 8) | (p.num_deltas << 16) | ((p.use_bp ? 1u : 0u) << 24);
+    h[2] = n_bytes;
+    h[3] = p.sub_bytes;
+    h[4] = num_sub;
+  }
+  uint32_t* table = (uint32_t*)(dst + kHeaderBytes);
+  uint8_t* payload = dst + kHeaderBytes + 4 * (size_t)num_sub;
+  const Carve c = carve(lds + (size_t)wv * lds_per_wave, p.sub_bytes, w, p.num_rles);
+  uint32_t pay = 0;
+  for (uint32_t s = 0; s < num_sub; ++s) {
+    const uint32_t off = s * p.sub_bytes;
+    const uint32_t bytes = n_bytes - off < p.sub_bytes ? n_bytes - off : p.sub_bytes;
+    uint32_t sz;
+    switch (w) {
+    case 1:
+      sz = casc::compress_sub<uint8_t>(src + off, bytes, payload + pay, p, (uint8_t*)c.a, (uint8_t*)c.b, c.pool);
+      break;
+    case 2:
+      sz = casc::compress_sub<uint16_t>(src + off, bytes, payload + pay, p, (uint16_t*)c.a, (uint16_t*)c.b, c.pool);
+      break;
+    case 4:
+      sz = casc::compress_sub<uint32_t>(src + off, bytes, payload + pay, p, (uint32_t*)c.a, (uint32_t*)c.b, c.pool);
+      break;
+    default:
+      sz = casc::compress_sub<uint64_t>(src + off, bytes, payload + pay, p, (uint64_t*)c.a, (uint64_t*)c.b, c.pool);
+      break;
+    }
+    pay += sz;
+    if (lane == 0) {
+      table[s] = pay;
+    }
+    wave::sync();
+  }
+  if (lane == 0) {
+    out_bytes[chunk] = kHeaderBytes + 4 * (size_t)num_sub + pay;
+  }
+}
+
+/* pass 0: every chunk whose streams fit kFastBudget of LDS; the others are flagged in
+ * `todo` and decoded by pass 1 (one wave per workgroup, kBigBudget). */
+__global__ void cascaded_decompress_kernel(
+    const void* const* __restrict__ comp_ptrs,
+    const size_t* __restrict__ comp_bytes,
+    const size_t* out_caps,
+    size_t* actual_bytes,
+    size_t batch_size,
+    void* const* __restrict__ out_ptrs,
+    nvcompStatus_t* statuses,
+    uint32_t* todo,
+    uint32_t pass,
+    uint32_t lds_per_wave,
+    uint32_t waves_per_block)
+{
+  WAVE_DYNAMIC_LDS(lds);
+  const uint32_t wv = wave::uniform(threadIdx.x >> 6);
+  const size_t chunk = (size_t)blockIdx.x * waves_per_block + wv;
+  if (chunk >= batch_size) {
+    return;
+  }
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  if (pass == 1 && wave::uniform(todo[chunk]) == 0) {
+    return;
+  }
+  const uint8_t* src = wave::uniform_ptr((const uint8_t*)comp_ptrs[chunk]);
+  uint8_t* dst = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
+  const size_t src_len = wave::uniform64(comp_bytes[chunk]);
+  const size_t cap = wave::uniform64(out_caps[chunk]);
+  uint32_t err = casc::kOk;
+  uint32_t produced = 0;
+  bool deferred = false;
+  do {
+    if (((uintptr_t)src & 3u) != 0) {
+      err = casc::kErrAlign;
+      break;
+    }
+    if (src_len < kHeaderBytes) {
+      err = casc::kErrInput;
+      break;
+    }
+    const uint32_t* h = (const uint32_t*)src;
+    const uint32_t magic = wave::uniform(h[0]);
+    const uint32_t cfg = wave::uniform(h[1]);
+    const uint32_t n_bytes = wave::uniform(h[2]);
+    const uint32_t sub = wave::uniform(h[3]);
+    const uint32_t num_sub = wave::uniform(h[4]);
+    const uint32_t type = cfg & 0xffu, num_rles = (cfg >> 8) & 0xffu, num_deltas = (cfg >> 16) & 0xffu;
+    if (magic != casc::kMagic || type > 7 || num_rles > 7 || num_deltas > 7) {
+      err = casc::kErrInput;
+      break;
+    }
+    const uint32_t w = casc::type_width(type);
+    if (sub == 0 || sub % w != 0 || n_bytes % w != 0 || sub / w > casc::kMaxElems
+        || num_sub != (uint32_t)(((uint64_t)n_bytes + sub - 1) / sub) || src_len < kHeaderBytes + 4 * (uint64_t)num_sub) {
+      err = casc::kErrInput;
+      break;
+    }
+    if (n_bytes > cap) {
+      err = casc::kErrOutput;
+      break;
+    }
+    if (((uintptr_t)dst & (w - 1)) != 0) {
+      err = casc::kErrAlign;
+      break;
+    }
+    if (casc::lds_bytes_per_wave(sub, w, num_rles) > lds_per_wave) {
+      if (pass == 0) {
+        deferred = true;
+      } else {
+        err = casc::kErrInput; /* larger than anything the compressor accepts */
+      }
+      break;
+    }
+    const uint32_t* table = (const uint32_t*)(src + kHeaderBytes);
+    const uint8_t* payload = src + kHeaderBytes + 4 * (size_t)num_sub;
+    const uint32_t pay_len = (uint32_t)(src_len - kHeaderBytes - 4 * (size_t)num_sub);
+    const Carve c = carve(lds + (size_t)wv * lds_per_wave, sub, w, num_rles);
+    uint32_t begin = 0;
+    for (uint32_t s = 0; s < num_sub && !err; ++s) {
+      const uint32_t end = wave::uniform(table[s]);
+      const uint32_t off = s * sub;
+      const uint32_t bytes = n_bytes - off < sub ? n_bytes - off : sub;
+      if (end < begin || end > pay_len || end - begin < 4) {
+        err = casc::kErrInput;
+        break;
+      }
+      bool ok;
+      switch (w) {
+      case 1:
+        ok = casc::decompress_sub<uint8_t>(payload + begin, end - begin, dst + off, bytes, num_rles, num_deltas,
+                                           (uint8_t*)c.a, (uint8_t*)c.b, c.pool, c.marks);
+        break;
+      case 2:
+        ok = casc::decompress_sub<uint16_t>(payload + begin, end - begin, dst + off, bytes, num_rles, num_deltas,
+                                            (uint16_t*)c.a, (uint16_t*)c.b, c.pool, c.marks);
+        break;
+      case 4:
+        ok = casc::decompress_sub<uint32_t>(payload + begin, end - begin, dst + off, bytes, num_rles, num_deltas,
+                                            (uint32_t*)c.a, (uint32_t*)c.b, c.pool, c.marks);
+        break;
+      default:
+        ok = casc::decompress_sub<uint64_t>(payload + begin, end - begin, dst + off, bytes, num_rles, num_deltas,
+                                            (uint64_t*)c.a, (uint64_t*)c.b, c.pool, c.marks);
+        break;
+      }
+      if (!ok) {
+        err = casc::kErrInput;
+      }
+      begin = end;
+      wave::sync();
+    }
+    produced = n_bytes;
+  } while (false);
+  if (lane == 0) {
+    if (pass == 0) {
+      todo[chunk] = deferred ? 1u : 0u;
+    }
+    if (!deferred) {
+      if (actual_bytes != nullptr) {
+        actual_bytes[chunk] = err ? 0 : produced;
+      }
+      if (statuses != nullptr) {
+        statuses[chunk] = err == casc::kOk ? nvcompSuccess
+                          : (err & casc::kErrAlign) ? nvcompErrorAlignment
+                                                    : nvcompErrorCannotDecompress;
+      }
+    }
+  }
+}
+
+__global__ void cascaded_size_kernel(
+    const void* const* __restrict__ comp_ptrs, const size_t* __restrict__ comp_bytes, size_t* sizes, size_t batch_size)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch_size) {
+    return;
+  }
+  const uint8_t* src = (const uint8_t*)comp_ptrs[i];
+  size_t n = 0;
+  if (comp_bytes[i] >= kHeaderBytes && ((uintptr_t)src & 3u) == 0) {
+    const uint32_t* h = (const uint32_t*)src;
+    if (h[0] == casc::kMagic) {
+      n = h[2];
+    }
+  }
+  sizes[i] = n;
+}
+
+} // namespace
+
+extern "C" {
+
+nvcompStatus_t nvcompBatchedCascadedCompressGetTempSize(
+    size_t /*batch_size*/, size_t max_uncompressed_chunk_bytes, nvcompBatchedCascadedOpts_t format_opts, size_t* temp_bytes)
+{
+  if (temp_bytes == nullptr || !opts_ok(format_opts)) {
+    return nvcompErrorInvalidValue;
+  }
+  if (max_uncompressed_chunk_bytes > nvcompCascadedCompressionMaxAllowedChunkSize) {
+    return nvcompErrorChunkSizeTooLarge;
+  }
+  *temp_bytes = 0; /* all intermediate streams live in LDS */
+  return nvcompSuccess;
+}
+
+nvcompStatus_t nvcompBatchedCascadedCompressGetMaxOutputChunkSize(
+    size_t max_uncompressed_chunk_bytes, nvcompBatchedCascadedOpts_t format_opts, size_t* max_compressed_bytes)
+{
+  if (max_compressed_bytes == nullptr || !opts_ok(format_opts)) {
+    return nvcompErrorInvalidValue;
+  }
+  if (max_uncompressed_chunk_bytes > nvcompCascadedCompressionMaxAllowedChunkSize) {
+    return nvcompErrorChunkSizeTooLarge;
+  }
+  /* worst case: every sub-chunk stored raw (4-byte marker + bytes padded to 4) */
+  const size_t num_sub = (max_uncompressed_chunk_bytes + format_opts.chunk_size - 1) / format_opts.chunk_size;
+  *max_compressed_bytes = kHeaderBytes + 4 * num_sub + 8 * num_sub + ((max_uncompressed_chunk_bytes + 3) & ~(size_t)3);
+  return nvcompSuccess;
+}
+
+nvcompStatus_t nvcompBatchedCascadedCompressAsync(
+    const void* const* device_uncompressed_ptrs,
+    const size_t* device_uncompressed_bytes,
+    size_t max_uncompressed_chunk_bytes,
+    size_t batch_size,
+    void* /*device_temp_ptr*/,
+    size_t /*temp_bytes*/,
+    void* const* device_compressed_ptrs,
+    size_t* device_compressed_bytes,
+    nvcompBatchedCascadedOpts_t format_opts,
+    hipStream_t stream)
+{
+  if (!opts_ok(format_opts)) {
+    return nvcompErrorInvalidValue;
+  }
+  if (max_uncompressed_chunk_bytes > nvcompCascadedCompressionMaxAllowedChunkSize) {
+    return nvcompErrorChunkSizeTooLarge;
+  }
+  if (batch_size == 0) {
+    return nvcompSuccess;
+  }
+  if (device_uncompressed_ptrs == nullptr || device_uncompressed_bytes == nullptr || device_compressed_ptrs == nullptr
+      || device_compressed_bytes == nullptr) {
+    return nvcompErrorInvalidValue;
+  }
+  casc::Params p;
+  p.sub_bytes = (uint32_t)format_opts.chunk_size;
+  p.type = (uint32_t)format_opts.type;
+  p.num_rles = (uint32_t)format_opts.num_RLEs;
+  p.num_deltas = (uint32_t)format_opts.num_deltas;
+  p.use_bp = (uint32_t)format_opts.use_bp;
+  const uint32_t w = 1u << (p.type >> 1);
+  const uint32_t per_wave = casc::lds_bytes_per_wave(p.sub_bytes, w, p.num_rles);
+  if (per_wave > kBigBudget) {
+    return nvcompErrorNotSupported;
+  }
+  uint32_t waves = kBigBudget / per_wave;
+  waves = waves > 4 ? 4 : waves;
+  const unsigned grid = (unsigned)((batch_size + waves - 1) / waves);
+  clear_stale_error();
+  hipLaunchKernelGGL(cascaded_compress_kernel, dim3(grid), dim3(64 * waves), per_wave * waves, stream,
+                     device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
+                     device_compressed_bytes, p, per_wave, waves);
+  return launch_status();
+}
+
+nvcompStatus_t nvcompBatchedCascadedDecompressGetTempSize(
+    size_t num_chunks, size_t /*max_uncompressed_chunk_bytes*/, size_t* temp_bytes)
+{
+  if (temp_bytes == nullptr) {
+    return nvcompErrorInvalidValue;
+  }
+  *temp_bytes = 4 * num_chunks; /* one "needs the large-LDS pass" word per chunk */
+  return nvcompSuccess;
+}
+
+nvcompStatus_t nvcompBatchedCascadedDecompressAsync(
+    const void* const* device_compressed_ptrs,
+    const size_t* device_compressed_bytes,
+    const size_t* device_uncompressed_bytes,
+    size_t* device_actual_uncompressed_bytes,
+    size_t batch_size,
+    void* const device_temp_ptr,
+    size_t temp_bytes,
+    void* const* device_uncompressed_ptrs,
+    nvcompStatus_t* device_statuses,
+    hipStream_t stream)
+{
+  if (batch_size == 0) {
+    return nvcompSuccess;
+  }
+  if (device_compressed_ptrs == nullptr || device_compressed_bytes == nullptr || device_uncompressed_bytes == nullptr
+      || device_uncompressed_ptrs == nullptr || device_temp_ptr == nullptr || temp_bytes < 4 * batch_size) {
+    return nvcompErrorInvalidValue;
+  }
+  uint32_t* todo = (uint32_t*)device_temp_ptr;
+  clear_stale_error();
+  hipLaunchKernelGGL(cascaded_decompress_kernel, dim3((unsigned)((batch_size + 3) / 4)), dim3(256), 4 * kFastBudget,
+                     stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
+                     device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 0u,
+                     kFastBudget, 4u);
+  hipLaunchKernelGGL(cascaded_decompress_kernel, dim3((unsigned)batch_size), dim3(64), kBigBudget, stream,
+                     device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
+                     device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 1u,
+                     kBigBudget, 1u);
+  return launch_status();
+}
+
+nvcompStatus_t nvcompBatchedCascadedGetDecompressSizeAsync(
+    const void* const* device_compressed_ptrs,
+    const size_t* device_compressed_bytes,
+    size_t* device_uncompressed_bytes,
+    size_t batch_size,
+    hipStream_t stream)
+{
+  if (batch_size == 0) {
+    return nvcompSuccess;
+  }
+  if (device_compressed_ptrs == nullptr || device_compressed_bytes == nullptr || device_uncompressed_bytes == nullptr) {
+    return nvcompErrorInvalidValue;
+  }
+  clear_stale_error();
+  hipLaunchKernelGGL(cascaded_size_kernel, dim3((unsigned)((batch_size + 255) / 256)), dim3(256), 0, stream,
+                     device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes, batch_size);
+  return launch_status();
+}
+
+} // extern "C"

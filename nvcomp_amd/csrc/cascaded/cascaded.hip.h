@@ -1,0 +1,543 @@
+/*
+ * cascaded/cascaded.hip.h -- batched Cascaded codec (RLE + delta + bit-packing)
+ * for gfx950. Replaces the device side of nvcompBatchedCascaded{Compress,
+ * Decompress,GetDecompressSize}Async (reference call sites:
+ * benchmarks/benchmark_cascaded_chunked.cu:137-151; scheme:
+ * doc/cascaded_overview.md:6-44).
+ *
+ * One wavefront per user chunk; the chunk is cut into sub-chunks of
+ * opts.chunk_size bytes that are coded independently, one after the other, with
+ * all intermediate streams in LDS:
+ *   RLE    : run starts = ballot of (v[i] != v[i-1]), compacted with popcounts;
+ *   delta  : d[i] = v[i] - v[i-1] per 64-element tile (back to front), inverse =
+ *            DPP prefix sum with a carry between tiles;
+ *   bitpack: wave-wide min/max, then every lane assembles whole 32-bit output
+ *            words (no atomics); unpack is element-parallel.
+ * The container is this library's own (DESIGN.md "Cascaded stream layout");
+ * oracle/cascaded_ref.c is its bit-exact CPU model.
+ */
+#pragma once
+
+#include "common/wave.h"
+
+namespace casc {
+
+constexpr uint32_t kMagic = 0x43534143u; /* 'CASC' */
+constexpr uint32_t kRawMarker = 0xffffffffu;
+constexpr uint32_t kMaxElems = 16384;
+
+enum : uint32_t { kOk = 0, kErrInput = 1, kErrOutput = 2, kErrAlign = 4 };
+
+struct Params
+{
+  uint32_t sub_bytes; /* opts.chunk_size */
+  uint32_t type;      /* nvcompType_t 0..7 */
+  uint32_t num_rles;
+  uint32_t num_deltas;
+  uint32_t use_bp;
+};
+
+__device__ __forceinline__ uint32_t type_width(uint32_t t)
+{
+  return 1u << (t >> 1); /* 0,1 -> 1; 2,3 -> 2; 4,5 -> 4; 6,7 -> 8 */
+}
+
+__device__ __forceinline__ bool type_signed(uint32_t t)
+{
+  return (t & 1u) == 0;
+}
+
+__device__ __forceinline__ uint64_t width_mask(uint32_t w)
+{
+  return w == 8 ? ~0ull : ((1ull << (8 * w)) - 1);
+}
+
+__device__ __forceinline__ uint32_t bits_for(uint64_t range)
+{
+  return range ? 64u - (uint32_t)__builtin_clzll(range) : 0u;
+}
+
+/* order-preserving key: signed values of width w -> unsigned order */
+__device__ __forceinline__ uint64_t to_key(uint64_t v, uint32_t w, bool as_signed)
+{
+  if (!as_signed) {
+    return v;
+  }
+  const uint32_t sh = 64 - 8 * w;
+  return (uint64_t)((int64_t)(v << sh) >> sh) ^ 0x8000000000000000ull;
+}
+
+__device__ __forceinline__ uint64_t shuffle64(uint64_t v, uint32_t src)
+{
+  const uint32_t lo = wave::shuffle((uint32_t)v, src);
+  const uint32_t hi = wave::shuffle((uint32_t)(v >> 32), src);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t reduce_min64(uint64_t v)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  for (uint32_t m = 32; m >= 1; m >>= 1) {
+    const uint64_t o = shuffle64(v, lane ^ m);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint64_t reduce_max64(uint64_t v)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  for (uint32_t m = 32; m >= 1; m >>= 1) {
+    const uint64_t o = shuffle64(v, lane ^ m);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+/* inclusive prefix sum of 64-bit values across the wave */
+__device__ __forceinline__ uint64_t scan_add64(uint64_t v)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  for (uint32_t d = 1; d < 64; d <<= 1) {
+    const uint64_t o = shuffle64(v, (lane - d) & 63u);
+    if (lane >= d) {
+      v += o;
+    }
+  }
+  return v;
+}
+
+/* ---- element access: streams are arrays of T (values) or uint16_t (runs) ---- */
+
+template <typename T>
+struct Stream
+{
+  const T* p;
+  __device__ __forceinline__ uint64_t get(uint32_t i) const { return (uint64_t)p[i]; }
+};
+
+/* min / range of a stream -> (min value as stored, bits) */
+template <typename S>
+__device__ __forceinline__ void stream_range(const S& s, uint32_t count, uint32_t w, bool as_signed, uint64_t& mn_out,
+                                             uint32_t& bits_out)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  uint64_t lo = ~0ull, hi = 0;
+  for (uint32_t i = lane; i < count; i += 64) {
+    const uint64_t k = to_key(s.get(i), w, as_signed);
+    lo = k < lo ? k : lo;
+    hi = k > hi ? k : hi;
+  }
+  lo = reduce_min64(lo);
+  hi = reduce_max64(hi);
+  if (count == 0) {
+    mn_out = 0;
+    bits_out = 0;
+    return;
+  }
+  bits_out = bits_for(hi - lo);
+  /* back from key space: the minimum as a w-byte value */
+  mn_out = (as_signed ? (lo ^ 0x8000000000000000ull) : lo) & width_mask(w);
+}
+
+__device__ __forceinline__ uint32_t stream_bytes(uint32_t count, uint32_t bits)
+{
+  return 12 + 4 * (uint32_t)(((uint64_t)count * bits + 31) / 32);
+}
+
+/* Write one packed stream at dst (global, 4-byte aligned). Every lane assembles
+ * whole output words from the elements that overlap them. */
+template <typename S>
+__device__ __forceinline__ uint32_t pack_stream(uint8_t* dst, const S& s, uint32_t count, uint32_t w, uint64_t mn,
+                                                uint32_t bits)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  uint32_t* out = (uint32_t*)dst;
+  if (lane == 0) {
+    out[0] = bits;
+    out[1] = (uint32_t)mn;
+    out[2] = (uint32_t)(mn >> 32);
+  }
+  const uint32_t words = (uint32_t)(((uint64_t)count * bits + 31) / 32);
+  const uint64_t wmask = width_mask(w);
+  const uint64_t vmask = bits == 64 ? ~0ull : ((1ull << bits) - 1);
+  for (uint32_t k = lane; k < words; k += 64) {
+    const uint64_t bit0 = (uint64_t)k * 32;
+    uint32_t e = (uint32_t)(bit0 / bits);
+    uint32_t e_last = (uint32_t)((bit0 + 31) / bits);
+    e_last = e_last < count - 1 ? e_last : count - 1;
+    uint32_t word = 0;
+    for (; e <= e_last; ++e) {
+      const uint64_t x = ((s.get(e) - mn) & wmask) & vmask;
+      const int64_t rel = (int64_t)((uint64_t)e * bits) - (int64_t)bit0;
+      word |= rel >= 0 ? (uint32_t)(x << rel) : (uint32_t)(x >> (-rel));
+    }
+    out[3 + k] = word;
+  }
+  return 12 + 4 * words;
+}
+
+/* Unpack a stream from src (global, 4-byte aligned) into LDS dst[0..count). */
+template <typename T>
+__device__ __forceinline__ bool unpack_stream(const uint8_t* src, uint32_t avail, T* dst, uint32_t count, uint32_t w,
+                                              uint32_t& used)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  used = 0;
+  if (avail < 12) {
+    return false;
+  }
+  const uint32_t* in = (const uint32_t*)src;
+  const uint32_t bits = in[0];
+  const uint64_t mn = (uint64_t)in[1] | ((uint64_t)in[2] << 32);
+  if (bits > 64) {
+    return false;
+  }
+  const uint32_t words = (uint32_t)(((uint64_t)count * bits + 31) / 32);
+  if (avail < 12 + 4 * (uint64_t)words) {
+    return false;
+  }
+  const uint64_t wmask = width_mask(w);
+  const uint64_t vmask = bits == 64 ? ~0ull : ((1ull << bits) - 1);
+  for (uint32_t i = lane; i < count; i += 64) {
+    uint64_t x = 0;
+    if (bits) {
+      const uint64_t bit = (uint64_t)i * bits;
+      const uint32_t k = (uint32_t)(bit / 32);
+      const uint32_t sh = (uint32_t)(bit % 32);
+      x = (uint64_t)in[3 + k] >> sh;
+      if (sh + bits > 32) {
+        x |= (uint64_t)in[3 + k + 1] << (32 - sh);
+      }
+      if (sh + bits > 64) {
+        x |= (uint64_t)in[3 + k + 2] << (64 - sh);
+      }
+      x &= vmask;
+    }
+    dst[i] = (T)((x + mn) & wmask);
+  }
+  used = 12 + 4 * words;
+  return true;
+}
+
+/* ---- layers ---------------------------------------------------------------- */
+
+/* RLE of A[0..c) -> values in B, run lengths in runs; returns the new count. */
+template <typename T>
+__device__ __forceinline__ uint32_t rle_encode(const T* A, uint32_t c, T* B, uint16_t* runs)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  uint32_t m = 0;
+  /* pass 1: compact run starts; runs[] temporarily holds the start index of each run */
+  for (uint32_t base = 0; base < c; base += 64) {
+    const uint32_t i = base + lane;
+    const bool in = i < c;
+    const T v = in ? A[i] : (T)0;
+    const T prev = (in && i > 0) ? A[i - 1] : (T)0;
+    const bool head = in && (i == 0 || v != prev);
+    const uint64_t mask = wave::ballot(head);
+    const uint32_t rank = wave::popc64(mask & ((1ull << lane) - 1));
+    if (head) {
+      B[m + rank] = v;
+      runs[m + rank] = (uint16_t)i;
+    }
+    m += wave::popc64(mask);
+  }
+  wave::sync();
+  /* pass 2: start indices -> run lengths (start of the next run minus own start) */
+  for (uint32_t base = 0; base < m; base += 64) {
+    const uint32_t j = base + lane;
+    uint32_t len = 0;
+    if (j < m) {
+      const uint32_t next = j + 1 < m ? runs[j + 1] : c;
+      len = next - runs[j];
+    }
+    wave::sync();
+    if (j < m) {
+      runs[j] = (uint16_t)len;
+    }
+    wave::sync();
+  }
+  return m;
+}
+
+/* in place: A[i] -= A[i-1] for i >= 1 (tiles back to front) */
+template <typename T>
+__device__ __forceinline__ void delta_encode(T* A, uint32_t c)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t tiles = (c + 63) / 64;
+  for (uint32_t t = tiles; t-- > 0;) {
+    const uint32_t i = t * 64 + lane;
+    T d = 0;
+    if (i < c) {
+      d = i > 0 ? (T)(A[i] - A[i - 1]) : A[i];
+    }
+    wave::sync();
+    if (i < c) {
+      A[i] = d;
+    }
+    wave::sync();
+  }
+}
+
+/* in place inclusive prefix sum (inverse delta) */
+template <typename T>
+__device__ __forceinline__ void delta_decode(T* A, uint32_t c)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  uint64_t carry = 0;
+  for (uint32_t base = 0; base < c; base += 64) {
+    const uint32_t i = base + lane;
+    const uint64_t v = i < c ? (uint64_t)A[i] : 0;
+    uint64_t s;
+    if (sizeof(T) <= 4) {
+      s = (uint64_t)wave::scan_add_inclusive((uint32_t)v);
+    } else {
+      s = scan_add64(v);
+    }
+    s += carry;
+    if (i < c) {
+      A[i] = (T)s;
+    }
+    /* carry = total of this tile (lane 63's inclusive sum) */
+    if (sizeof(T) <= 4) {
+      carry = (uint64_t)wave::read_lane((uint32_t)s, 63);
+    } else {
+      carry = ((uint64_t)wave::read_lane((uint32_t)(s >> 32), 63) << 32) | wave::read_lane((uint32_t)s, 63);
+    }
+  }
+  wave::sync();
+}
+
+/* Expand values A[0..c) with run lengths runs[0..c) into B[0..target).
+ * marks: LDS scratch of `target` uint16. Returns false if the runs are inconsistent. */
+template <typename T>
+__device__ __forceinline__ bool rle_decode(const T* A, const uint16_t* runs, uint32_t c, T* B, uint32_t target,
+                                           uint16_t* marks)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  for (uint32_t i = lane; i < target; i += 64) {
+    marks[i] = 0;
+  }
+  wave::sync();
+  /* exclusive scan of run lengths -> start of every run; mark it with (run index + 1) */
+  uint32_t carry = 0;
+  bool bad = false;
+  for (uint32_t base = 0; base < c; base += 64) {
+    const uint32_t j = base + lane;
+    const uint32_t r = j < c ? runs[j] : 0;
+    const uint32_t incl = wave::scan_add_inclusive(r) + carry;
+    const uint32_t start = incl - r;
+    if (j < c) {
+      if (r == 0 || incl > target) {
+        bad = true;
+      } else {
+        marks[start] = (uint16_t)(j + 1);
+      }
+    }
+    carry = wave::read_lane(incl, 63);
+  }
+  if (wave::ballot(bad) || carry != target) {
+    return false;
+  }
+  wave::sync();
+  /* running maximum of the marks = index of the run every output element belongs to */
+  uint32_t run_carry = 0;
+  for (uint32_t base = 0; base < target; base += 64) {
+    const uint32_t i = base + lane;
+    const uint32_t mk = i < target ? marks[i] : 0;
+    uint32_t run = wave::scan_max_inclusive(mk);
+    run = run > run_carry ? run : run_carry;
+    if (i < target) {
+      B[i] = A[run - 1];
+    }
+    run_carry = wave::read_lane(run, 63);
+  }
+  wave::sync();
+  return true;
+}
+
+/* ---- sub-chunk codec ------------------------------------------------------- */
+
+template <typename T>
+__device__ __forceinline__ uint32_t compress_sub(
+    const uint8_t* src, uint32_t bytes, uint8_t* dst, const Params& p, T* A, T* B, uint16_t* pool)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t w = sizeof(T);
+  const uint32_t n = bytes / w;
+  const T* in = (const T*)src;
+  for (uint32_t i = lane; i < n; i += 64) {
+    A[i] = in[i];
+  }
+  wave::sync();
+  const uint32_t layers = p.num_rles > p.num_deltas ? p.num_rles : p.num_deltas;
+  uint32_t counts[8];
+  uint32_t c = n;
+  uint32_t pool_used = 0;
+  uint32_t run_off[8];
+  T* cur = A;
+  T* oth = B;
+  for (uint32_t l = 0; l < layers; ++l) {
+    if (l < p.num_rles) {
+      run_off[l] = pool_used;
+      c = rle_encode(cur, c, oth, pool + pool_used);
+      pool_used += c;
+      counts[l] = c;
+      T* t = cur;
+      cur = oth;
+      oth = t;
+      wave::sync();
+    }
+    if (l < p.num_deltas) {
+      delta_encode(cur, c);
+    }
+  }
+  /* sizes first: a sub-chunk that would not shrink is stored raw */
+  uint64_t mins[9];
+  uint32_t bitsv[9];
+  uint32_t sz = 4 + 4 * p.num_rles;
+  for (uint32_t l = 0; l < p.num_rles; ++l) {
+    if (p.use_bp) {
+      Stream<uint16_t> s{pool + run_off[l]};
+      stream_range(s, counts[l], 2, false, mins[l], bitsv[l]);
+    } else {
+      mins[l] = 0;
+      bitsv[l] = 16;
+    }
+    sz += stream_bytes(counts[l], bitsv[l]);
+  }
+  {
+    const bool as_signed = p.num_deltas > 0 ? true : type_signed(p.type);
+    if (p.use_bp) {
+      Stream<T> s{cur};
+      stream_range(s, c, w, as_signed, mins[8], bitsv[8]);
+    } else {
+      mins[8] = 0;
+      bitsv[8] = 8 * w;
+    }
+    sz += stream_bytes(c, bitsv[8]);
+  }
+  const uint32_t raw_sz = 4 + ((bytes + 3u) & ~3u);
+  uint32_t* out32 = (uint32_t*)dst;
+  if (sz >= raw_sz) {
+    if (lane == 0) {
+      out32[0] = kRawMarker;
+    }
+    /* raw bytes, zero padded to a multiple of 4 */
+    const uint32_t padded = raw_sz - 4;
+    for (uint32_t i = lane; i < padded; i += 64) {
+      dst[4 + i] = i < bytes ? src[i] : (uint8_t)0;
+    }
+    return raw_sz;
+  }
+  if (lane == 0) {
+    out32[0] = n;
+    for (uint32_t l = 0; l < p.num_rles; ++l) {
+      out32[1 + l] = counts[l];
+    }
+  }
+  uint32_t pos = 4 + 4 * p.num_rles;
+  for (uint32_t l = 0; l < p.num_rles; ++l) {
+    Stream<uint16_t> s{pool + run_off[l]};
+    pos += pack_stream(dst + pos, s, counts[l], 2, mins[l], bitsv[l]);
+  }
+  {
+    Stream<T> s{cur};
+    pos += pack_stream(dst + pos, s, c, w, mins[8], bitsv[8]);
+  }
+  return pos;
+}
+
+template <typename T>
+__device__ __forceinline__ bool decompress_sub(
+    const uint8_t* src, uint32_t avail, uint8_t* dst, uint32_t bytes, uint32_t num_rles, uint32_t num_deltas, T* A, T* B,
+    uint16_t* pool, uint16_t* marks)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t w = sizeof(T);
+  const uint32_t n = bytes / w;
+  if (avail < 4) {
+    return false;
+  }
+  const uint32_t first = *(const uint32_t*)src;
+  if (first == kRawMarker) {
+    if (avail < 4 + bytes) {
+      return false;
+    }
+    for (uint32_t i = lane; i < bytes; i += 64) {
+      dst[i] = src[4 + i];
+    }
+    return true;
+  }
+  if (first != n || avail < 4 + 4 * num_rles) {
+    return false;
+  }
+  uint32_t counts[8];
+  uint32_t run_off[8];
+  uint32_t pos = 4;
+  uint32_t prev = n;
+  uint32_t pool_used = 0;
+  for (uint32_t l = 0; l < num_rles; ++l) {
+    counts[l] = *(const uint32_t*)(src + pos);
+    pos += 4;
+    if (counts[l] > prev || (counts[l] == 0 && prev != 0)) {
+      return false;
+    }
+    prev = counts[l];
+    run_off[l] = pool_used;
+    pool_used += counts[l];
+  }
+  for (uint32_t l = 0; l < num_rles; ++l) {
+    uint32_t used;
+    if (!unpack_stream<uint16_t>(src + pos, avail - pos, pool + run_off[l], counts[l], 2, used)) {
+      return false;
+    }
+    pos += used;
+  }
+  uint32_t c = num_rles ? counts[num_rles - 1] : n;
+  {
+    uint32_t used;
+    if (!unpack_stream<T>(src + pos, avail - pos, A, c, w, used)) {
+      return false;
+    }
+  }
+  wave::sync();
+  const uint32_t layers = num_rles > num_deltas ? num_rles : num_deltas;
+  T* cur = A;
+  T* oth = B;
+  for (uint32_t l = layers; l-- > 0;) {
+    if (l < num_deltas) {
+      delta_decode(cur, c);
+    }
+    if (l < num_rles) {
+      const uint32_t target = l == 0 ? n : counts[l - 1];
+      if (!rle_decode(cur, pool + run_off[l], c, oth, target, marks)) {
+        return false;
+      }
+      c = target;
+      T* t = cur;
+      cur = oth;
+      oth = t;
+    }
+  }
+  T* out = (T*)dst;
+  for (uint32_t i = lane; i < n; i += 64) {
+    out[i] = cur[i];
+  }
+  return true;
+}
+
+/* LDS bytes one wave needs for a given configuration (host + device agree). */
+__host__ __device__ inline uint32_t lds_bytes_per_wave(uint32_t sub_bytes, uint32_t width, uint32_t num_rles)
+{
+  const uint32_t n = sub_bytes / width;
+  const uint32_t vals = (sub_bytes + 15u) & ~15u;
+  const uint32_t rl = num_rles ? num_rles : 1;
+  const uint32_t pool = (2u * n * rl + 15u) & ~15u;
+  const uint32_t marks = (2u * n + 15u) & ~15u;
+  return 2 * vals + pool + marks;
+}
+
+} // namespace casc

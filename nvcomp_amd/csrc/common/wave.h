@@ -141,6 +141,18 @@ __device__ __forceinline__ uint32_t reduce_max(uint32_t v)
   return read_lane(v, 63);
 }
 
+/* Inclusive running maximum across the wave (same DPP ladder). */
+__device__ __forceinline__ uint32_t scan_max_inclusive(uint32_t v)
+{
+  v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+  v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+  v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+  v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+  v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+  v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+  return v;
+}
+
 __device__ __forceinline__ uint32_t reduce_add(uint32_t v)
 {
   return read_lane(scan_add_inclusive(v), 63);
@@ -176,3 +188,6 @@ __device__ __forceinline__ uint32_t popc64(uint64_t m)
 /* Algorithm statistics hook (rounds, path counts): compiled out on the device; the
  * host emulation (tests/emu/common/wave.h) turns it into counters for design studies. */
 #define LZ_STAT(name, n) ((void)0)
+
+/* The workgroup's dynamically sized LDS segment (size given at launch). */
+#define WAVE_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) uint8_t name[]

@@ -131,6 +131,16 @@ inline uint32_t reduce_max(uint32_t v)
   return m;
 }
 
+inline uint32_t scan_max_inclusive(uint32_t v)
+{
+  emu::wave_rendezvous(kMax, v, 0);
+  uint32_t m = 0;
+  for (int i = 0; i <= lane_id(); ++i) {
+    m = umax(m, (uint32_t)emu::peer(i).a);
+  }
+  return m;
+}
+
 inline uint32_t reduce_add(uint32_t v)
 {
   emu::wave_rendezvous(kScan, v, 0);
@@ -150,6 +160,7 @@ inline uint32_t popc64(uint64_t m) { return (uint32_t)__builtin_popcountll(m); }
 
 /* statistics hook: lane 0 of a wave accumulates named counters (see emu_stats_dump) */
 extern "C" void emu_stat_add(const char* name, unsigned long long n);
+#define WAVE_DYNAMIC_LDS(name) uint8_t* name = emu::dynamic_lds()
 #define LZ_STAT(name, n)                  \
   do {                                    \
     const unsigned long long v_ = (n);    \

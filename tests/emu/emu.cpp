@@ -86,6 +86,8 @@ void complete_wave(WaveRt& w, BlockRt& b, int wave_index)
 
 } // namespace
 
+alignas(16) static uint8_t g_dynamic_lds[160 * 1024];
+uint8_t* dynamic_lds() { return g_dynamic_lds; }
 Lane* cur() { return &g_cur->pub; }
 const dim3& block_dim() { return g_bdim; }
 const dim3& grid_dim() { return g_gdim; }

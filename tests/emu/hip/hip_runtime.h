@@ -82,6 +82,7 @@ uint64_t live_mask();
 void block_rendezvous();
 
 void launch(const std::function<void()>& body, dim3 grid, dim3 block);
+uint8_t* dynamic_lds(); /* 160 KiB, 16-byte aligned, shared by the lanes of the running workgroup */
 void set_seed(uint64_t seed);
 
 } // namespace emu

@@ -1,0 +1,122 @@
+"""Cascaded codec: HIP path (or its host emulation) vs oracle/cascaded_ref.c.
+
+The reference documents the scheme but not the bitstream (doc/cascaded_overview.md),
+so parity is pinned to this library's own container: compressed bytes must be
+IDENTICAL to the CPU model's, decompression must invert both, over every element
+type and RLE/delta/bit-packing combination (benchmarks/benchmark_cascaded_chunked.cu:
+35-36 defaults {4096, type, 2, 1, 1}; benchmark_all_algorithms.sh:5-8 uses 1/0/1, 0/0/1)."""
+import numpy as np
+import pytest
+
+from nvcomp_amd import datasets
+from nvcomp_amd._lib import NvcompStatus
+
+WIDTH = [1, 1, 2, 2, 4, 4, 8, 8]
+
+
+def roundtrip(backend, oracle, chunks, opts):
+    sub, typ, r, d, bp = opts
+    codec = backend.codec("Cascaded", opts)
+    comp = codec.compress(chunks, in_align=8)
+    for i, (cc, c) in enumerate(zip(comp, chunks)):
+        ref = oracle.cascaded_compress(c, sub, typ, r, d, bp)
+        assert cc.size == ref.size and np.array_equal(cc, ref), f"chunk {i}: compressed bytes differ from the CPU model"
+        rc, out = oracle.cascaded_decompress(cc, c.size)
+        assert rc == 0 and np.array_equal(out, c)
+    outs, actual, status = codec.decompress(comp, [c.size for c in chunks], comp_align=8, out_align=8)
+    assert (status == NvcompStatus.Success).all(), status
+    assert actual.tolist() == [c.size for c in chunks]
+    for o, c in zip(outs, chunks):
+        assert np.array_equal(o, c)
+    sizes = codec.get_decompress_size(comp, comp_align=8)
+    assert sizes.tolist() == [c.size for c in chunks]
+    return sum(c.size for c in chunks) / max(1, sum(c.size for c in comp))
+
+
+@pytest.mark.parametrize("typ", range(8))
+def test_default_scheme_all_types(backend, oracle, typ):
+    rng = np.random.RandomState(typ)
+    w = WIDTH[typ]
+    chunks = []
+    for name in ("int32", "float32", "lowcard", "zeros", "noise"):
+        n = int(rng.randint(1, 2500)) * 8
+        chunks.append(datasets.CLASSES[name](n, typ))
+    chunks.append(np.zeros(0, dtype=np.uint8))
+    chunks.append(datasets.int32_column(65536, 3))
+    roundtrip(backend, oracle, chunks, (4096, typ, 2, 1, 1))
+    assert w in (1, 2, 4, 8)
+
+
+@pytest.mark.parametrize("r,d,bp", [(0, 0, 1), (1, 0, 1), (0, 1, 1), (2, 2, 1), (3, 1, 1), (1, 2, 0), (2, 1, 0), (0, 0, 0),
+                                     (7, 7, 1)])
+def test_scheme_combinations(backend, oracle, r, d, bp):
+    chunks = [datasets.int32_column(20000, r + d), datasets.float32_column(8192, 1), datasets.lowcard(5000 * 4, 2),
+              datasets.noise(4096, 3)]
+    for typ in (1, 4, 7):
+        if r == 7 and typ == 1:
+            # 7 RLE layers x 4096 one-byte elements need more LDS than one workgroup may hold
+            with pytest.raises(RuntimeError, match="returned 11"):  # nvcompErrorNotSupported
+                backend.codec("Cascaded", (4096, typ, r, d, bp)).compress(chunks)
+            continue
+        roundtrip(backend, oracle, chunks, (4096, typ, r, d, bp))
+
+
+def test_sub_chunk_sizes(backend, oracle):
+    chunks = [datasets.int32_column(40000, 9), datasets.table_rows(12000, 4)]
+    for sub in (256, 512, 1000, 4096, 8192, 16384):
+        roundtrip(backend, oracle, chunks, (sub, 4, 2, 1, 1))
+    # these need more than the 16 KiB/wave of the first decode pass -> large-LDS second pass
+    roundtrip(backend, oracle, chunks, (8192, 0, 1, 1, 1))
+    roundtrip(backend, oracle, chunks, (16384, 6, 2, 1, 1))
+
+
+def test_benchmark_config_ratio(backend, oracle):
+    """config 4 of BASELINE.json: int32 columnar data, default opts, 64 KiB user chunks."""
+    data = datasets.int32_column(4 * 65536, 5)
+    ratio = roundtrip(backend, oracle, datasets.split_chunks(data), (4096, 4, 2, 1, 1))
+    assert ratio > 10
+
+
+def test_corrupt_and_misaligned(backend, oracle):
+    chunks = [datasets.int32_column(30000, 2)] * 6
+    codec = backend.codec("Cascaded")
+    comp = codec.compress(chunks)
+    rng = np.random.RandomState(5)
+    bad = []
+    for i, c in enumerate(comp):
+        b = c.copy()
+        if i == 0:
+            b = b[: b.size // 2]
+        elif i == 1:
+            b[0] ^= 0xFF
+        elif i == 2:
+            b[rng.randint(20, b.size)] ^= 0x10
+        elif i == 3:
+            b[8] ^= 0x40  # uncompressed size field
+        bad.append(b)
+    caps = [c.size for c in chunks]
+    caps[5] -= 4
+    outs, actual, status = codec.decompress(bad, caps, comp_align=8, out_align=8)
+    for i, (b, cap) in enumerate(zip(bad, caps)):
+        rc, ref = oracle.cascaded_decompress(b, cap)
+        if rc == 0:
+            assert status[i] == NvcompStatus.Success and np.array_equal(outs[i][: ref.size], ref)
+        else:
+            assert status[i] != NvcompStatus.Success and actual[i] == 0
+    outs, actual, status = codec.decompress(comp, [c.size for c in chunks], comp_align=8, out_align=8, base_misalign=1)
+    assert (status == NvcompStatus.ErrorAlignment).all()
+
+
+def test_opts_validation(backend):
+    import ctypes as C
+
+    from nvcomp_amd._lib import CascadedOpts
+
+    lib = backend.lib
+    out = C.c_size_t(0)
+    ok = CascadedOpts(4096, 4, 2, 1, 1)
+    assert lib.nvcompBatchedCascadedCompressGetMaxOutputChunkSize(65536, ok, C.byref(out)) == 0
+    assert out.value >= 65536
+    for bad in (CascadedOpts(4096, 8, 2, 1, 1), CascadedOpts(4096, 4, 8, 1, 1), CascadedOpts(4096, 4, 2, 1, 2),
+                CascadedOpts(100, 4, 2, 1, 1), CascadedOpts(4098, 4, 2, 1, 1)):
+        assert lib.nvcompBatchedCascadedCompressGetMaxOutputChunkSize(65536, bad, C.byref(out)) == NvcompStatus.ErrorInvalidValue
