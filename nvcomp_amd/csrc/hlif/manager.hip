@@ -1,0 +1,575 @@
+/*
+ * hlif/manager.hip -- implementation of the high-level C++ interface
+ * (include/nvcomp/nvcompManager.hpp, nvcompManagerFactory.hpp).
+ *
+ * A manager = chunking + scratch + a self-describing container around the batched
+ * low-level codec ("HLIF now dispatches to LLIF", reference CHANGELOG.md:17).
+ * Everything on the data path is enqueued on the user's stream; only the calls the
+ * reference documents as synchronising (configure_decompression(comp_buffer),
+ * get_compressed_output_size, create_manager) wait for the stream.
+ *
+ * Container (DESIGN.md "HLIF container"), all little endian:
+ *   [0,64)   header: magic 'NVAM', version, format, uncompressed size, chunk size,
+ *            chunk count, format options, flags, total container size
+ *   then     u64 comp_size[N]     actual compressed size of every chunk
+ *            u64 comp_offset[N+1] start of every chunk relative to the data area (8-byte aligned)
+ *            u32 crc_uncomp[N], u32 crc_comp[N]   (only when checksums were computed)
+ *   then     the compressed chunks, each starting on an 8-byte boundary.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "nvcomp.hpp"
+
+#include "common/wave.h"
+
+namespace nvcomp {
+
+namespace detail {
+
+struct StatusWord
+{
+  nvcompStatus_t* host = nullptr; /* pinned, device-visible */
+  StatusWord()
+  {
+    if (hipHostMalloc((void**)&host, sizeof(nvcompStatus_t), hipHostMallocMapped) != hipSuccess) {
+      throw std::runtime_error("nvcomp: cannot allocate a pinned status word");
+    }
+    *host = nvcompSuccess;
+  }
+  ~StatusWord()
+  {
+    if (host) {
+      (void)hipHostFree(host);
+    }
+  }
+  StatusWord(const StatusWord&) = delete;
+  StatusWord& operator=(const StatusWord&) = delete;
+};
+
+} // namespace detail
+
+nvcompStatus_t* CompressionConfig::get_status() const
+{
+  return status ? status->host : nullptr;
+}
+
+nvcompStatus_t* DecompressionConfig::get_status() const
+{
+  return status ? status->host : nullptr;
+}
+
+namespace {
+
+constexpr uint32_t kMagic = 0x4d41564eu; /* 'NVAM' */
+constexpr uint32_t kFlagChecksums = 1u;
+
+struct Header
+{
+  uint32_t magic;
+  uint16_t version;
+  uint16_t format;
+  uint64_t uncompressed_size;
+  uint32_t chunk_size;
+  uint32_t num_chunks;
+  uint8_t opts[24];
+  uint32_t flags;
+  uint32_t reserved;
+  uint64_t compressed_size;
+};
+static_assert(sizeof(Header) == 64, "container header is 64 bytes");
+
+void hip_check(hipError_t e, const char* what)
+{
+  if (e != hipSuccess) {
+    throw std::runtime_error(std::string("nvcomp: ") + what + ": " + hipGetErrorString(e));
+  }
+}
+
+void nv_check(nvcompStatus_t s, const char* what)
+{
+  if (s != nvcompSuccess) {
+    throw std::runtime_error(std::string("nvcomp: ") + what + " failed with status " + std::to_string((int)s));
+  }
+}
+
+size_t round8(size_t v)
+{
+  return (v + 7) & ~(size_t)7;
+}
+
+/* sizes + offsets + (always reserved) checksum slots: the layout does not depend on
+ * whether checksums were computed, so decompress() never has to read the header */
+size_t table_bytes(size_t n)
+{
+  return round8(8 * n + 8 * (n + 1) + 8 * n);
+}
+
+/* ---- device helpers -------------------------------------------------------- */
+
+__global__ void setup_compress_kernel(
+    const uint8_t* decomp, size_t total, size_t chunk, size_t n, uint8_t* stage, size_t stride, const void** in_ptrs,
+    size_t* in_sizes, void** out_ptrs)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    in_ptrs[i] = decomp + i * chunk;
+    in_sizes[i] = total - i * chunk < chunk ? total - i * chunk : chunk;
+    out_ptrs[i] = stage + i * stride;
+  }
+}
+
+/* One workgroup: exclusive scan of the 8-byte padded chunk sizes -> offsets; header. */
+__global__ void __launch_bounds__(256) layout_kernel(
+    const size_t* comp_sizes, size_t n, uint8_t* comp_buffer, Header header, size_t tables, nvcompStatus_t* status)
+{
+  __shared__ uint64_t partial[256];
+  uint64_t* sizes_out = (uint64_t*)(comp_buffer + sizeof(Header));
+  uint64_t* offsets = sizes_out + n;
+  const size_t per = (n + 255) / 256;
+  const size_t lo = (size_t)threadIdx.x * per;
+  const size_t hi = lo + per < n ? lo + per : n;
+  uint64_t sum = 0;
+  for (size_t i = lo; i < hi; ++i) {
+    sum += (comp_sizes[i] + 7) & ~(uint64_t)7;
+  }
+  partial[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t run = 0;
+    for (int t = 0; t < 256; ++t) {
+      const uint64_t v = partial[t];
+      partial[t] = run;
+      run += v;
+    }
+    offsets[n] = run;
+    header.compressed_size = sizeof(Header) + tables + run;
+    *(Header*)comp_buffer = header;
+    if (status != nullptr) {
+      *status = nvcompSuccess;
+    }
+  }
+  __syncthreads();
+  uint64_t run = partial[threadIdx.x];
+  for (size_t i = lo; i < hi; ++i) {
+    offsets[i] = run;
+    sizes_out[i] = comp_sizes[i];
+    run += (comp_sizes[i] + 7) & ~(uint64_t)7;
+  }
+}
+
+/* One wavefront per chunk: staged chunk -> its final place in the container. */
+__global__ void __launch_bounds__(256) gather_kernel(const uint8_t* stage, size_t stride, size_t n, uint8_t* comp_buffer, size_t tables)
+{
+  const size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) {
+    return;
+  }
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t* sizes = (const uint64_t*)(comp_buffer + sizeof(Header));
+  const uint64_t* offsets = sizes + n;
+  const uint64_t* src = (const uint64_t*)(stage + i * stride); /* both sides are 8-byte aligned */
+  uint64_t* dst = (uint64_t*)(comp_buffer + sizeof(Header) + tables + offsets[i]);
+  const size_t words = (sizes[i] + 7) / 8;
+  for (size_t k = lane; k < words; k += 64) {
+    dst[k] = src[k];
+  }
+}
+
+__global__ void setup_decompress_kernel(
+    const uint8_t* comp_buffer, size_t tables, size_t n, size_t total, size_t chunk, uint8_t* decomp,
+    const void** comp_ptrs, size_t* comp_sizes, void** out_ptrs, size_t* out_caps)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint64_t* sizes = (const uint64_t*)(comp_buffer + sizeof(Header));
+    const uint64_t* offsets = sizes + n;
+    comp_ptrs[i] = comp_buffer + sizeof(Header) + tables + offsets[i];
+    comp_sizes[i] = sizes[i];
+    out_ptrs[i] = decomp + i * chunk;
+    out_caps[i] = total - i * chunk < chunk ? total - i * chunk : chunk;
+  }
+}
+
+/* CRC-32 (IEEE 802.3, reflected, as boost::crc_32_type / zlib): one thread per chunk. */
+__device__ uint32_t crc32_bytes(const uint8_t* p, size_t n, const uint32_t* table)
+{
+  uint32_t c = 0xffffffffu;
+  for (size_t i = 0; i < n; ++i) {
+    c = table[(c ^ p[i]) & 0xffu] ^ (c >> 8);
+  }
+  return c ^ 0xffffffffu;
+}
+
+__global__ void __launch_bounds__(256) crc_kernel(
+    const void* const* ptrs, const size_t* sizes, size_t n, uint32_t* out, const uint32_t* expect, uint32_t* mismatch,
+    const Header* header)
+{
+  /* verification is skipped on the device when the buffer carries no checksums */
+  if (expect != nullptr && !(header->flags & kFlagChecksums)) {
+    return;
+  }
+  __shared__ uint32_t table[256];
+  {
+    uint32_t c = threadIdx.x;
+    for (int k = 0; k < 8; ++k) {
+      c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+    }
+    table[threadIdx.x] = c;
+  }
+  __syncthreads();
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint32_t c = crc32_bytes((const uint8_t*)ptrs[i], sizes[i], table);
+    if (out != nullptr) {
+      out[i] = c;
+    }
+    if (expect != nullptr && expect[i] != c) {
+      atomicAdd(mismatch, 1u);
+    }
+  }
+}
+
+/* Fold the per-chunk statuses / sizes / checksum mismatches into the batch status word. */
+__global__ void __launch_bounds__(256) status_kernel(
+    const nvcompStatus_t* statuses, const size_t* actual, const size_t* expect, size_t n, const uint32_t* mismatch,
+    nvcompStatus_t* out)
+{
+  __shared__ uint32_t bad;
+  if (threadIdx.x == 0) {
+    bad = 0;
+  }
+  __syncthreads();
+  for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+    if (statuses[i] != nvcompSuccess || actual[i] != expect[i]) {
+      atomicAdd(&bad, 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *out = bad ? nvcompErrorCannotDecompress : (mismatch != nullptr && *mismatch) ? nvcompErrorBadChecksum : nvcompSuccess;
+  }
+}
+
+struct DeviceBuffer
+{
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  void reserve(size_t n)
+  {
+    if (n > bytes) {
+      if (ptr) {
+        (void)hipFree(ptr);
+        ptr = nullptr;
+      }
+      hip_check(hipMalloc(&ptr, n), "hipMalloc(scratch)");
+      bytes = n;
+    }
+  }
+  ~DeviceBuffer()
+  {
+    if (ptr) {
+      (void)hipFree(ptr);
+    }
+  }
+};
+
+} // namespace
+
+namespace detail {
+
+struct ManagerImpl
+{
+  BatchedManager::Format format;
+  size_t chunk;
+  uint8_t opts[24];
+  hipStream_t stream;
+  int device;
+  ChecksumPolicy policy;
+  DeviceBuffer arrays, stage, temp, misc;
+
+  bool compute_checksums() const { return policy == ComputeAndNoVerify || policy == ComputeAndVerifyIfPresent || policy == ComputeAndVerify; }
+  bool verify_checksums() const { return policy == NoComputeAndVerifyIfPresent || policy == ComputeAndVerifyIfPresent || policy == ComputeAndVerify; }
+
+  nvcompStatus_t max_chunk(size_t* out) const
+  {
+    switch (format) {
+    case BatchedManager::kLZ4: {
+      nvcompBatchedLZ4Opts_t o;
+      memcpy(&o, opts, sizeof(o));
+      return nvcompBatchedLZ4CompressGetMaxOutputChunkSize(chunk, o, out);
+    }
+    case BatchedManager::kSnappy: {
+      nvcompBatchedSnappyOpts_t o;
+      memcpy(&o, opts, sizeof(o));
+      return nvcompBatchedSnappyCompressGetMaxOutputChunkSize(chunk, o, out);
+    }
+    default: {
+      nvcompBatchedCascadedOpts_t o;
+      memcpy(&o, opts, sizeof(o));
+      return nvcompBatchedCascadedCompressGetMaxOutputChunkSize(chunk, o, out);
+    }
+    }
+  }
+
+  nvcompStatus_t compress_temp(size_t n, size_t* out) const
+  {
+    switch (format) {
+    case BatchedManager::kLZ4: {
+      nvcompBatchedLZ4Opts_t o;
+      memcpy(&o, opts, sizeof(o));
+      return nvcompBatchedLZ4CompressGetTempSize(n, chunk, o, out);
+    }
+    case BatchedManager::kSnappy: {
+      nvcompBatchedSnappyOpts_t o;
+      memcpy(&o, opts, sizeof(o));
+      return nvcompBatchedSnappyCompressGetTempSize(n, chunk, o, out);
+    }
+    default: {
+      nvcompBatchedCascadedOpts_t o;
+      memcpy(&o, opts, sizeof(o));
+      return nvcompBatchedCascadedCompressGetTempSize(n, chunk, o, out);
+    }
+    }
+  }
+
+  nvcompStatus_t decompress_temp(size_t n, size_t* out) const
+  {
+    switch (format) {
+    case BatchedManager::kLZ4: return nvcompBatchedLZ4DecompressGetTempSize(n, chunk, out);
+    case BatchedManager::kSnappy: return nvcompBatchedSnappyDecompressGetTempSize(n, chunk, out);
+    default: return nvcompBatchedCascadedDecompressGetTempSize(n, chunk, out);
+    }
+  }
+
+  nvcompStatus_t compress_async(const void* const* in_ptrs, const size_t* in_sizes, size_t n, void* t, size_t tb,
+                                void* const* out_ptrs, size_t* out_sizes) const
+  {
+    switch (format) {
+    case BatchedManager::kLZ4: {
+      nvcompBatchedLZ4Opts_t o;
+      memcpy(&o, opts, sizeof(o));
+      return nvcompBatchedLZ4CompressAsync(in_ptrs, in_sizes, chunk, n, t, tb, out_ptrs, out_sizes, o, stream);
+    }
+    case BatchedManager::kSnappy: {
+      nvcompBatchedSnappyOpts_t o;
+      memcpy(&o, opts, sizeof(o));
+      return nvcompBatchedSnappyCompressAsync(in_ptrs, in_sizes, chunk, n, t, tb, out_ptrs, out_sizes, o, stream);
+    }
+    default: {
+      nvcompBatchedCascadedOpts_t o;
+      memcpy(&o, opts, sizeof(o));
+      return nvcompBatchedCascadedCompressAsync(in_ptrs, in_sizes, chunk, n, t, tb, out_ptrs, out_sizes, o, stream);
+    }
+    }
+  }
+
+  nvcompStatus_t decompress_async(const void* const* cp, const size_t* cs, const size_t* caps, size_t* actual, size_t n,
+                                  void* t, size_t tb, void* const* op, nvcompStatus_t* st) const
+  {
+    switch (format) {
+    case BatchedManager::kLZ4: return nvcompBatchedLZ4DecompressAsync(cp, cs, caps, actual, n, t, tb, op, st, stream);
+    case BatchedManager::kSnappy: return nvcompBatchedSnappyDecompressAsync(cp, cs, caps, actual, n, t, tb, op, st, stream);
+    default: return nvcompBatchedCascadedDecompressAsync(cp, cs, caps, actual, n, t, tb, op, st, stream);
+    }
+  }
+
+  Header read_header(const uint8_t* comp_buffer) const
+  {
+    hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    Header h;
+    hip_check(hipMemcpy(&h, comp_buffer, sizeof(h), hipMemcpyDeviceToHost), "hipMemcpy(header)");
+    if (h.magic != kMagic || h.version != 1) {
+      throw std::runtime_error("nvcomp: buffer was not produced by an nvcomp manager of this library");
+    }
+    return h;
+  }
+};
+
+} // namespace detail
+
+BatchedManager::BatchedManager(
+    Format format, size_t uncomp_chunk_size, const void* format_opts, size_t format_opts_bytes, hipStream_t user_stream,
+    int device_id, ChecksumPolicy checksum_policy)
+    : impl_(new detail::ManagerImpl())
+{
+  if (uncomp_chunk_size == 0 || uncomp_chunk_size > (1u << 24) || format_opts_bytes > sizeof(impl_->opts)) {
+    throw std::invalid_argument("nvcomp: invalid manager arguments");
+  }
+  impl_->format = format;
+  impl_->chunk = uncomp_chunk_size;
+  memset(impl_->opts, 0, sizeof(impl_->opts));
+  memcpy(impl_->opts, format_opts, format_opts_bytes);
+  impl_->stream = user_stream;
+  impl_->device = device_id;
+  impl_->policy = checksum_policy;
+  size_t probe = 0;
+  nv_check(impl_->max_chunk(&probe), "format options validation");
+}
+
+BatchedManager::~BatchedManager() = default;
+
+CompressionConfig BatchedManager::configure_compression(const size_t decomp_buffer_size)
+{
+  CompressionConfig c;
+  c.uncompressed_buffer_size = decomp_buffer_size;
+  c.num_chunks = (decomp_buffer_size + impl_->chunk - 1) / impl_->chunk;
+  size_t max_out = 0;
+  nv_check(impl_->max_chunk(&max_out), "CompressGetMaxOutputChunkSize");
+  c.max_compressed_buffer_size = sizeof(Header) + table_bytes(c.num_chunks) + c.num_chunks * round8(max_out);
+  c.status = std::make_shared<detail::StatusWord>();
+  return c;
+}
+
+void BatchedManager::compress(const uint8_t* decomp_buffer, uint8_t* comp_buffer, const CompressionConfig& cfg)
+{
+  detail::ManagerImpl& m = *impl_;
+  hip_check(hipSetDevice(m.device), "hipSetDevice");
+  const size_t n = cfg.num_chunks;
+  const bool sums = m.compute_checksums();
+  size_t max_out = 0;
+  nv_check(m.max_chunk(&max_out), "CompressGetMaxOutputChunkSize");
+  const size_t stride = round8(max_out);
+  size_t tb = 0;
+  nv_check(m.compress_temp(n, &tb), "CompressGetTempSize");
+  m.arrays.reserve(32 * (n + 1) + 64);
+  m.stage.reserve(stride * (n ? n : 1));
+  m.temp.reserve(tb ? tb : 8);
+  const void** in_ptrs = (const void**)m.arrays.ptr;
+  size_t* in_sizes = (size_t*)(in_ptrs + n);
+  void** out_ptrs = (void**)(in_sizes + n);
+  size_t* out_sizes = (size_t*)(out_ptrs + n);
+  Header h;
+  memset(&h, 0, sizeof(h));
+  h.magic = kMagic;
+  h.version = 1;
+  h.format = (uint16_t)m.format;
+  h.uncompressed_size = cfg.uncompressed_buffer_size;
+  h.chunk_size = (uint32_t)m.chunk;
+  h.num_chunks = (uint32_t)n;
+  memcpy(h.opts, m.opts, sizeof(h.opts));
+  h.flags = sums ? kFlagChecksums : 0;
+  const size_t tables = table_bytes(n);
+  nvcompStatus_t* status = cfg.get_status();
+  if (n != 0) {
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(setup_compress_kernel, dim3(blocks), dim3(256), 0, m.stream, decomp_buffer,
+                       cfg.uncompressed_buffer_size, m.chunk, n, (uint8_t*)m.stage.ptr, stride, in_ptrs, in_sizes, out_ptrs);
+    nv_check(m.compress_async(in_ptrs, in_sizes, n, m.temp.ptr, tb, out_ptrs, out_sizes), "CompressAsync");
+  }
+  hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(256), 0, m.stream, out_sizes, n, comp_buffer, h, tables, status);
+  if (n != 0) {
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, m.stream, (const uint8_t*)m.stage.ptr,
+                       stride, n, comp_buffer, tables);
+    if (sums) {
+      uint32_t* crc_u = (uint32_t*)(comp_buffer + sizeof(Header) + 8 * n + 8 * (n + 1));
+      uint32_t* crc_c = crc_u + n;
+      const unsigned blocks = (unsigned)((n + 255) / 256);
+      hipLaunchKernelGGL(crc_kernel, dim3(blocks), dim3(256), 0, m.stream, (const void* const*)in_ptrs, in_sizes, n, crc_u,
+                         (const uint32_t*)nullptr, (uint32_t*)nullptr, (const Header*)comp_buffer);
+      hipLaunchKernelGGL(crc_kernel, dim3(blocks), dim3(256), 0, m.stream, (const void* const*)out_ptrs, out_sizes, n, crc_c,
+                         (const uint32_t*)nullptr, (uint32_t*)nullptr, (const Header*)comp_buffer);
+    }
+  }
+  hip_check(hipGetLastError(), "compress launch");
+}
+
+DecompressionConfig BatchedManager::configure_decompression(const uint8_t* comp_buffer)
+{
+  const Header h = impl_->read_header(comp_buffer);
+  if (h.format != (uint16_t)impl_->format) {
+    throw std::runtime_error("nvcomp: compressed buffer was written by a manager of a different format");
+  }
+  if (impl_->policy == ComputeAndVerify && !(h.flags & kFlagChecksums)) {
+    throw std::runtime_error("nvcomp: ComputeAndVerify requested but the buffer holds no checksums");
+  }
+  DecompressionConfig d;
+  d.decomp_data_size = h.uncompressed_size;
+  d.num_chunks = h.num_chunks;
+  d.status = std::make_shared<detail::StatusWord>();
+  return d;
+}
+
+DecompressionConfig BatchedManager::configure_decompression(const CompressionConfig& comp_config)
+{
+  DecompressionConfig d;
+  d.decomp_data_size = comp_config.uncompressed_buffer_size;
+  d.num_chunks = (uint32_t)comp_config.num_chunks;
+  d.status = std::make_shared<detail::StatusWord>();
+  return d;
+}
+
+void BatchedManager::decompress(uint8_t* decomp_buffer, const uint8_t* comp_buffer, const DecompressionConfig& cfg)
+{
+  detail::ManagerImpl& m = *impl_;
+  hip_check(hipSetDevice(m.device), "hipSetDevice");
+  const size_t n = cfg.num_chunks;
+  nvcompStatus_t* status = cfg.get_status();
+  if (n == 0) {
+    return;
+  }
+  size_t tb = 0;
+  nv_check(m.decompress_temp(n, &tb), "DecompressGetTempSize");
+  m.arrays.reserve(56 * (n + 1) + 64);
+  m.temp.reserve(tb ? tb : 8);
+  m.misc.reserve(16);
+  const void** comp_ptrs = (const void**)m.arrays.ptr;
+  size_t* comp_sizes = (size_t*)(comp_ptrs + n);
+  void** out_ptrs = (void**)(comp_sizes + n);
+  size_t* out_caps = (size_t*)(out_ptrs + n);
+  size_t* actual = out_caps + n;
+  nvcompStatus_t* statuses = (nvcompStatus_t*)(actual + n);
+  uint32_t* mismatch = (uint32_t*)m.misc.ptr;
+  const size_t tables = table_bytes(n);
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(setup_decompress_kernel, dim3(blocks), dim3(256), 0, m.stream, comp_buffer, tables, n,
+                     cfg.decomp_data_size, m.chunk, decomp_buffer, comp_ptrs, comp_sizes, out_ptrs, out_caps);
+  const bool verify = m.verify_checksums(); /* the kernels skip the check when the buffer has no checksums */
+  const uint32_t* crc_u = (const uint32_t*)(comp_buffer + sizeof(Header) + 8 * n + 8 * (n + 1));
+  const uint32_t* crc_c = crc_u + n;
+  if (verify) {
+    hip_check(hipMemsetAsync(mismatch, 0, 4, m.stream), "hipMemsetAsync");
+    hipLaunchKernelGGL(crc_kernel, dim3(blocks), dim3(256), 0, m.stream, (const void* const*)comp_ptrs, comp_sizes, n,
+                       (uint32_t*)nullptr, crc_c, mismatch, (const Header*)comp_buffer);
+  }
+  nv_check(m.decompress_async(comp_ptrs, comp_sizes, out_caps, actual, n, m.temp.ptr, tb, out_ptrs, statuses),
+           "DecompressAsync");
+  if (verify) {
+    hipLaunchKernelGGL(crc_kernel, dim3(blocks), dim3(256), 0, m.stream, (const void* const*)out_ptrs, out_caps, n,
+                       (uint32_t*)nullptr, crc_u, mismatch, (const Header*)comp_buffer);
+  }
+  hipLaunchKernelGGL(status_kernel, dim3(1), dim3(256), 0, m.stream, statuses, actual, out_caps, n,
+                     verify ? mismatch : (const uint32_t*)nullptr, status);
+  hip_check(hipGetLastError(), "decompress launch");
+}
+
+size_t BatchedManager::get_compressed_output_size(uint8_t* comp_buffer)
+{
+  return impl_->read_header(comp_buffer).compressed_size;
+}
+
+std::shared_ptr<nvcompManagerBase> create_manager(
+    const uint8_t* comp_buffer, hipStream_t stream, const int device_id, ChecksumPolicy checksum_policy)
+{
+  hip_check(hipSetDevice(device_id), "hipSetDevice");
+  hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+  Header h;
+  hip_check(hipMemcpy(&h, comp_buffer, sizeof(h), hipMemcpyDeviceToHost), "hipMemcpy(header)");
+  if (h.magic != kMagic || h.version != 1) {
+    throw std::runtime_error("nvcomp: create_manager: buffer was not produced by an nvcomp manager of this library");
+  }
+  size_t opts_bytes;
+  switch (h.format) {
+  case BatchedManager::kLZ4: opts_bytes = sizeof(nvcompBatchedLZ4Opts_t); break;
+  case BatchedManager::kSnappy: opts_bytes = sizeof(nvcompBatchedSnappyOpts_t); break;
+  case BatchedManager::kCascaded: opts_bytes = sizeof(nvcompBatchedCascadedOpts_t); break;
+  default: throw std::runtime_error("nvcomp: create_manager: unknown format id in the buffer header");
+  }
+  return std::make_shared<BatchedManager>(
+      (BatchedManager::Format)h.format, (size_t)h.chunk_size, h.opts, opts_bytes, stream, device_id, checksum_policy);
+}
+
+} // namespace nvcomp

@@ -1,0 +1,105 @@
+"""The C++ example and harness programs (examples/, benchmarks/) run end to end:
+they verify their own results (non-zero exit code on any mismatch), and the harness's
+stdout must stay awk-compatible with the reference's scripts (benchmarks/benchmark.sh:28-31)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from nvcomp_amd import datasets
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(cmd, **kw):
+    r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=600, **kw)
+    assert r.returncode == 0, f"{' '.join(cmd)}\n{r.stdout}\n{r.stderr}"
+    return r.stdout
+
+
+def test_hlif_example_on_emulator(tmp_path):
+    """high_level_quickstart_example against the host emulation of the kernels (CPU-only)."""
+    import conftest
+
+    conftest.emu_library()
+    exe = tmp_path / "hlq_emu"
+    run(["g++", "-O1", "-std=c++17", "-Itests/emu", "-Iinclude", "-Iexamples", "examples/high_level_quickstart_example.cpp",
+         "-o", str(exe), "-Ltests/emu", "-lnvcomp_emu", f"-Wl,-rpath,{REPO}/tests/emu"])
+    assert "all scenarios passed" in run([str(exe)])
+
+
+def test_low_level_example_on_emulator(tmp_path):
+    import conftest
+
+    conftest.emu_library()
+    exe = tmp_path / "llq_emu"
+    run(["g++", "-O1", "-std=c++17", "-Itests/emu", "-Iinclude", "-Iexamples", "examples/low_level_quickstart_example.cpp",
+         "-o", str(exe), "-Ltests/emu", "-lnvcomp_emu", f"-Wl,-rpath,{REPO}/tests/emu"])
+    assert "round-tripped in place" in run([str(exe)])
+
+
+@pytest.fixture(scope="module")
+def built_programs():
+    run(["make", "-C", "benchmarks", "-j8"])
+    run(["make", "-C", "examples", "-j4"])
+
+
+@pytest.fixture(scope="module")
+def sample_files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("data")
+    files = {}
+    for name, gen in (("table.txt", datasets.table_rows), ("floats.csv", datasets.float_csv), ("col.int32", datasets.int32_column)):
+        p = d / name
+        gen(300000, 1).tofile(p)
+        files[name] = str(p)
+    return files
+
+
+@pytest.mark.gpu
+def test_examples_on_gpu(built_programs, sample_files):
+    assert "all scenarios passed" in run(["examples/bin/high_level_quickstart_example"])
+    assert "round-tripped in place" in run(["examples/bin/low_level_quickstart_example"])
+    if os.path.exists(os.path.join(REPO, "examples/bin/lz4_cpu_compression")):
+        out = run(["examples/bin/lz4_cpu_compression", "-f", sample_files["table.txt"], sample_files["floats.csv"]])
+        assert "decompression validated" in out
+        out = run(["examples/bin/lz4_cpu_decompression", "-f", sample_files["table.txt"], sample_files["floats.csv"]])
+        assert "decompression validated" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog,extra", [("benchmark_lz4_chunked", []), ("benchmark_snappy_chunked", []),
+                                         ("benchmark_cascaded_chunked", ["-t", "int"])])
+def test_chunked_harness_on_gpu(built_programs, sample_files, prog, extra):
+    f = sample_files["col.int32"] if "cascaded" in prog else sample_files["table.txt"]
+    out = run([f"benchmarks/bin/{prog}", "-f", f, "-i", "2", "-x", "4"] + extra)
+    lines = out.strip().splitlines()
+    assert lines[0] == "----------" and lines[1] == "files: 1"
+    assert re.match(r"uncompressed \(B\): \d+$", lines[2])
+    assert re.match(r"comp_size: \d+, compressed ratio: \d+\.\d{4}$", lines[3])
+    assert re.match(r"compression throughput \(GB/s\): \d+\.\d{4}$", lines[4])
+    assert re.match(r"decompression throughput \(GB/s\): \d+\.\d{4}$", lines[5])
+    csv = run([f"benchmarks/bin/{prog}", "-f", f, "-c", "true"] + extra)
+    assert csv.splitlines()[0].startswith("Files, Duplicate data, Size in MB, Pages")
+
+
+@pytest.mark.gpu
+def test_hlif_and_synth_benchmarks_on_gpu(built_programs, sample_files):
+    for fmt in ("lz4", "snappy", "cascaded"):
+        f = sample_files["col.int32"] if fmt == "cascaded" else sample_files["table.txt"]
+        out = run(["benchmarks/bin/benchmark_hlif", fmt, "-f", f, "-n", "2"] + (["-t", "int"] if fmt == "cascaded" else []))
+        assert "decompression throughput (GB/s):" in out and "compressed ratio:" in out
+    out = run(["benchmarks/bin/benchmark_snappy_synth", "-b", "500", "-w", "2", "-i", "3"])
+    assert "decompression throughput (GB/s):" in out
+    out = run(["benchmarks/bin/benchmark_lz4_synth", "-b", "4"])
+    assert out.count("zeros") == 5 and out.count("random") == 5
+
+
+@pytest.mark.gpu
+def test_allgather_program_oversubscribed(built_programs, sample_files):
+    """benchmark_allgather logic on however many GPUs the box has (logical GPUs share devices)."""
+    for comp in ("none", "lz4"):
+        out = run(["benchmarks/bin/benchmark_allgather", "-f", sample_files["table.txt"], "-g", "2", "-h", "4", "-c", comp,
+                   "--oversubscribe"])
+        assert float(out.split()[-1]) > 0
