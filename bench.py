@@ -47,6 +47,7 @@ def parse_args():
     p.add_argument("--algo", choices=["lz4", "snappy"], default="lz4")
     p.add_argument("--mib-per-gpu", type=int, default=1024, help="uncompressed MiB decoded per GPU per step")
     p.add_argument("--unique-mib", type=int, default=64, help="unique MiB generated + CPU-compressed per rank")
+    p.add_argument("--unique-kib", type=int, default=0, help="(tests) unique KiB per rank, overrides --unique-mib/--mib-per-gpu")
     p.add_argument("--dataset", default="silesia_style")
     p.add_argument("--producer", choices=["hc", "fast", "port"], default="hc",
                    help="CPU compressor making the inputs: liblz4 HC-12 / liblz4 default / oracle port")
@@ -108,13 +109,19 @@ class TorchRuntime:
     def equal(self, a, b):
         return bool(self.torch.equal(a, b))
 
+    def as_tensor(self, buf):
+        return buf
+
     def shutdown(self):
         if self.dist is not None:
             self.dist.destroy_process_group()
 
 
 class EmuRuntime:
-    """--dry-run-emu only: wall-clock 'events', numpy buffers."""
+    """--dry-run-emu only: wall-clock 'events', numpy buffers, gloo between ranks."""
+
+    def __init__(self, dist=None):
+        self.dist = dist
 
     class _Event:
         def record(self):
@@ -130,16 +137,29 @@ class EmuRuntime:
         return EmuRuntime._Event()
 
     def barrier_sync(self):
-        pass
+        if self.dist is not None:
+            self.dist.barrier()
 
     def max_over_ranks(self, seconds):
-        return seconds
+        if self.dist is None:
+            return seconds
+        import torch
+
+        t = torch.tensor([seconds], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
 
     def equal(self, a, b):
         return bool(np.array_equal(a, b))
 
+    def as_tensor(self, buf):
+        import torch
+
+        return torch.from_numpy(buf)
+
     def shutdown(self):
-        pass
+        if self.dist is not None:
+            self.dist.destroy_process_group()
 
 
 def setup_runtime(args):
@@ -161,7 +181,13 @@ def setup_runtime(args):
         import conftest as emu_conftest
 
         lib, dev = emu_conftest.emu_library(), emu_conftest.HostDevice()
-        rt = EmuRuntime()
+        edist = None
+        if world > 1:  # CPU-only multi-process self-test: gloo
+            import torch.distributed as edist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            edist.init_process_group("gloo", rank=rank, world_size=world)
+        rt = EmuRuntime(edist)
     else:
         import torch
         import torch.distributed as dist
@@ -191,13 +217,13 @@ def run_case(args, ctx):
     from oracle import oracle_py as oracle  # producer of inputs + cpu_baseline checker only
 
     oracle.build()
-    unique = args.unique_mib << 20
+    unique = (args.unique_kib << 10) if args.unique_kib else (args.unique_mib << 20)
     gen = getattr(datasets, args.dataset) if hasattr(datasets, args.dataset) else datasets.CLASSES[args.dataset]
     data = gen(unique, rank)
     chunks = datasets.split_chunks(data, CHUNK)
     comp, producer = cpu_compress(oracle, args.algo, chunks, args.producer, threads)
     n_unique = len(chunks)
-    replicas = max(1, (args.mib_per_gpu << 20) // unique)
+    replicas = 1 if args.unique_kib else max(1, (args.mib_per_gpu << 20) // unique)
     n = n_unique * replicas
     comp_sizes = np.array([c.size for c in comp], dtype=np.uint64)
     comp_offs = np.zeros(n_unique, dtype=np.uint64)
@@ -350,16 +376,152 @@ def run_case(args, ctx):
                       + ("liblz4 LZ4_decompress_safe" if (use_ref and args.algo == "lz4") else
                          "libsnappy RawUncompress" if use_ref else "oracle/ C port"),
         }
+    if world > 1:
+        digests = [None] * world
+        rt.dist.all_gather_object(digests, shard_digest(data))
+        result["config"]["shard_digests"] = digests
     if args.dry_run_emu:
         result["value"] = None
         result["data"] = "DRY RUN on the CPU emulation of the kernels: not a measurement"
     return result
 
 
+def shard_digest(data):
+    """Cheap content fingerprint of a rank's shard (shows that ranks work on different chunks)."""
+    import zlib
+
+    return zlib.crc32(np.ascontiguousarray(data[: 1 << 20]).tobytes()) & 0xFFFFFFFF
+
+
+def run_allgather_case(args, ctx):
+    """benchmark_allgather.cpp semantics over RCCL (reference: benchmarks/benchmark_allgather.cpp:288-470):
+    every rank LZ4-compresses its shard on its GPU, the compressed bytes are all-gathered over xGMI
+    (two collectives per step: the chunk sizes, then the compacted payloads padded to the largest
+    rank's total), every rank decompresses the G-1 remote shards and ends up with all the data.
+    Unlike the reference, the payload moved is the ACTUAL compressed size, not the bound."""
+    import torch
+
+    import nvcomp_amd
+    from nvcomp_amd import datasets
+    from nvcomp_amd.batched import DeviceBatch
+
+    rank, world, lib, dev, rt = ctx["rank"], ctx["world"], ctx["lib"], ctx["dev"], ctx["rt"]
+    dist = rt.dist
+    assert world >= 2 and dist is not None, "--allgather needs at least 2 ranks"
+    codec = nvcomp_amd.BatchedCodec(lib, dev, "LZ4")
+    unique = (args.unique_kib << 10) if args.unique_kib else (args.unique_mib << 20)
+    gen = getattr(datasets, args.dataset) if hasattr(datasets, args.dataset) else datasets.CLASSES[args.dataset]
+    data = gen(unique, rank)
+    replicas = 1 if args.unique_kib else max(1, (args.mib_per_gpu << 20) // unique)
+    shard_bytes = unique * replicas
+    n = shard_bytes // CHUNK
+    raw = rt.as_tensor(rt.repeat(dev.upload(data), replicas))
+    max_out = (codec.max_compressed_size(CHUNK) + 7) // 8 * 8
+    slots = rt.as_tensor(dev.empty(n * max_out))
+    sizes = rt.as_tensor(dev.upload(np.zeros(n, dtype=np.int64).view(np.uint8))).view(torch.int64)
+    raw_sizes = np.full(n, CHUNK, dtype=np.uint64)
+
+    def ptr(t):
+        return int(t.data_ptr())
+
+    def dev_u64(arr):
+        return dev.upload(np.asarray(arr, dtype=np.uint64).view(np.uint8))
+
+    src = DeviceBatch(raw, dev_u64(ptr(raw) + np.arange(n, dtype=np.uint64) * CHUNK), dev_u64(raw_sizes), None, raw_sizes, n)
+    dst = DeviceBatch(slots, dev_u64(ptr(slots) + np.arange(n, dtype=np.uint64) * max_out), sizes, None, raw_sizes, n)
+    ctb = codec.compress_temp_size(n, CHUNK)
+    ctemp = dev.empty(ctb) if ctb else None
+    dtb = codec.decompress_temp_size(n * (world - 1), CHUNK)
+    dtemp = dev.empty(dtb) if dtb else None
+    out = rt.as_tensor(dev.empty(shard_bytes * world))
+    all_sizes_flat = torch.zeros(world * n, dtype=torch.int64, device=sizes.device)
+    all_sizes = all_sizes_flat.view(world, n)
+    col = torch.arange(max_out, device=sizes.device)[None, :]
+    m = n * (world - 1)
+    actual = dev.upload(np.zeros(m, dtype=np.uint64).view(np.uint8))
+    statuses = dev.upload(np.full(m, -1, dtype=np.int32).view(np.uint8))
+    remote = [r for r in range(world) if r != rank]
+    out_ptrs = np.concatenate([ptr(out) + r * shard_bytes + np.arange(n, dtype=np.uint64) * CHUNK for r in remote])
+    out_batch = DeviceBatch(out, dev_u64(out_ptrs), dev_u64(np.full(m, CHUNK)), None, None, m)
+    moved = [0]
+
+    def step():
+        rc = codec.compress_async(src, dst, CHUNK, ctemp, ctb)
+        assert rc == 0, rc
+        # compaction of the padded slots: rows truncated to their compressed size, concatenated
+        compact = slots.view(n, max_out)[col < sizes[:, None]]
+        dist.all_gather_into_tensor(all_sizes_flat, sizes)
+        totals = all_sizes.sum(dim=1)
+        cap = int(totals.max().item())  # host sync, like the reference's sync_all_streams before the copies
+        moved[0] = int(totals.sum().item())
+        mine = torch.zeros(cap, dtype=torch.uint8, device=sizes.device)
+        mine[: compact.numel()] = compact
+        gathered = torch.empty(world * cap, dtype=torch.uint8, device=sizes.device)
+        dist.all_gather_into_tensor(gathered, mine)
+        offs = torch.cumsum(all_sizes, dim=1) - all_sizes
+        base = torch.tensor([ptr(gathered) + r * cap for r in range(world)], dtype=torch.int64, device=sizes.device)
+        comp_ptrs = (offs + base[:, None])[remote].reshape(-1).contiguous()
+        comp_sizes = all_sizes[remote].reshape(-1).contiguous()
+        batch = DeviceBatch(gathered, comp_ptrs, comp_sizes, None, None, m)
+        rc = codec.decompress_async(batch, out_batch, actual, statuses, dtemp, dtb)
+        assert rc == 0, rc
+        out[rank * shard_bytes: (rank + 1) * shard_bytes] = raw  # own shard: plain copy (benchmark_allgather.cpp:386-393)
+        return gathered  # keep alive until the stream has consumed it
+
+    keep = None
+    for _ in range(args.warmup):
+        keep = step()
+    rt.barrier_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        keep = step()
+    rt.barrier_sync()
+    elapsed = rt.max_over_ranks(time.perf_counter() - t0)
+    del keep
+    st = dev.download(statuses).view(np.int32)[:m]
+    assert (st == 0).all(), f"{int((st != 0).sum())} remote chunks failed"
+    # every rank must now hold every shard: compare fingerprints with the owners'
+    weights = (torch.arange(shard_bytes, device=sizes.device) % 65521).to(torch.int64)
+    prints = torch.stack([(out[r * shard_bytes: (r + 1) * shard_bytes].to(torch.int64) * weights).sum() for r in range(world)])
+    owner = torch.zeros(world, dtype=torch.int64, device=sizes.device)
+    own = (raw.to(torch.int64) * weights).sum().reshape(1)
+    dist.all_gather_into_tensor(owner, own)
+    assert torch.equal(prints, owner), "a rank holds wrong data after the all-gather"
+    total = shard_bytes * world
+    per_step = elapsed / args.steps
+    return {
+        "metric": "lz4 all-gather system GB/s (benchmark_allgather semantics)",
+        "value": round(total * (world - 1) / per_step / 1e9, 3),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(per_step * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {
+            "workload": "LZ4 compress shard -> RCCL all-gather of compressed bytes -> decompress remote shards "
+                        "(BASELINE.json configs[4], benchmarks/benchmark_allgather.cpp)",
+            "dataset": args.dataset,
+            "uncompressed_bytes_per_gpu": shard_bytes,
+            "chunks_per_gpu": n,
+            "per_gpu_GBps": round(total * (world - 1) / world / per_step / 1e9, 3),
+            "compressed_bytes_moved_per_step": moved[0],
+            "ratio": round(total / max(1, moved[0]), 4),
+        },
+    }
+
+
 def main():
     args = parse_args()
     ctx = setup_runtime(args)
-    result = run_case(args, ctx)
+    result = run_allgather_case(args, ctx) if args.allgather else run_case(args, ctx)
+    if args.dry_run_emu and args.allgather:
+        result["value"] = None
+        result["data"] = "DRY RUN on the CPU emulation of the kernels: not a measurement"
     if ctx["rank"] == 0:
         print(json.dumps(result), flush=True)
     ctx["rt"].shutdown()

@@ -37,7 +37,7 @@ class HostDevice:
         return buf[: buf.size if nbytes is None else int(nbytes)].copy()
 
     def ptr(self, buf):
-        return buf.ctypes.data
+        return int(buf.data_ptr()) if hasattr(buf, "data_ptr") else buf.ctypes.data
 
     def stream(self):
         return None

@@ -1,0 +1,68 @@
+"""The drop-in boundary: libnvcomp.so loads without a GPU and exports every function that
+include/nvcomp/*.h declares; option structs and enums have the layout the reference's call
+sites pin. No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import nvcomp_amd
+from nvcomp_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    names = set()
+    for h in ("lz4.h", "snappy.h", "cascaded.h"):
+        text = open(os.path.join(REPO, "include", "nvcomp", h)).read()
+        names |= set(re.findall(r"nvcompStatus_t\s+(nvcompBatched\w+)\s*\(", text))
+    return sorted(names)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(nvcomp_amd.LIB_PATH):
+        nvcomp_amd.build_library()
+    return C.CDLL(nvcomp_amd.LIB_PATH)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared_functions()
+    assert len(names) == 6 * 3 + 4  # six entry points per format + the *GetTempSizeEx pairs
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_host_only_queries_work_without_gpu(lib):
+    _lib.declare(lib)
+    out = C.c_size_t(0)
+    assert lib.nvcompBatchedLZ4CompressGetMaxOutputChunkSize(65536, _lib.LZ4Opts(0), C.byref(out)) == 0
+    assert out.value == 65809  # == LZ4_compressBound(65536), BASELINE.md section 2
+    assert lib.nvcompBatchedSnappyCompressGetMaxOutputChunkSize(65536, _lib.SnappyOpts(0), C.byref(out)) == 0
+    assert out.value == 76490  # == snappy::MaxCompressedLength(65536)
+    assert lib.nvcompBatchedLZ4DecompressGetTempSize(1000, 65536, C.byref(out)) == 0
+    assert lib.nvcompBatchedCascadedDecompressGetTempSize(1000, 65536, C.byref(out)) == 0 and out.value == 4000
+    assert lib.nvcompBatchedLZ4CompressGetTempSize(10, 65536, _lib.LZ4Opts(0), None) == _lib.NvcompStatus.ErrorInvalidValue
+
+
+def test_struct_and_enum_layout():
+    assert C.sizeof(_lib.LZ4Opts) == 4 and C.sizeof(_lib.SnappyOpts) == 4
+    assert C.sizeof(_lib.CascadedOpts) == 24 and _lib.CascadedOpts.type.offset == 8
+    text = open(os.path.join(REPO, "include", "nvcomp", "shared_types.h")).read()
+    for name, val in (("nvcompSuccess", 0), ("nvcompErrorCannotDecompress", 12), ("nvcompErrorBadChecksum", 13),
+                      ("nvcompErrorAlignment", 17), ("NVCOMP_TYPE_CHAR", 0), ("NVCOMP_TYPE_ULONGLONG", 7)):
+        assert re.search(rf"{name}\s*=\s*{val}\b", text), name
+    assert re.search(r"NVCOMP_TYPE_BITS\s*=\s*0xff", text)
+
+
+def test_header_compiles_as_c():
+    import subprocess
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        open(src, "w").write('#include "nvcomp.h"\nint main(void){nvcompBatchedLZ4Opts_t o = nvcompBatchedLZ4DefaultOpts; return (int)o.data_type;}\n')
+        subprocess.run(["gcc", "-std=c99", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(REPO, "include"), "-I", "/opt/rocm/include",
+                        "-c", src, "-o", os.path.join(d, "t.o")], check=True)

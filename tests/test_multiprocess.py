@@ -1,0 +1,38 @@
+"""N>1 path of bench.py on CPU: two processes, gloo, the kernels' host emulation.
+
+Checks what the real multi-GPU run relies on: rendezvous on 127.0.0.1, every rank decodes
+its OWN shard (different content per rank), barrier + max-over-ranks timing, one JSON line
+from rank 0; and for --allgather, that every rank ends up holding every shard
+(the program asserts the fingerprints)."""
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def launch(extra, port):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--dry-run-emu", "--unique-kib", "128",
+           "--steps", "1", "--warmup", "0"] + extra
+    r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    return json.loads(lines[0])
+
+
+def test_sharded_decompress_two_ranks():
+    res = launch(["--no-cpu-baseline", "--no-extras"], 29621)
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["value"] is None
+    digests = res["config"]["shard_digests"]
+    assert len(digests) == 2 and digests[0] != digests[1], "ranks must work on different shards"
+    assert res["config"]["chunks_per_gpu"] == 2
+
+
+def test_allgather_two_ranks():
+    res = launch(["--allgather"], 29622)
+    assert res["n_gpus"] == 2 and "all-gather" in res["metric"]
+    assert res["config"]["compressed_bytes_moved_per_step"] > 0
+    assert res["config"]["ratio"] > 1.0
