@@ -364,15 +364,18 @@ def run_case(args, ctx):
         # bounded sample of the same chunk arrays: the unique set, best of 5.
         use_ref = oracle.have_ref()
         code = oracle.LZ4_DEC if args.algo == "lz4" else oracle.SNAPPY_DEC
-        secs, outs, errs = oracle.batch_run(code, comp, [c.size for c in chunks], threads=threads, repeats=5,
-                                            use_ref=use_ref)
-        assert errs == 0 and all(o.size == c.size for o, c in zip(outs, chunks))
+        # bounded sample: the unique set repeated so that every thread gets >= 16 MiB per run
+        # (thread start-up dominates a small sample on a many-core host), best of 5 runs
+        reps = max(1, min(replicas, (16 * threads + args.unique_mib - 1) // max(1, args.unique_mib)))
+        s_comp, s_caps = comp * reps, [c.size for c in chunks] * reps
+        secs, outs, errs = oracle.batch_run(code, s_comp, s_caps, threads=threads, repeats=5, use_ref=use_ref)
+        assert errs == 0 and all(o.size == c for o, c in zip(outs, s_caps))
         result["cpu_baseline"] = {
-            "value": round(unique / secs / 1e9, 3),
+            "value": round(unique * reps / secs / 1e9, 3),
             "unit": "GB/s",
             "cores": threads,
             "kind": "reference" if use_ref else "port",
-            "sample": f"{unique >> 20} MiB ({n_unique} chunks) of the same workload, best of 5, "
+            "sample": f"{(unique * reps) >> 20} MiB ({n_unique * reps} chunks) of the same workload, best of 5, "
                       + ("liblz4 LZ4_decompress_safe" if (use_ref and args.algo == "lz4") else
                          "libsnappy RawUncompress" if use_ref else "oracle/ C port"),
         }
