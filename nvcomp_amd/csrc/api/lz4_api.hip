@@ -29,12 +29,15 @@ int lz4_decode_variant()
     if (e == nullptr) {
       return 0;
     }
+    if (e[0] == 'a') {
+      return e[1] == '1' ? 11 : 12;
+    }
     return e[0] == 'd' ? 1 : e[0] == 's' ? 2 : 0;
   }();
   return v;
 }
 
-template <bool CHECKED>
+template <bool CHECKED, int ABLATE = 0>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZW_WAVES_PER_SIMD) lz4_decompress_window_kernel(
     const void* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes,
@@ -62,7 +65,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZW_WAVES_PER_SIMD
   if (in_len64 > 0xffffffffull - 64) {
     err = lz::kErrInput;
   } else {
-    produced = lz4w::decode_chunk<CHECKED>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds[w], err);
+    produced = lz4w::decode_chunk<CHECKED, ABLATE>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds[w], err);
   }
   if (wave::lane_id() == 0) {
     if (actual_bytes != nullptr) {
@@ -224,6 +227,18 @@ nvcompStatus_t nvcompBatchedLZ4DecompressAsync(
   const bool checked = device_statuses != nullptr;
   const int variant = lz4_decode_variant();
   const bool serial = variant == 2;
+  if (variant >= 10) { /* profiling-only ablations (NVCOMP_AMD_LZ4_DECODE=a1|a2): wrong output by design */
+    if (variant == 11) {
+      hipLaunchKernelGGL((lz4_decompress_window_kernel<false, 1>), grid, block, 0, stream, device_compressed_ptrs,
+                         device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,
+                         batch_size, device_uncompressed_ptrs, device_statuses);
+    } else {
+      hipLaunchKernelGGL((lz4_decompress_window_kernel<false, 2>), grid, block, 0, stream, device_compressed_ptrs,
+                         device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,
+                         batch_size, device_uncompressed_ptrs, device_statuses);
+    }
+    return launch_status();
+  }
   if (variant == 0) {
     if (checked) {
       hipLaunchKernelGGL((lz4_decompress_window_kernel<true>), grid, block, 0, stream, device_compressed_ptrs,

@@ -104,6 +104,33 @@ __device__ __forceinline__ uint32_t write_lane_scalar(uint32_t vec, uint32_t val
   return vec;
 }
 
+/*
+ * Walk a chain of relative steps held one per lane: starting at position r (< limit <= 64),
+ * repeat { rec[k++] = r; r += step[r]; } while (r < limit). This is the serial critical
+ * path of the LZ decoders (one iteration per token), so it is written out: 2 VALU
+ * (v_readlane, v_writelane) + 4 SALU per iteration, the lane counter living in M0. The
+ * CU's single scalar ALU is the resource the decoders run out of first.
+ * Requires k + (iterations) <= 64. r and k are updated in place.
+ */
+__device__ __forceinline__ void chain_walk(uint32_t step, uint32_t limit, uint32_t& r, uint32_t& k, uint32_t& rec)
+{
+  uint32_t d;
+  asm volatile(
+      "s_mov_b32 m0, %[k]\n\t"
+      "s_nop 0\n"
+      "1:\n\t"
+      "v_readlane_b32 %[d], %[step], %[r]\n\t"
+      "v_writelane_b32 %[rec], %[r], m0\n\t"
+      "s_add_u32 m0, m0, 1\n\t"
+      "s_add_u32 %[r], %[r], %[d]\n\t"
+      "s_cmp_lt_u32 %[r], %[limit]\n\t"
+      "s_cbranch_scc1 1b\n\t"
+      "s_mov_b32 %[k], m0"
+      : [rec] "+v"(rec), [r] "+s"(r), [k] "+s"(k), [d] "=&s"(d)
+      : [step] "v"(step), [limit] "s"(limit)
+      : "scc");
+}
+
 /* Per-lane gather: lane i receives v of lane src_lane(i) (ds_bpermute_b32). */
 __device__ __forceinline__ uint32_t shuffle(uint32_t v, uint32_t src_lane)
 {

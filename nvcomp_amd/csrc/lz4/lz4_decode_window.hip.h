@@ -27,43 +27,28 @@ struct Chase
   uint32_t q;     /* virtual position of the next token */
 };
 
-/* Distance from a (speculative) token at virtual position p to the next token. */
+/* Distance from a (speculative) token at virtual position p to the next token.
+ * Branch-free: the token and the byte behind it are fetched together, the one byte a
+ * match-length extension may need is the only dependent LDS read; whether the answer
+ * can be trusted is decided at the end (kUnknown -> scalar slow path). */
 __device__ __forceinline__ uint32_t token_delta(const lzw::InRing& r, uint32_t p)
 {
-  if (p < r.lo || p + 2 > r.hi || p >= r.vend) {
-    return kUnknown;
-  }
   const uint8_t* ring = r.ring;
-  const uint32_t t = ring[p & (lzw::kInRing - 1)];
-  uint32_t pos = p + 1;
-  uint32_t lit = t >> 4;
-  if (lit == 15) {
-    const uint32_t e = ring[pos & (lzw::kInRing - 1)];
-    if (e == 255) {
-      return kUnknown;
-    }
-    lit += e;
-    ++pos;
-  }
-  pos += lit;
-  if (pos >= r.vend) {
-    return pos - p; /* literals reach the end of the chunk: the chase stops here */
-  }
-  pos += 2;
-  if ((t & 15u) == 15u) {
-    if (pos >= r.hi) {
-      return kUnknown;
-    }
-    if (pos >= r.vend) {
-      return pos - p;
-    }
-    const uint32_t e = ring[pos & (lzw::kInRing - 1)];
-    if (e == 255) {
-      return kUnknown;
-    }
-    ++pos;
-  }
-  return pos - p;
+  const uint32_t m = lzw::kInRing - 1;
+  const uint32_t t = ring[p & m];
+  const uint32_t e1 = ring[(p + 1) & m];
+  const uint32_t lit_code = t >> 4;
+  const bool lit_ext = lit_code == 15;
+  const uint32_t lit = lit_code + (lit_ext ? e1 : 0u);
+  const uint32_t lit_end = p + 1 + (lit_ext ? 1u : 0u) + lit;
+  const bool ends = lit_end >= r.vend; /* literals reach the end of the chunk: the chase stops here */
+  const uint32_t mpos = lit_end + 2;   /* where a match-length extension byte would sit */
+  const uint32_t e2 = ring[mpos & m];
+  const bool m_ext = (t & 15u) == 15u;
+  const uint32_t delta = ends ? lit_end - p : mpos + (m_ext ? 1u : 0u) - p;
+  const bool unknown = p < r.lo || p + 2 > r.hi || p >= r.vend || (lit_ext && e1 == 255)
+                       || (!ends && m_ext && (mpos >= r.hi || e2 == 255));
+  return unknown ? kUnknown : delta;
 }
 
 __device__ __forceinline__ void chase_reload(Chase& c, const lzw::InRing& r)
@@ -130,22 +115,28 @@ __device__ __forceinline__ uint32_t chase(Chase& c, const lzw::InRing& r, uint32
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j) {
       const uint32_t base = c.wb + 64 * j;
-      uint32_t lim = base + 64;
-      lim = lim < r.vend ? lim : r.vend;
-      if (k <= 64 - 22) { /* a 64-byte sub-window holds at most 22 tokens (>= 3 bytes each) */
-        while (c.q < lim) {
-          const uint32_t d = wave::read_lane(c.nx[j], c.q - base);
-          seqpos = wave::write_lane_scalar(seqpos, c.q, k);
-          ++k;
-          c.q += d;
+      uint32_t lim = r.vend - base; /* relative to this sub-window */
+      lim = lim < 64 ? lim : 64;
+      if (c.q >= base && c.q - base < lim) {
+        uint32_t rel = c.q - base;
+        const uint32_t k0 = k;
+        uint32_t recorded = 0;
+        if (k <= 64 - 22) { /* a 64-byte sub-window holds at most 22 tokens */
+          wave::chain_walk(c.nx[j], lim, rel, k, recorded);
+        } else {
+          while (rel < lim && k < 64) {
+            const uint32_t d = wave::read_lane(c.nx[j], rel);
+            recorded = wave::write_lane(recorded, rel, k);
+            ++k;
+            rel += d;
+          }
         }
-      } else {
-        while (c.q < lim && k < 64) {
-          const uint32_t d = wave::read_lane(c.nx[j], c.q - base);
-          seqpos = wave::write_lane_scalar(seqpos, c.q, k);
-          ++k;
-          c.q += d;
+        /* the walk recorded positions relative to the sub-window */
+        const uint32_t lane = (uint32_t)wave::lane_id();
+        if (lane >= k0 && lane < k) {
+          seqpos = base + recorded;
         }
+        c.q = base + rel;
       }
     }
     if (c.q >= kUnknown) { /* the last recorded token needs the scalar walk */
@@ -219,7 +210,9 @@ __device__ __forceinline__ void parse(const lzw::InRing& r, uint32_t p, bool act
 }
 
 /* Decode one chunk with the calling wave; `lds` is this wave's kLdsPerWave bytes. */
-template <bool CHECKED>
+/* ABLATE (profiling builds only, results are wrong by construction): 1 = stop after the
+ * token chase, 2 = after the parse, 0 = the real decoder. */
+template <bool CHECKED, int ABLATE = 0>
 __device__ __forceinline__ uint32_t decode_chunk(
     const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_cap, uint8_t* lds, uint32_t& err)
 {
@@ -248,9 +241,19 @@ __device__ __forceinline__ uint32_t decode_chunk(
     const uint32_t before = count;
     count = chase(c, ir, seqpos, count);
     (void)before;
+    if (ABLATE == 1) {
+      op += wave::reduce_add(lane < count ? seqpos : 0u) & 1u;
+      count = 0;
+      continue;
+    }
     lz::Seq s;
     bool bad;
     parse(ir, seqpos, lane < count, s, bad);
+    if (ABLATE == 2) {
+      op += wave::reduce_add(s.lit_len + s.match_len + s.match_off) & 1u;
+      count = 0;
+      continue;
+    }
     if (wave::ballot(bad)) {
       err |= lz::kErrInput;
       return 0;

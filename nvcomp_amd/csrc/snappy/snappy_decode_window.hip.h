@@ -23,32 +23,24 @@ struct Chase
   uint32_t q;
 };
 
-/* Distance from a (speculative) tag at virtual position p to the next tag; kUnknown = unknown. */
+/* Distance from a (speculative) tag at virtual position p to the next tag; kUnknown = unknown.
+ * Branch-free: the tag and the four bytes behind it (a literal's length field) are fetched
+ * together; the ring's 16-byte mirror covers a dword that starts before the ring's end. */
 __device__ __forceinline__ uint32_t tag_delta(const lzw::InRing& r, uint32_t p)
 {
-  if (p < r.lo || p + 5 > r.hi || p >= r.vend) {
-    return kUnknown;
-  }
   const uint8_t* ring = r.ring;
-  const uint32_t t = ring[p & (lzw::kInRing - 1)];
+  const uint32_t m = lzw::kInRing - 1;
+  const uint32_t t = ring[p & m];
+  const uint32_t w = lzw::ld32(ring + ((p + 1) & m));
   const uint32_t kind = t & 3u;
-  if (kind != 0) {
-    return kind == 3 ? 5u : kind + 1;
-  }
-  uint32_t len = t >> 2;
-  uint32_t hdr = 1;
-  if (len >= 60) {
-    const uint32_t nb = len - 59;
-    len = 0;
-    for (uint32_t i = 0; i < nb; ++i) {
-      len |= (uint32_t)ring[(p + 1 + i) & (lzw::kInRing - 1)] << (8 * i);
-    }
-    hdr += nb;
-    if (len >= 0x7fffff00u) {
-      return kUnknown;
-    }
-  }
-  return hdr + len + 1;
+  const uint32_t code = t >> 2;
+  const uint32_t nb = code >= 60 ? code - 59 : 0u; /* bytes of an explicit literal length */
+  const uint32_t ext = nb == 4 ? w : (w & ((1u << (8 * nb)) - 1u));
+  const uint32_t lit_len = (nb ? ext : code); /* length - 1 */
+  const uint32_t lit_delta = 1 + nb + lit_len + 1;
+  const uint32_t copy_delta = kind == 3 ? 5u : kind + 1;
+  const bool unknown = p < r.lo || p + 5 > r.hi || p >= r.vend || (kind == 0 && nb && ext >= 0x7fffff00u);
+  return unknown ? kUnknown : (kind == 0 ? lit_delta : copy_delta);
 }
 
 __device__ __forceinline__ void chase_reload(Chase& c, const lzw::InRing& r)
@@ -103,22 +95,28 @@ __device__ __forceinline__ uint32_t chase(Chase& c, const lzw::InRing& r, uint32
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j) {
       const uint32_t base = c.wb + 64 * j;
-      uint32_t lim = base + 64;
-      lim = lim < r.vend ? lim : r.vend;
-      if (k <= 64 - 32) { /* a 64-byte sub-window holds at most 32 elements (>= 2 bytes each) */
-        while (c.q < lim) {
-          const uint32_t d = wave::read_lane(c.nx[j], c.q - base);
-          seqpos = wave::write_lane_scalar(seqpos, c.q, k);
-          ++k;
-          c.q += d;
+      uint32_t lim = r.vend - base; /* relative to this sub-window */
+      lim = lim < 64 ? lim : 64;
+      if (c.q >= base && c.q - base < lim) {
+        uint32_t rel = c.q - base;
+        const uint32_t k0 = k;
+        uint32_t recorded = 0;
+        if (k <= 64 - 32) { /* a 64-byte sub-window holds at most 32 tokens */
+          wave::chain_walk(c.nx[j], lim, rel, k, recorded);
+        } else {
+          while (rel < lim && k < 64) {
+            const uint32_t d = wave::read_lane(c.nx[j], rel);
+            recorded = wave::write_lane(recorded, rel, k);
+            ++k;
+            rel += d;
+          }
         }
-      } else {
-        while (c.q < lim && k < 64) {
-          const uint32_t d = wave::read_lane(c.nx[j], c.q - base);
-          seqpos = wave::write_lane_scalar(seqpos, c.q, k);
-          ++k;
-          c.q += d;
+        /* the walk recorded positions relative to the sub-window */
+        const uint32_t lane = (uint32_t)wave::lane_id();
+        if (lane >= k0 && lane < k) {
+          seqpos = base + recorded;
         }
+        c.q = base + rel;
       }
     }
     if (c.q >= kUnknown) { /* the last recorded token needs the scalar walk */

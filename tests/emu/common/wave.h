@@ -92,6 +92,17 @@ inline uint32_t write_lane_scalar(uint32_t vec, uint32_t val, uint32_t lane)
   return write_lane(vec, val, lane);
 }
 
+inline uint32_t read_lane(uint32_t v, uint32_t lane);
+inline void chain_walk(uint32_t step, uint32_t limit, uint32_t& r, uint32_t& k, uint32_t& rec)
+{
+  do {
+    const uint32_t d = read_lane(step, r);
+    rec = write_lane(rec, r, k);
+    ++k;
+    r += d;
+  } while (r < limit);
+}
+
 inline uint32_t gload_u8(const uint8_t* p) { return *p; }
 inline uint32_t gload_u32(const uint8_t* p)
 {
