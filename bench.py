@@ -345,7 +345,7 @@ def run_case(args, ctx):
         from nvcomp_amd.batched import empty_batch
 
         max_out = codec.max_compressed_size(CHUNK)
-        k = min(n, 4096)
+        k = n
         src = DeviceBatch(out_slab, out_batch.ptrs, out_batch.sizes, None, out_batch.host_sizes[:k], k)
         dst = empty_batch(dev, [max_out] * k, stride=max_out)
         ctb = codec.compress_temp_size(k, CHUNK)

@@ -65,6 +65,38 @@ __device__ __forceinline__ uint32_t emit_sequence(
 
 struct Emitter
 {
+  static __device__ __forceinline__ uint32_t ext_bytes(uint32_t v) /* extension bytes for a length code v */
+  {
+    return v >= 15 ? (v - 15) / 255 + 1 : 0;
+  }
+  static __device__ __forceinline__ uint32_t seq_size(uint32_t lit_len, uint32_t match_len, uint32_t /*offset*/)
+  {
+    return 1 + ext_bytes(lit_len) + lit_len + 2 + ext_bytes(match_len - kMinMatch);
+  }
+  /* one lane can write it: at most one extension byte per length, literal run <= 64 bytes */
+  static __device__ __forceinline__ bool is_small(uint32_t lit_len, uint32_t match_len)
+  {
+    return lit_len <= 64 && match_len - kMinMatch < 15 + 255;
+  }
+  static __device__ __forceinline__ uint32_t lit_offset(uint32_t lit_len)
+  {
+    return 1 + (lit_len >= 15 ? 1u : 0u);
+  }
+  static __device__ __forceinline__ void emit_small_header(uint8_t* dst, uint32_t lit_len, uint32_t offset, uint32_t match_len)
+  {
+    const uint32_t ml = match_len - kMinMatch;
+    dst[0] = (uint8_t)(((lit_len < 15 ? lit_len : 15u) << 4) | (ml < 15 ? ml : 15u));
+    uint32_t pos = 1;
+    if (lit_len >= 15) {
+      dst[pos++] = (uint8_t)(lit_len - 15);
+    }
+    pos += lit_len;
+    dst[pos] = (uint8_t)(offset & 255u);
+    dst[pos + 1] = (uint8_t)(offset >> 8);
+    if (ml >= 15) {
+      dst[pos + 2] = (uint8_t)(ml - 15);
+    }
+  }
   static __device__ __forceinline__ uint32_t match(
       uint8_t* dst, const uint8_t* lit, uint32_t lit_len, uint32_t offset, uint32_t match_len)
   {

@@ -83,6 +83,68 @@ __device__ __forceinline__ uint32_t emit_copy(uint8_t* dst, uint32_t offset, uin
 
 struct Emitter
 {
+  static __device__ __forceinline__ uint32_t literal_size(uint32_t len)
+  {
+    if (len == 0) {
+      return 0;
+    }
+    const uint32_t n = len - 1;
+    return len + 1 + (n < 60 ? 0u : n < (1u << 8) ? 1u : n < (1u << 16) ? 2u : n < (1u << 24) ? 3u : 4u);
+  }
+  static __device__ __forceinline__ uint32_t piece_size(uint32_t offset, uint32_t len)
+  {
+    return (len >= 4 && len < 12 && offset < 2048) ? 2u : 3u;
+  }
+  static __device__ __forceinline__ uint32_t copy_size(uint32_t offset, uint32_t len)
+  {
+    uint32_t sz = 0;
+    if (len >= 68) {
+      const uint32_t full = (len - 68) / 64 + 1;
+      sz = 3 * full;
+      len -= 64 * full;
+    }
+    if (len > 64) {
+      sz += piece_size(offset, 60);
+      len -= 60;
+    }
+    return sz + piece_size(offset, len);
+  }
+  static __device__ __forceinline__ uint32_t seq_size(uint32_t lit_len, uint32_t match_len, uint32_t offset)
+  {
+    return literal_size(lit_len) + copy_size(offset, match_len);
+  }
+  static __device__ __forceinline__ bool is_small(uint32_t lit_len, uint32_t match_len)
+  {
+    return lit_len <= 64 && match_len <= 64;
+  }
+  static __device__ __forceinline__ uint32_t lit_offset(uint32_t lit_len)
+  {
+    return lit_len == 0 ? 0u : (lit_len - 1 < 60 ? 1u : 2u);
+  }
+  static __device__ __forceinline__ void emit_small_header(uint8_t* dst, uint32_t lit_len, uint32_t offset, uint32_t match_len)
+  {
+    uint32_t pos = 0;
+    if (lit_len != 0) {
+      const uint32_t n = lit_len - 1;
+      if (n < 60) {
+        dst[0] = (uint8_t)(n << 2);
+        pos = 1;
+      } else {
+        dst[0] = (uint8_t)(60u << 2);
+        dst[1] = (uint8_t)n;
+        pos = 2;
+      }
+      pos += lit_len;
+    }
+    if (match_len >= 4 && match_len < 12 && offset < 2048) {
+      dst[pos] = (uint8_t)(1u | ((match_len - 4) << 2) | ((offset >> 8) << 5));
+      dst[pos + 1] = (uint8_t)(offset & 255u);
+    } else {
+      dst[pos] = (uint8_t)(2u | ((match_len - 1) << 2));
+      dst[pos + 1] = (uint8_t)(offset & 255u);
+      dst[pos + 2] = (uint8_t)(offset >> 8);
+    }
+  }
   static __device__ __forceinline__ uint32_t match(
       uint8_t* dst, const uint8_t* lit, uint32_t lit_len, uint32_t offset, uint32_t match_len)
   {
