@@ -331,7 +331,7 @@ def run_case(args, ctx):
                 traffic = None
         result["roofline"] = {
             "bound": "hbm",
-            "kernel": f"{args.algo}_decompress_kernel",
+            "kernel": f"{args.algo}_decompress_window_kernel",
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",

@@ -10,6 +10,8 @@
 
 #include "nvcomp/cascaded.h"
 
+#include "common/log.h"
+
 #include "cascaded/cascaded.hip.h"
 
 namespace {
@@ -44,6 +46,7 @@ struct Carve
   uint8_t* b;
   uint16_t* pool;
   uint16_t* marks;
+  casc::LayerMeta* meta;
 };
 
 __device__ __forceinline__ Carve carve(uint8_t* lds, uint32_t sub_bytes, uint32_t width, uint32_t num_rles)
@@ -57,6 +60,7 @@ __device__ __forceinline__ Carve carve(uint8_t* lds, uint32_t sub_bytes, uint32_
   c.b = lds + vals;
   c.pool = (uint16_t*)(lds + 2 * vals);
   c.marks = (uint16_t*)(lds + 2 * vals + pool);
+  c.meta = (casc::LayerMeta*)(lds + 2 * vals + pool + ((2u * n + 15u) & ~15u));
   return c;
 }
 
@@ -106,16 +110,16 @@ __global__ void cascaded_compress_kernel(
     uint32_t sz;
     switch (w) {
     case 1:
-      sz = casc::compress_sub<uint8_t>(src + off, bytes, payload + pay, p, (uint8_t*)c.a, (uint8_t*)c.b, c.pool);
+      sz = casc::compress_sub<uint8_t>(src + off, bytes, payload + pay, p, (uint8_t*)c.a, (uint8_t*)c.b, c.pool, c.meta);
       break;
     case 2:
-      sz = casc::compress_sub<uint16_t>(src + off, bytes, payload + pay, p, (uint16_t*)c.a, (uint16_t*)c.b, c.pool);
+      sz = casc::compress_sub<uint16_t>(src + off, bytes, payload + pay, p, (uint16_t*)c.a, (uint16_t*)c.b, c.pool, c.meta);
       break;
     case 4:
-      sz = casc::compress_sub<uint32_t>(src + off, bytes, payload + pay, p, (uint32_t*)c.a, (uint32_t*)c.b, c.pool);
+      sz = casc::compress_sub<uint32_t>(src + off, bytes, payload + pay, p, (uint32_t*)c.a, (uint32_t*)c.b, c.pool, c.meta);
       break;
     default:
-      sz = casc::compress_sub<uint64_t>(src + off, bytes, payload + pay, p, (uint64_t*)c.a, (uint64_t*)c.b, c.pool);
+      sz = casc::compress_sub<uint64_t>(src + off, bytes, payload + pay, p, (uint64_t*)c.a, (uint64_t*)c.b, c.pool, c.meta);
       break;
     }
     pay += sz;
@@ -220,19 +224,19 @@ __global__ void cascaded_decompress_kernel(
       switch (w) {
       case 1:
         ok = casc::decompress_sub<uint8_t>(payload + begin, end - begin, dst + off, bytes, num_rles, num_deltas,
-                                           (uint8_t*)c.a, (uint8_t*)c.b, c.pool, c.marks);
+                                           (uint8_t*)c.a, (uint8_t*)c.b, c.pool, c.marks, c.meta);
         break;
       case 2:
         ok = casc::decompress_sub<uint16_t>(payload + begin, end - begin, dst + off, bytes, num_rles, num_deltas,
-                                            (uint16_t*)c.a, (uint16_t*)c.b, c.pool, c.marks);
+                                            (uint16_t*)c.a, (uint16_t*)c.b, c.pool, c.marks, c.meta);
         break;
       case 4:
         ok = casc::decompress_sub<uint32_t>(payload + begin, end - begin, dst + off, bytes, num_rles, num_deltas,
-                                            (uint32_t*)c.a, (uint32_t*)c.b, c.pool, c.marks);
+                                            (uint32_t*)c.a, (uint32_t*)c.b, c.pool, c.marks, c.meta);
         break;
       default:
         ok = casc::decompress_sub<uint64_t>(payload + begin, end - begin, dst + off, bytes, num_rles, num_deltas,
-                                            (uint64_t*)c.a, (uint64_t*)c.b, c.pool, c.marks);
+                                            (uint64_t*)c.a, (uint64_t*)c.b, c.pool, c.marks, c.meta);
         break;
       }
       if (!ok) {
@@ -322,6 +326,8 @@ nvcompStatus_t nvcompBatchedCascadedCompressAsync(
     nvcompBatchedCascadedOpts_t format_opts,
     hipStream_t stream)
 {
+  nvlog::call(3, "nvcompBatchedCascadedCompressAsync(batch_size=%zu, max_uncompressed_chunk_bytes=%zu, stream=%p)", batch_size,
+              max_uncompressed_chunk_bytes, (void*)stream);
   if (!opts_ok(format_opts)) {
     return nvcompErrorInvalidValue;
   }
@@ -378,6 +384,8 @@ nvcompStatus_t nvcompBatchedCascadedDecompressAsync(
     nvcompStatus_t* device_statuses,
     hipStream_t stream)
 {
+  nvlog::call(3, "nvcompBatchedCascadedDecompressAsync(batch_size=%zu, statuses=%s, actual_sizes=%s, stream=%p)", batch_size,
+              device_statuses ? "yes" : "null", device_actual_uncompressed_bytes ? "yes" : "null", (void*)stream);
   if (batch_size == 0) {
     return nvcompSuccess;
   }

@@ -9,6 +9,8 @@
 
 #include "nvcomp/lz4.h"
 
+#include "common/log.h"
+
 #include "lz4/lz4_decode.hip.h"
 #include "lz4/lz4_decode_window.hip.h"
 #include "lz4/lz4_encode.hip.h"
@@ -214,6 +216,8 @@ nvcompStatus_t nvcompBatchedLZ4DecompressAsync(
     nvcompStatus_t* device_statuses,
     hipStream_t stream)
 {
+  nvlog::call(3, "nvcompBatchedLZ4DecompressAsync(batch_size=%zu, statuses=%s, actual_sizes=%s, stream=%p)", batch_size,
+              device_statuses ? "yes" : "null", device_actual_uncompressed_bytes ? "yes" : "null", (void*)stream);
   if (batch_size == 0) {
     return nvcompSuccess;
   }
@@ -340,6 +344,8 @@ nvcompStatus_t nvcompBatchedLZ4CompressAsync(
     nvcompBatchedLZ4Opts_t format_opts,
     hipStream_t stream)
 {
+  nvlog::call(3, "nvcompBatchedLZ4CompressAsync(batch_size=%zu, max_uncompressed_chunk_bytes=%zu, stream=%p)", batch_size,
+              max_uncompressed_chunk_bytes, (void*)stream);
   if (!lz4_type_ok(format_opts.data_type)) {
     return nvcompErrorInvalidValue;
   }

@@ -9,6 +9,8 @@
 
 #include "nvcomp/snappy.h"
 
+#include "common/log.h"
+
 #include "snappy/snappy_decode.hip.h"
 #include "snappy/snappy_decode_window.hip.h"
 #include "snappy/snappy_encode.hip.h"
@@ -211,6 +213,8 @@ nvcompStatus_t nvcompBatchedSnappyDecompressAsync(
     nvcompStatus_t* device_statuses,
     hipStream_t stream)
 {
+  nvlog::call(3, "nvcompBatchedSnappyDecompressAsync(batch_size=%zu, statuses=%s, actual_sizes=%s, stream=%p)", batch_size,
+              device_statuses ? "yes" : "null", device_actual_uncompressed_bytes ? "yes" : "null", (void*)stream);
   if (batch_size == 0) {
     return nvcompSuccess;
   }
@@ -325,6 +329,8 @@ nvcompStatus_t nvcompBatchedSnappyCompressAsync(
     nvcompBatchedSnappyOpts_t format_opts,
     hipStream_t stream)
 {
+  nvlog::call(3, "nvcompBatchedSnappyCompressAsync(batch_size=%zu, max_uncompressed_chunk_bytes=%zu, stream=%p)", batch_size,
+              max_uncompressed_chunk_bytes, (void*)stream);
   if (!snappy_opts_ok(format_opts)) {
     return nvcompErrorInvalidValue;
   }

@@ -360,9 +360,20 @@ __device__ __forceinline__ bool rle_decode(const T* A, const uint16_t* runs, uin
 
 /* ---- sub-chunk codec ------------------------------------------------------- */
 
+/* Per-wave bookkeeping of the layer loops, kept in LDS: indexing private arrays with the
+ * run-time layer number would put them in scratch memory. */
+struct LayerMeta
+{
+  uint32_t counts[8];
+  uint32_t run_off[8];
+  uint32_t bits[9];
+  uint32_t pad;
+  uint64_t mins[9];
+};
+
 template <typename T>
 __device__ __forceinline__ uint32_t compress_sub(
-    const uint8_t* src, uint32_t bytes, uint8_t* dst, const Params& p, T* A, T* B, uint16_t* pool)
+    const uint8_t* src, uint32_t bytes, uint8_t* dst, const Params& p, T* A, T* B, uint16_t* pool, LayerMeta* meta)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   const uint32_t w = sizeof(T);
@@ -373,18 +384,20 @@ __device__ __forceinline__ uint32_t compress_sub(
   }
   wave::sync();
   const uint32_t layers = p.num_rles > p.num_deltas ? p.num_rles : p.num_deltas;
-  uint32_t counts[8];
+  uint32_t* counts = meta->counts;
+  uint32_t* run_off = meta->run_off;
   uint32_t c = n;
   uint32_t pool_used = 0;
-  uint32_t run_off[8];
   T* cur = A;
   T* oth = B;
   for (uint32_t l = 0; l < layers; ++l) {
     if (l < p.num_rles) {
-      run_off[l] = pool_used;
       c = rle_encode(cur, c, oth, pool + pool_used);
+      if (lane == 0) {
+        run_off[l] = pool_used;
+        counts[l] = c;
+      }
       pool_used += c;
-      counts[l] = c;
       T* t = cur;
       cur = oth;
       oth = t;
@@ -394,9 +407,10 @@ __device__ __forceinline__ uint32_t compress_sub(
       delta_encode(cur, c);
     }
   }
+  wave::sync();
   /* sizes first: a sub-chunk that would not shrink is stored raw */
-  uint64_t mins[9];
-  uint32_t bitsv[9];
+  uint64_t* mins = meta->mins;
+  uint32_t* bitsv = meta->bits;
   uint32_t sz = 4 + 4 * p.num_rles;
   for (uint32_t l = 0; l < p.num_rles; ++l) {
     if (p.use_bp) {
@@ -453,7 +467,7 @@ __device__ __forceinline__ uint32_t compress_sub(
 template <typename T>
 __device__ __forceinline__ bool decompress_sub(
     const uint8_t* src, uint32_t avail, uint8_t* dst, uint32_t bytes, uint32_t num_rles, uint32_t num_deltas, T* A, T* B,
-    uint16_t* pool, uint16_t* marks)
+    uint16_t* pool, uint16_t* marks, LayerMeta* meta)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   const uint32_t w = sizeof(T);
@@ -474,21 +488,25 @@ __device__ __forceinline__ bool decompress_sub(
   if (first != n || avail < 4 + 4 * num_rles) {
     return false;
   }
-  uint32_t counts[8];
-  uint32_t run_off[8];
+  uint32_t* counts = meta->counts;
+  uint32_t* run_off = meta->run_off;
   uint32_t pos = 4;
   uint32_t prev = n;
   uint32_t pool_used = 0;
   for (uint32_t l = 0; l < num_rles; ++l) {
-    counts[l] = *(const uint32_t*)(src + pos);
+    const uint32_t cl = wave::uniform(*(const uint32_t*)(src + pos));
     pos += 4;
-    if (counts[l] > prev || (counts[l] == 0 && prev != 0)) {
+    if (cl > prev || (cl == 0 && prev != 0)) {
       return false;
     }
-    prev = counts[l];
-    run_off[l] = pool_used;
-    pool_used += counts[l];
+    prev = cl;
+    if (lane == 0) {
+      counts[l] = cl;
+      run_off[l] = pool_used;
+    }
+    pool_used += cl;
   }
+  wave::sync();
   for (uint32_t l = 0; l < num_rles; ++l) {
     uint32_t used;
     if (!unpack_stream<uint16_t>(src + pos, avail - pos, pool + run_off[l], counts[l], 2, used)) {
@@ -537,7 +555,7 @@ __host__ __device__ inline uint32_t lds_bytes_per_wave(uint32_t sub_bytes, uint3
   const uint32_t rl = num_rles ? num_rles : 1;
   const uint32_t pool = (2u * n * rl + 15u) & ~15u;
   const uint32_t marks = (2u * n + 15u) & ~15u;
-  return 2 * vals + pool + marks;
+  return 2 * vals + pool + marks + 192; /* + LayerMeta */
 }
 
 } // namespace casc

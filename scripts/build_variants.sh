@@ -15,7 +15,8 @@ build() { # tag, flags...
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o nvcomp_amd/lib/alt/libnvcomp_${tag}.so $objs
   echo "built $tag"
 }
-build w2kb1 -DNVCOMP_LZW_OUTWIN=2048 -DNVCOMP_LZW_BATCHMAX=1024 -DNVCOMP_LZW_KEEP=768 -DNVCOMP_LZW_INRING=2048 -DNVCOMP_LZW_WAVES_PER_SIMD=8
-build w2kb1o6 -DNVCOMP_LZW_OUTWIN=2048 -DNVCOMP_LZW_BATCHMAX=1024 -DNVCOMP_LZW_KEEP=768 -DNVCOMP_LZW_INRING=2048 -DNVCOMP_LZW_WAVES_PER_SIMD=6
-build w3kb1 -DNVCOMP_LZW_OUTWIN=3072 -DNVCOMP_LZW_BATCHMAX=1280 -DNVCOMP_LZW_KEEP=1536 -DNVCOMP_LZW_INRING=2048 -DNVCOMP_LZW_WAVES_PER_SIMD=7
-build w4kb1 -DNVCOMP_LZW_OUTWIN=4096 -DNVCOMP_LZW_BATCHMAX=1536 -DNVCOMP_LZW_KEEP=2048 -DNVCOMP_LZW_INRING=2048 -DNVCOMP_LZW_WAVES_PER_SIMD=6
+build w2k8  -DNVCOMP_LZW_OUTWIN=2048 -DNVCOMP_LZW_INRING=2048 -DNVCOMP_LZW_WAVES_PER_SIMD=8
+build w3k7  -DNVCOMP_LZW_OUTWIN=3072 -DNVCOMP_LZW_BATCHMAX=1024 -DNVCOMP_LZW_KEEP=1792 -DNVCOMP_LZW_INRING=2048 -DNVCOMP_LZW_WAVES_PER_SIMD=7
+build w4k6  -DNVCOMP_LZW_OUTWIN=4096 -DNVCOMP_LZW_BATCHMAX=1024 -DNVCOMP_LZW_KEEP=2816 -DNVCOMP_LZW_INRING=2048 -DNVCOMP_LZW_WAVES_PER_SIMD=6
+build w6k4  -DNVCOMP_LZW_OUTWIN=6144 -DNVCOMP_LZW_BATCHMAX=1024 -DNVCOMP_LZW_KEEP=4864 -DNVCOMP_LZW_INRING=2048 -DNVCOMP_LZW_WAVES_PER_SIMD=4
+build w2k8i1 -DNVCOMP_LZW_OUTWIN=2048 -DNVCOMP_LZW_INRING=1024 -DNVCOMP_LZW_WAVES_PER_SIMD=8

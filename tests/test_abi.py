@@ -66,3 +66,21 @@ def test_header_compiles_as_c():
         open(src, "w").write('#include "nvcomp.h"\nint main(void){nvcompBatchedLZ4Opts_t o = nvcompBatchedLZ4DefaultOpts; return (int)o.data_type;}\n')
         subprocess.run(["gcc", "-std=c99", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(REPO, "include"), "-I", "/opt/rocm/include",
                         "-c", src, "-o", os.path.join(d, "t.o")], check=True)
+
+
+def test_call_logging_env(tmp_path):
+    """NVCOMP_LOG_LEVEL / NVCOMP_LOG_FILE (reference README.md:79-88): level 3 logs every low-level call."""
+    import subprocess
+    import sys
+
+    log = tmp_path / "calls.log"
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+        "import conftest, numpy as np\n"
+        "be = conftest.Backend('emu', conftest.emu_library(), conftest.HostDevice())\n"
+        "c = be.codec('LZ4').compress([np.arange(5000, dtype=np.uint8)])\n"
+        "be.codec('LZ4').decompress(c, [5000])\n" % (REPO, REPO))
+    env = dict(os.environ, NVCOMP_LOG_LEVEL="3", NVCOMP_LOG_FILE=str(log))
+    subprocess.run([sys.executable, "-c", code], check=True, env=env)
+    text = log.read_text()
+    assert "nvcompBatchedLZ4CompressAsync(batch_size=1" in text and "nvcompBatchedLZ4DecompressAsync(batch_size=1" in text
