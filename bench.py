@@ -533,6 +533,17 @@ def main():
         result["data"] = "DRY RUN on the CPU emulation of the kernels: not a measurement"
     if ctx["rank"] == 0:
         print(json.dumps(result), flush=True)
+    if os.environ.get("NVCOMP_AMD_PROF"):  # phase clocks of a -DNVCOMP_LZW_PROF build (scripts/build_variants.sh)
+        import ctypes
+        import nvcomp_amd
+        lib = nvcomp_amd.load_library()
+        slots = (ctypes.c_ulonglong * 12)()
+        if hasattr(lib, "nvcompAmdProfRead") and lib.nvcompAmdProfRead(slots, 12) > 0:
+            tot = float(sum(slots)) or 1.0
+            names = ["in_ensure", "chase_build", "chase_enum", "parse", "exec_prep", "make_room", "far_issue+literals",
+                     "far_store", "match_rounds", "flush", "loop_top", "-"]
+            print(json.dumps({"phase_share": {n: round(v / tot, 4) for n, v in zip(names, slots)},
+                              "cycles_total": tot}), file=sys.stderr, flush=True)
     ctx["rt"].shutdown()
 
 

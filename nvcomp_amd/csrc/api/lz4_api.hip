@@ -67,7 +67,13 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZW_WAVES_PER_SIMD
   if (in_len64 > 0xffffffffull - 64) {
     err = lz::kErrInput;
   } else {
+#ifdef NVCOMP_LZW_PROF
+    lzw::prof_begin();
+#endif
     produced = lz4w::decode_chunk<CHECKED, ABLATE>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds[w], err);
+#ifdef NVCOMP_LZW_PROF
+    lzw::prof_end();
+#endif
   }
   if (wave::lane_id() == 0) {
     if (actual_bytes != nullptr) {
@@ -367,3 +373,20 @@ nvcompStatus_t nvcompBatchedLZ4CompressAsync(
 }
 
 } // extern "C"
+
+#ifdef NVCOMP_LZW_PROF
+/* Profiling builds only: read (and clear) the per-phase cycle sums of the window decoder. */
+extern "C" int nvcompAmdProfRead(unsigned long long* host_slots, int n)
+{
+  unsigned long long v[lzw::kProfSlots] = {};
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(lzw::g_prof), sizeof(v)) != hipSuccess) {
+    return -1;
+  }
+  for (int i = 0; i < n && i < (int)lzw::kProfSlots; ++i) {
+    host_slots[i] = v[i];
+  }
+  unsigned long long z[lzw::kProfSlots] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(lzw::g_prof), z, sizeof(z));
+  return (int)lzw::kProfSlots;
+}
+#endif

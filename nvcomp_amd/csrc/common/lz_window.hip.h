@@ -53,10 +53,58 @@ constexpr uint32_t kInRing = NVCOMP_LZW_INRING;     /* bytes of compressed-strea
 constexpr uint32_t kInBlock = 1024;  /* ring refill granule: 64 lanes x 16 bytes */
 constexpr uint32_t kOutLds = kOutWin + 32;
 constexpr uint32_t kInLds = kInRing + 16; /* first 16 bytes mirrored after the end */
-constexpr uint32_t kLdsPerWave = kOutLds + kInLds;
+#ifndef NVCOMP_LZW_PCHASE
+#define NVCOMP_LZW_PCHASE 1 /* 1: jump-table token chase (below); 0: the serial v_readlane walk */
+#endif
+constexpr uint32_t kChaseWin = 256;                 /* stream positions one chase window covers */
+constexpr uint32_t kChaseLevels = 6;                /* jump tables for 1, 2, 4, 8, 16, 32 tokens ahead */
+constexpr uint32_t kChaseLds = NVCOMP_LZW_PCHASE ? kChaseLevels * kChaseWin : 0;
+constexpr uint32_t kLdsPerWave = kOutLds + kInLds + kChaseLds;
 
 constexpr uint32_t kLitShort = 32;   /* lane-parallel literal runs: up to 8 dwords */
 constexpr uint32_t kMatchShort = 32; /* lane-parallel matches:      up to 8 dwords */
+
+/* ---- phase clock (profiling builds only: -DNVCOMP_LZW_PROF) ------------------ */
+#ifdef NVCOMP_LZW_PROF
+constexpr uint32_t kProfSlots = 12;
+__device__ unsigned long long g_prof[kProfSlots];
+__device__ __forceinline__ unsigned long long* prof_slots()
+{
+  __shared__ unsigned long long slots[16][kProfSlots + 1];
+  return slots[threadIdx.x >> 6];
+}
+__device__ __forceinline__ void prof_begin()
+{
+  if (wave::lane_id() == 0) {
+    unsigned long long* p = prof_slots();
+    for (uint32_t i = 0; i < kProfSlots; ++i) {
+      p[i] = 0;
+    }
+    p[kProfSlots] = __builtin_readcyclecounter();
+  }
+}
+__device__ __forceinline__ void prof_mark(uint32_t slot)
+{
+  if (wave::lane_id() == 0) {
+    unsigned long long* p = prof_slots();
+    const unsigned long long t = __builtin_readcyclecounter();
+    p[slot] += t - p[kProfSlots];
+    p[kProfSlots] = t;
+  }
+}
+__device__ __forceinline__ void prof_end()
+{
+  if (wave::lane_id() == 0) {
+    unsigned long long* p = prof_slots();
+    for (uint32_t i = 0; i < kProfSlots; ++i) {
+      atomicAdd(&g_prof[i], p[i]);
+    }
+  }
+}
+#define LZW_T(slot) lzw::prof_mark(slot)
+#else
+#define LZW_T(slot) ((void)0)
+#endif
 
 /* ---- compressed-stream ring ------------------------------------------------ */
 
@@ -148,6 +196,117 @@ __device__ __forceinline__ uint32_t in_byte(const InRing& r, uint32_t v)
 __device__ __forceinline__ uint32_t in_byte_uniform(const InRing& r, uint32_t v)
 {
   return wave::uniform(in_byte(r, v));
+}
+
+/* ---- token chase by pointer doubling ------------------------------------------
+ *
+ * The format-specific part is a functor `delta(r, p)`: the distance from a (speculative)
+ * token at virtual position p to the token after it, or kUnknownDelta when that cannot be
+ * told from the resident bytes. For a window of 256 positions the wave builds, in LDS,
+ * byte tables J_i[p] = distance from p to the 2^i-th token after p (255 = leaves the
+ * window / unknown), i = 0..5, by five doubling rounds J_i[p] = J_{i-1}[p] + J_{i-1}[p +
+ * J_{i-1}[p]]. Lane n then finds the n-th token after any start position by following the
+ * set bits of n through the tables: 64 token positions for 6 dependent LDS reads, instead of
+ * 64 dependent scalar steps. The tables do not depend on the start, so a window is built
+ * once however many batches it feeds. */
+
+constexpr uint32_t kUnknownDelta = 1u << 28; /* chunk sizes are < 2^28 */
+
+struct Chase
+{
+  uint32_t wb;    /* virtual position of window slot 0 */
+  uint32_t nx[4]; /* nx[j] lane l: delta of position wb + 64 j + l */
+  uint32_t q;     /* virtual position of the next token */
+  uint8_t* tab;   /* LDS, kChaseLds bytes */
+};
+
+__device__ __forceinline__ void chase_init(Chase& c, uint32_t q, uint8_t* lds)
+{
+  c.q = q;
+  c.wb = q - kChaseWin; /* forces a build */
+  c.tab = lds;
+}
+
+template <class Delta>
+__device__ __forceinline__ void chase_build(Chase& c, const InRing& r, Delta delta)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  c.wb = c.q;
+  const uint32_t room = r.vend - c.wb; /* c.q < vend */
+  const uint32_t limit = room < kChaseWin ? room : kChaseWin;
+  uint32_t a[4];
+#pragma unroll
+  for (uint32_t j = 0; j < 4; ++j) {
+    const uint32_t p = 64 * j + lane;
+    c.nx[j] = delta(r, c.wb + p);
+    a[j] = p + c.nx[j] < limit ? c.nx[j] : 255u; /* the successor must be a token inside the window */
+    c.tab[p] = (uint8_t)a[j];
+  }
+  wave::sync();
+#pragma unroll
+  for (uint32_t i = 1; i < kChaseLevels; ++i) {
+    const uint8_t* prev = c.tab + (i - 1) * kChaseWin;
+    uint8_t* cur = c.tab + i * kChaseWin;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+      const uint32_t p = 64 * j + lane;
+      /* a == 255 reads past its table (into the next one, still inside kChaseLds): the sum saturates anyway */
+      const uint32_t b = prev[p + a[j]];
+      const uint32_t sum = a[j] + b;
+      a[j] = sum < 255u ? sum : 255u; /* valid sums are <= 254: p + sum < 256 */
+      cur[p] = (uint8_t)a[j];
+    }
+    wave::sync();
+  }
+}
+
+/* Append token positions to seqpos lanes [k, 64); returns the new count. `slow(r, p)`
+ * gives the successor of the token at p when its delta is kUnknownDelta. */
+template <class Delta, class Slow>
+__device__ __forceinline__ uint32_t chase_tokens(
+    Chase& c, const InRing& r, uint32_t& seqpos, uint32_t k, Delta delta, Slow slow)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  while (k < 64 && c.q < r.vend) {
+    if (c.q - c.wb >= kChaseWin) {
+      chase_build(c, r, delta);
+      LZW_T(1);
+    }
+    /* lane n: the n-th token from c.q, if it lies in this window */
+    uint32_t pos = c.q - c.wb;
+    bool valid = true;
+#pragma unroll
+    for (uint32_t i = 0; i < kChaseLevels; ++i) {
+      if ((lane >> i) & 1u) {
+        const uint32_t a = c.tab[i * kChaseWin + pos];
+        if (a == 255u) {
+          valid = false;
+        } else {
+          pos += a;
+        }
+      }
+    }
+    const uint32_t count = wave::popc64(wave::ballot(valid)); /* a prefix of the lanes; lane 0 always */
+    const uint32_t room = 64 - k;
+    const uint32_t take = count < room ? count : room;
+    const uint32_t shifted = k ? wave::shuffle(pos, (lane - k) & 63u) : pos;
+    if (lane >= k && lane < k + take) {
+      seqpos = c.wb + shifted;
+    }
+    k += take;
+    if (take < count) {
+      c.q = c.wb + wave::read_lane(pos, take);
+    } else {
+      /* the window's chain is used up: leave through the last token's own delta */
+      const uint32_t last = wave::read_lane(pos, count - 1);
+      const uint32_t sel = last >> 6;
+      const uint32_t v = sel == 0 ? c.nx[0] : sel == 1 ? c.nx[1] : sel == 2 ? c.nx[2] : c.nx[3];
+      const uint32_t d = wave::read_lane(v, last & 63u);
+      c.q = d >= kUnknownDelta ? slow(r, c.wb + last) : c.wb + last + d;
+    }
+    LZW_T(2);
+  }
+  return k;
 }
 
 /* ---- output window --------------------------------------------------------- */
@@ -395,7 +554,9 @@ __device__ __forceinline__ uint32_t execute_window_batch(
   LZ_STAT("batches", 1);
   LZ_STAT("seqs", take);
   LZ_STAT("bytes", total);
+  LZW_T(4);
   out_make_room(ow, op);
+  LZW_T(5);
 
   /* ---- far matches: sources older than the window, read from HBM ---- */
   const uint32_t match_src = match_dst - s.match_off;
@@ -404,7 +565,11 @@ __device__ __forceinline__ uint32_t execute_window_batch(
   uint32_t far_data[8];
   const uint32_t far_steps = steps_for(far_lane, my_match);
   if (far_lane) {
+#ifdef NVCOMP_LZW_FAR_ABLATE /* profiling builds only (wrong output): far reads folded onto the chunk's first KiB */
+    const uint8_t* src = ow.out + (match_src & 1023u);
+#else
     const uint8_t* src = ow.out + match_src;
+#endif
     if (far_steps == 2) {
       load_dwords_clamped<2>(far_data, src, my_match);
     } else if (far_steps == 4) {
@@ -465,6 +630,7 @@ __device__ __forceinline__ uint32_t execute_window_batch(
     }
   }
 
+  LZW_T(6);
   /* ---- far match data into the window ---- */
   if (far_lane) {
     uint8_t* dst = out_at(ow, match_dst);
@@ -477,6 +643,7 @@ __device__ __forceinline__ uint32_t execute_window_batch(
     }
   }
   wave::sync();
+  LZW_T(7);
 
   /* ---- remaining matches, oldest first: multi-round resolution in LDS ---- */
   {
@@ -531,7 +698,9 @@ __device__ __forceinline__ uint32_t execute_window_batch(
     }
   }
 
+  LZW_T(8);
   out_flush(ow, op, op + total);
+  LZW_T(9);
   wave::sync(); /* later far reads of this wave must see the flushed bytes */
   op += total;
   return take;

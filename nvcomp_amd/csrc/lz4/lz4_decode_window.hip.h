@@ -20,12 +20,14 @@ namespace lz4w {
  * pass (chunk sizes are < 2^28, so position + kUnknown never looks like a position). */
 constexpr uint32_t kUnknown = 1u << 28;
 
+#if !NVCOMP_LZW_PCHASE
 struct Chase
 {
   uint32_t wb;    /* virtual position of lane 0 of nx[0] */
   uint32_t nx[4]; /* nx[j] lane l: distance from a token at wb+64j+l to the next token; kUnknown = slow path */
   uint32_t q;     /* virtual position of the next token */
 };
+#endif
 
 /* Distance from a (speculative) token at virtual position p to the next token.
  * Branch-free: the token and the byte behind it are fetched together, the one byte a
@@ -51,6 +53,7 @@ __device__ __forceinline__ uint32_t token_delta(const lzw::InRing& r, uint32_t p
   return unknown ? kUnknown : delta;
 }
 
+#if !NVCOMP_LZW_PCHASE
 __device__ __forceinline__ void chase_reload(Chase& c, const lzw::InRing& r)
 {
   c.wb = c.q;
@@ -61,6 +64,7 @@ __device__ __forceinline__ void chase_reload(Chase& c, const lzw::InRing& r)
     c.nx[j] = token_delta(r, c.wb + 64 * j + lane);
   }
 }
+#endif
 
 /* Scalar walk over one token with multi-byte length extensions. */
 __device__ __forceinline__ uint32_t chase_slow_next(const lzw::InRing& r, uint32_t q)
@@ -101,6 +105,7 @@ __device__ __forceinline__ uint32_t chase_slow_next(const lzw::InRing& r, uint32
   return pos;
 }
 
+#if !NVCOMP_LZW_PCHASE
 /* Append token positions to seqpos lanes [k, 64). Returns the new count.
  * The inner loop is the serial critical path of the decoder: one s_sub, one
  * v_readlane, the lane write and two scalar adds per token. Unknown deltas are
@@ -147,6 +152,18 @@ __device__ __forceinline__ uint32_t chase(Chase& c, const lzw::InRing& r, uint32
   }
   return k;
 }
+#endif /* !NVCOMP_LZW_PCHASE */
+
+#if NVCOMP_LZW_PCHASE
+struct DeltaFn
+{
+  __device__ __forceinline__ uint32_t operator()(const lzw::InRing& r, uint32_t p) const { return token_delta(r, p); }
+};
+struct SlowFn
+{
+  __device__ __forceinline__ uint32_t operator()(const lzw::InRing& r, uint32_t p) const { return chase_slow_next(r, p); }
+};
+#endif
 
 /* Lane-parallel field decode of the sequence whose token is at virtual position p. */
 __device__ __forceinline__ void parse(const lzw::InRing& r, uint32_t p, bool active, lz::Seq& s, bool& bad)
@@ -225,9 +242,14 @@ __device__ __forceinline__ uint32_t decode_chunk(
   lzw::OutWindow ow;
   lzw::in_init(ir, in, in_len, lds + lzw::kOutLds);
   lzw::out_init(ow, out, lds);
+#if NVCOMP_LZW_PCHASE
+  lzw::Chase c;
+  lzw::chase_init(c, ir.vbeg, lds + lzw::kOutLds + lzw::kInLds);
+#else
   Chase c;
   c.q = ir.vbeg;
   c.wb = c.q - 256; /* forces a reload */
+#endif
   uint32_t op = 0;
   uint32_t seqpos = 0;
   uint32_t count = 0; /* sequences recorded in seqpos lanes [0, count) and not yet executed */
@@ -237,9 +259,15 @@ __device__ __forceinline__ uint32_t decode_chunk(
     }
     /* keep the stream resident from the oldest unexecuted token to well past the chase */
     const uint32_t oldest = count ? wave::read_lane(seqpos, 0) : c.q;
+    LZW_T(10);
     lzw::in_ensure(ir, oldest, (c.q & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
+    LZW_T(0);
     const uint32_t before = count;
+#if NVCOMP_LZW_PCHASE
+    count = lzw::chase_tokens(c, ir, seqpos, count, DeltaFn(), SlowFn());
+#else
     count = chase(c, ir, seqpos, count);
+#endif
     (void)before;
     if (ABLATE == 1) {
       op += wave::reduce_add(lane < count ? seqpos : 0u) & 1u;
@@ -249,6 +277,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
     lz::Seq s;
     bool bad;
     parse(ir, seqpos, lane < count, s, bad);
+    LZW_T(3);
     if (ABLATE == 2) {
       op += wave::reduce_add(s.lit_len + s.match_len + s.match_off) & 1u;
       count = 0;

@@ -16,12 +16,14 @@ namespace snappyw {
  * pass (chunk sizes are < 2^28, so position + kUnknown never looks like a position). */
 constexpr uint32_t kUnknown = 1u << 28;
 
+#if !NVCOMP_LZW_PCHASE
 struct Chase
 {
   uint32_t wb;
   uint32_t nx[4];
   uint32_t q;
 };
+#endif
 
 /* Distance from a (speculative) tag at virtual position p to the next tag; kUnknown = unknown.
  * Branch-free: the tag and the four bytes behind it (a literal's length field) are fetched
@@ -43,6 +45,7 @@ __device__ __forceinline__ uint32_t tag_delta(const lzw::InRing& r, uint32_t p)
   return unknown ? kUnknown : (kind == 0 ? lit_delta : copy_delta);
 }
 
+#if !NVCOMP_LZW_PCHASE
 __device__ __forceinline__ void chase_reload(Chase& c, const lzw::InRing& r)
 {
   c.wb = c.q;
@@ -52,6 +55,7 @@ __device__ __forceinline__ void chase_reload(Chase& c, const lzw::InRing& r)
     c.nx[j] = tag_delta(r, c.wb + 64 * j + lane);
   }
 }
+#endif
 
 /* Scalar fallback (tag not resolvable from the ring). */
 __device__ __forceinline__ uint32_t chase_slow_next(const lzw::InRing& r, uint32_t q)
@@ -81,6 +85,7 @@ __device__ __forceinline__ uint32_t chase_slow_next(const lzw::InRing& r, uint32
   return pos + len + 1;
 }
 
+#if !NVCOMP_LZW_PCHASE
 /* Append token positions to seqpos lanes [k, 64). Returns the new count.
  * The inner loop is the serial critical path of the decoder: one s_sub, one
  * v_readlane, the lane write and two scalar adds per token. Unknown deltas are
@@ -127,6 +132,18 @@ __device__ __forceinline__ uint32_t chase(Chase& c, const lzw::InRing& r, uint32
   }
   return k;
 }
+#endif /* !NVCOMP_LZW_PCHASE */
+
+#if NVCOMP_LZW_PCHASE
+struct DeltaFn
+{
+  __device__ __forceinline__ uint32_t operator()(const lzw::InRing& r, uint32_t p) const { return tag_delta(r, p); }
+};
+struct SlowFn
+{
+  __device__ __forceinline__ uint32_t operator()(const lzw::InRing& r, uint32_t p) const { return chase_slow_next(r, p); }
+};
+#endif
 
 __device__ __forceinline__ void parse(const lzw::InRing& r, uint32_t p, bool active, lz::Seq& s, bool& bad)
 {
@@ -225,9 +242,14 @@ __device__ __forceinline__ uint32_t decode_chunk(
     return 0;
   }
   const uint32_t limit = CHECKED ? total : out_cap;
+#if NVCOMP_LZW_PCHASE
+  lzw::Chase c;
+  lzw::chase_init(c, q, lds + lzw::kOutLds + lzw::kInLds);
+#else
   Chase c;
   c.q = q;
   c.wb = c.q - 256;
+#endif
   uint32_t op = 0;
   uint32_t seqpos = 0;
   uint32_t count = 0;
@@ -237,7 +259,11 @@ __device__ __forceinline__ uint32_t decode_chunk(
     }
     const uint32_t oldest = count ? wave::read_lane(seqpos, 0) : c.q;
     lzw::in_ensure(ir, oldest, (c.q & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
+#if NVCOMP_LZW_PCHASE
+    count = lzw::chase_tokens(c, ir, seqpos, count, DeltaFn(), SlowFn());
+#else
     count = chase(c, ir, seqpos, count);
+#endif
     lz::Seq s;
     bool bad;
     parse(ir, seqpos, lane < count, s, bad);
