@@ -51,9 +51,18 @@ class CascadedOpts(C.Structure):
                 ("use_bp", C.c_int)]
 
 
-OPTS = {"LZ4": LZ4Opts, "Snappy": SnappyOpts, "Cascaded": CascadedOpts}
+class BitcompOpts(C.Structure):
+    _fields_ = [("algorithm_type", C.c_int), ("data_type", C.c_int)]
 
-# Every symbol include/nvcomp/{lz4,snappy,cascaded}.h declares, per format.
+
+class ANSOpts(C.Structure):
+    _fields_ = [("type", C.c_int)]
+
+
+OPTS = {"LZ4": LZ4Opts, "Snappy": SnappyOpts, "Cascaded": CascadedOpts, "Bitcomp": BitcompOpts, "ANS": ANSOpts}
+FORMATS = tuple(OPTS)
+
+# Every symbol include/nvcomp/{lz4,snappy,cascaded,bitcomp,ans}.h declares, per format.
 ENTRY_POINTS = (
     "CompressGetTempSize",
     "CompressGetMaxOutputChunkSize",
@@ -66,6 +75,8 @@ EXTRA_ENTRY_POINTS = {
     "LZ4": ("CompressGetTempSizeEx", "DecompressGetTempSizeEx"),
     "Snappy": ("CompressGetTempSizeEx", "DecompressGetTempSizeEx"),
     "Cascaded": (),
+    "Bitcomp": (),
+    "ANS": (),
 }
 
 
@@ -76,7 +87,7 @@ def build_library(verbose: bool = False) -> str:
     return LIB_PATH
 
 
-def declare(lib: C.CDLL, formats=("LZ4", "Snappy", "Cascaded")) -> C.CDLL:
+def declare(lib: C.CDLL, formats=FORMATS) -> C.CDLL:
     """Attach argtypes/restype for the formats the library exports."""
     vp, sz, szp = C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)
     for fmt in formats:

@@ -129,7 +129,7 @@ class BatchedCodec:
         self.lib, self.dev, self.fmt = lib, dev, fmt
         self.opts_t = OPTS[fmt]
         if opts is None:
-            opts = {"LZ4": (0,), "Snappy": (0,), "Cascaded": (4096, 4, 2, 1, 1)}[fmt]
+            opts = {"LZ4": (0,), "Snappy": (0,), "Cascaded": (4096, 4, 2, 1, 1), "Bitcomp": (0, 1), "ANS": (0,)}[fmt]
         self.opts = opts if isinstance(opts, self.opts_t) else self.opts_t(*opts)
         self._p = "nvcompBatched" + fmt
 

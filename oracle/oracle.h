@@ -38,6 +38,16 @@ size_t oracle_cascaded_compress(const uint8_t* src, size_t n_bytes, uint8_t* dst
                                 int type, int num_rles, int num_deltas, int use_bp);
 int oracle_cascaded_decompress(const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_cap, size_t* out_len);
 
+/* Bitcomp (oracle/bitcomp_ref.c; own stream, parity unpinned). elem_size in {1,2,4,8}; algo 0 = delta, 1 = plain. */
+size_t oracle_bitcomp_max_compressed(size_t n_bytes, int elem_size);
+size_t oracle_bitcomp_compress(const uint8_t* src, size_t n_bytes, uint8_t* dst, size_t dst_cap, int algo, int elem_size);
+int oracle_bitcomp_decompress(const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_cap, size_t* out_len);
+
+/* ANS (oracle/ans_ref.c; own stream, parity unpinned) */
+size_t oracle_ans_max_compressed(size_t n_bytes);
+size_t oracle_ans_compress(const uint8_t* src, size_t n_bytes, uint8_t* dst, size_t dst_cap);
+int oracle_ans_decompress(const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_cap, size_t* out_len);
+
 /* Batched, threaded drivers used for the cpu_baseline timing (oracle/batch.c).
  * codec: 0 = lz4 decompress, 1 = snappy decompress, 2 = lz4 compress, 3 = snappy compress.
  * Returns wall seconds of the best of `repeats` runs; per-chunk result sizes in out_sizes. */

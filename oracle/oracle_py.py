@@ -76,6 +76,20 @@ class _Lib:
             p.oracle_cascaded_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _szp]
             p.oracle_cascaded_max_compressed.restype = C.c_size_t
             p.oracle_cascaded_max_compressed.argtypes = [C.c_size_t, C.c_size_t, C.c_int]
+        if hasattr(p, "oracle_bitcomp_compress"):
+            p.oracle_bitcomp_compress.restype = C.c_size_t
+            p.oracle_bitcomp_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+            p.oracle_bitcomp_decompress.restype = C.c_int
+            p.oracle_bitcomp_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _szp]
+            p.oracle_bitcomp_max_compressed.restype = C.c_size_t
+            p.oracle_bitcomp_max_compressed.argtypes = [C.c_size_t, C.c_int]
+        if hasattr(p, "oracle_ans_compress"):
+            p.oracle_ans_compress.restype = C.c_size_t
+            p.oracle_ans_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+            p.oracle_ans_decompress.restype = C.c_int
+            p.oracle_ans_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _szp]
+            p.oracle_ans_max_compressed.restype = C.c_size_t
+            p.oracle_ans_max_compressed.argtypes = [C.c_size_t]
         r = self.ref
         if r is not None:
             for name in ("ref_lz4_decompress", "ref_lz4_compress", "ref_snappy_decompress", "ref_snappy_compress"):
@@ -192,6 +206,34 @@ def cascaded_decompress(comp, cap: int) -> Tuple[int, np.ndarray]:
 
 def cascaded_bound(n: int, sub_chunk: int = 4096, type_: int = 4) -> int:
     return int(lib().port.oracle_cascaded_max_compressed(n, sub_chunk, type_))
+
+
+def bitcomp_compress(raw, algo: int = 0, elem_size: int = 1) -> np.ndarray:
+    p = lib().port
+    src = _as_u8(raw)
+    cap = int(p.oracle_bitcomp_max_compressed(src.size, elem_size))
+    dst = np.zeros(max(cap, 1), dtype=np.uint8)
+    n = p.oracle_bitcomp_compress(_ptr(src), src.size, _ptr(dst), cap, algo, elem_size)
+    assert n > 0, "oracle_bitcomp_compress rejected its arguments"
+    return dst[:n].copy()
+
+
+def bitcomp_decompress(comp, cap: int) -> Tuple[int, np.ndarray]:
+    return _dec(lib().port.oracle_bitcomp_decompress, comp, cap)
+
+
+def ans_compress(raw) -> np.ndarray:
+    p = lib().port
+    src = _as_u8(raw)
+    cap = int(p.oracle_ans_max_compressed(src.size))
+    dst = np.zeros(max(cap, 1), dtype=np.uint8)
+    n = p.oracle_ans_compress(_ptr(src), src.size, _ptr(dst), cap)
+    assert n > 0, "oracle_ans_compress rejected its arguments"
+    return dst[:n].copy()
+
+
+def ans_decompress(comp, cap: int) -> Tuple[int, np.ndarray]:
+    return _dec(lib().port.oracle_ans_decompress, comp, cap)
 
 
 # ------------------------------------------------- liblz4 / libsnappy ("reference")
