@@ -210,6 +210,12 @@ __device__ __forceinline__ uint32_t popc64(uint64_t m)
   return (uint32_t)__builtin_popcountll(m);
 }
 
+/* Number of set bits of m below the calling lane (v_mbcnt_lo/hi). */
+__device__ __forceinline__ uint32_t prefix_popc(uint64_t m)
+{
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 } // namespace wave
 
 /* Algorithm statistics hook (rounds, path counts): compiled out on the device; the

@@ -15,13 +15,13 @@ sys.path.insert(0, REPO)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--algo", default="cascaded", choices=["lz4", "snappy", "cascaded"])
+    ap.add_argument("--algo", default="cascaded", choices=["lz4", "snappy", "cascaded", "bitcomp", "ans"])
     ap.add_argument("--dataset", default="int32")
     ap.add_argument("--mib", type=int, default=256)
     ap.add_argument("--unique-mib", type=int, default=16)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--chunk", type=int, default=65536)
-    ap.add_argument("--opts", default="4096,4,2,1,1", help="cascaded: chunk_size,type,num_RLEs,num_deltas,use_bp")
+    ap.add_argument("--opts", default="4096,4,2,1,1", help="cascaded: chunk_size,type,num_RLEs,num_deltas,use_bp; bitcomp: algo,type")
     a = ap.parse_args()
     import torch
 
@@ -31,8 +31,8 @@ def main():
 
     lib = nvcomp_amd.load_library()
     dev = nvcomp_amd.TorchDevice("cuda:0")
-    fmt = {"lz4": "LZ4", "snappy": "Snappy", "cascaded": "Cascaded"}[a.algo]
-    opts = tuple(int(x) for x in a.opts.split(",")) if a.algo == "cascaded" else None
+    fmt = {"lz4": "LZ4", "snappy": "Snappy", "cascaded": "Cascaded", "bitcomp": "Bitcomp", "ans": "ANS"}[a.algo]
+    opts = tuple(int(x) for x in a.opts.split(",")) if a.algo in ("cascaded", "bitcomp") else None
     codec = nvcomp_amd.BatchedCodec(lib, dev, fmt, opts)
     unique = a.unique_mib << 20
     gen = getattr(datasets, a.dataset) if hasattr(datasets, a.dataset) else datasets.CLASSES[a.dataset]

@@ -166,6 +166,11 @@ inline void sync() { emu::wave_rendezvous(kSync, 0, 0); }
 
 inline uint32_t ctz64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
 inline uint32_t popc64(uint64_t m) { return (uint32_t)__builtin_popcountll(m); }
+inline uint32_t prefix_popc(uint64_t m)
+{
+  const uint32_t l = (uint32_t)lane_id();
+  return (uint32_t)__builtin_popcountll(m & ((1ull << l) - 1ull));
+}
 
 } // namespace wave
 
