@@ -17,7 +17,7 @@ int main(int argc, char** argv)
 {
   try {
     if (argc < 2) {
-      std::cerr << "Usage: benchmark_hlif {lz4|snappy|cascaded} -f FILE [-c chunk] [-g gpu] [-n iters] [-t type] [-r -d -b]"
+      std::cerr << "Usage: benchmark_hlif {lz4|snappy|cascaded|bitcomp|ans} -f FILE [-c chunk] [-g gpu] [-n iters] [-t type] [-r -d -b]"
                 << std::endl;
       return 1;
     }
@@ -65,8 +65,13 @@ int main(int argc, char** argv)
     } else if (format == "cascaded") {
       casc.type = type;
       manager.reset(new CascadedManager(chunk, casc, stream, gpu, NoComputeNoVerify));
+    } else if (format == "bitcomp") {
+      manager.reset(new BitcompManager(chunk, nvcompBatchedBitcompFormatOpts{0 /* algo--fixed for now */, type}, stream, gpu,
+                                       NoComputeNoVerify));
+    } else if (format == "ans") {
+      manager.reset(new ANSManager(chunk, nvcompBatchedANSOpts_t{}, stream, gpu, NoComputeNoVerify));
     } else {
-      throw std::runtime_error("ERROR: unsupported format \"" + format + "\" (this build: lz4, snappy, cascaded)");
+      throw std::runtime_error("ERROR: unsupported format \"" + format + "\" (this build: lz4, snappy, cascaded, bitcomp, ans)");
     }
     const std::vector<char> data = util::read_file(file);
     const size_t n = data.size();

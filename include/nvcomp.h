@@ -14,5 +14,7 @@
 #include "nvcomp/lz4.h"
 #include "nvcomp/snappy.h"
 #include "nvcomp/cascaded.h"
+#include "nvcomp/bitcomp.h"
+#include "nvcomp/ans.h"
 
 #endif /* NVCOMP_H */

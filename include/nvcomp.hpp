@@ -3,6 +3,8 @@
 #pragma once
 
 #include "nvcomp.h"
+#include "nvcomp/ans.hpp"
+#include "nvcomp/bitcomp.hpp"
 #include "nvcomp/cascaded.hpp"
 #include "nvcomp/lz4.hpp"
 #include "nvcomp/nvcompManager.hpp"

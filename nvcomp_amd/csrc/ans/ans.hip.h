@@ -7,18 +7,18 @@
  *
  *   chunk := 'A' 'N' 'S' 0x01 | u32 n_bytes | u8 mode | 0 0 0 | body
  *   mode 0 (stored):  body = the n_bytes raw bytes
- *   mode 1 (rANS):    body = u32 n_words | u16 freq[256] (sum 2048) | u32 state[64] | u16 words[n_words]
+ *   mode 1 (rANS):    body = u32 n_words | u16 freq[256] (sum 1024) | u32 state[64] | u16 words[n_words]
  *
  * Symbol i of the chunk belongs to lane (i % 256) / 4 and row 4 (i / 256) + i % 4: a lane
  * codes 4 consecutive bytes of every 256-byte group, so both directions move whole dwords,
  * coalesced over the wave. Every lane runs its own rANS state (32 bit, lower bound 2^16,
- * 11-bit probabilities, 16-bit renormalisation words). The encoder walks the rows from the
+ * 10-bit probabilities, 16-bit renormalisation words). The encoder walks the rows from the
  * last to the first; in a row the lanes that must renormalise append their words to the
  * stream in lane order (ballot + prefix count). The decoder starts from the stored states at
  * the end of the word stream and walks the rows forward, taking the same groups back. A
  * chunk is stored when coding would not make it smaller, so no output exceeds n_bytes + 12.
  *
- * LDS per wave: compress 1 KiB (histogram, then the symbol table); decompress 8 KiB decode
+ * LDS per wave: compress 4 KiB (four histograms, then the symbol table in their place); decompress 4 KiB decode
  * table (one dword per slot: symbol | freq << 8 | (slot - start) << 20) + 1 KiB stream ring +
  * the cumulative table.
  */
@@ -31,7 +31,10 @@
 
 namespace ans {
 
-constexpr uint32_t kProbBits = 11;
+#ifndef NVCOMP_ANS_PROB_BITS
+#define NVCOMP_ANS_PROB_BITS 10 /* format constant (profiles/r01_ans_prob_bits.json); other values are for A/B builds only */
+#endif
+constexpr uint32_t kProbBits = NVCOMP_ANS_PROB_BITS;
 constexpr uint32_t kProbScale = 1u << kProbBits;
 constexpr uint32_t kStateLow = 1u << 16;
 constexpr uint32_t kHeaderBytes = 12;
@@ -40,7 +43,8 @@ constexpr uint32_t kStateOffset = kFreqOffset + 512;
 constexpr uint32_t kWordsOffset = kStateOffset + 256;
 constexpr uint32_t kMinCodedBytes = 1024; /* smaller chunks are always stored */
 constexpr uint32_t kRingWords = 512;
-constexpr uint32_t kEncodeLds = 1024;
+constexpr uint32_t kHistCopies = 4; /* the lanes spread their LDS atomics over this many histograms */
+constexpr uint32_t kEncodeLds = 1024 * kHistCopies; /* >= the 2 KiB symbol table that replaces the histograms */
 constexpr uint32_t kDecodeLds = kProbScale * 4 + kRingWords * 2 + 528;
 constexpr uint32_t kErrNone = 0;
 constexpr uint32_t kErrInput = 1;
@@ -108,7 +112,7 @@ __device__ __forceinline__ uint32_t store_raw(const uint8_t* __restrict__ src, u
 
 /* Scale the histogram to kProbScale keeping every present symbol >= 1. Lane l holds the
  * counts of symbols 4l..4l+3 in c[] and receives their frequencies in f[]. Deterministic:
- * floor(c * 2048 / n) floored at 1, then the surplus or deficit goes to / comes from the most
+ * floor(c * 1024 / n) floored at 1, then the surplus or deficit goes to / comes from the most
  * frequent symbol (lowest index on ties), repeatedly if it cannot absorb all of it. */
 __device__ __forceinline__ void normalise(const uint32_t c[4], uint32_t n, uint32_t f[4])
 {
@@ -172,19 +176,20 @@ __device__ __forceinline__ uint32_t encode_chunk(
   if (n < kMinCodedBytes) {
     return store_raw(src, n, dst);
   }
-  uint32_t* table = (uint32_t*)lds; /* histogram, then per symbol freq | start << 16 */
+  uint32_t* table = (uint32_t*)lds; /* histograms, then per symbol freq | start << 16 */
 #pragma unroll
-  for (uint32_t j = 0; j < 4; ++j) {
-    table[4 * lane + j] = 0;
+  for (uint32_t j = 0; j < 4 * kHistCopies; ++j) {
+    table[64 * j + lane] = 0;
   }
   wave::sync();
+  uint32_t* hist = table + 256 * (lane % kHistCopies);
   const uint32_t groups = (n + 255) / 256;
   for (uint32_t q = 0; q < groups; ++q) {
     const uint32_t v = load_group_dword(src, n, 256 * q, lane);
 #pragma unroll
     for (uint32_t r = 0; r < 4; ++r) {
       if (256 * q + 4 * lane + r < n) {
-        atomicAdd(&table[(v >> (8 * r)) & 255u], 1u);
+        atomicAdd(&hist[(v >> (8 * r)) & 255u], 1u);
       }
     }
   }
@@ -192,14 +197,23 @@ __device__ __forceinline__ uint32_t encode_chunk(
   uint32_t c[4], f[4], start[4];
 #pragma unroll
   for (uint32_t j = 0; j < 4; ++j) {
-    c[j] = table[4 * lane + j];
+    c[j] = 0;
+    for (uint32_t k = 0; k < kHistCopies; ++k) {
+      c[j] += table[256 * k + 4 * lane + j];
+    }
   }
   normalise(c, n, f);
   cumulate(f, start);
   wave::sync();
+  /* per symbol: { freq | start << 12 | log2ceil(freq) << 24, magic } -- x / freq by multiplication
+   * (Granlund & Montgomery, "Division by invariant integers using multiplication", PLDI 1994, fig. 4.1) */
 #pragma unroll
   for (uint32_t j = 0; j < 4; ++j) {
-    table[4 * lane + j] = f[j] | (start[j] << 16);
+    const uint32_t d = f[j] ? f[j] : 1u;
+    const uint32_t l = d > 1 ? 32u - (uint32_t)__builtin_clz(d - 1) : 0u;
+    const uint32_t magic = (uint32_t)((((uint64_t)((1u << l) - d)) << 32) / d) + 1u;
+    table[2 * (4 * lane + j)] = f[j] | (start[j] << 12) | (l << 24);
+    table[2 * (4 * lane + j) + 1] = magic;
     store_as<uint16_t>(dst + kFreqOffset + 2 * (4 * lane + j), (uint16_t)f[j]);
   }
   wave::sync();
@@ -214,10 +228,12 @@ __device__ __forceinline__ uint32_t encode_chunk(
     for (uint32_t rr = 0; rr < 4; ++rr) {
       const uint32_t r = 3 - rr;
       const bool active = 256 * q + 4 * lane + r < n;
-      const uint32_t e = table[(v >> (8 * r)) & 255u];
-      const uint32_t freq = e & 0xffffu;
-      const uint32_t base = e >> 16;
-      const bool emit = active && (x >> (32 - kProbBits)) >= freq; /* x >= freq << 21 */
+      const uint32_t sym = (v >> (8 * r)) & 255u;
+      const uint32_t e = table[2 * sym];
+      const uint32_t magic = table[2 * sym + 1];
+      const uint32_t freq = e & 0xfffu;
+      const uint32_t base = (e >> 12) & 0xfffu;
+      const bool emit = active && (x >> (32 - kProbBits)) >= freq; /* x >= freq << (32 - kProbBits) */
       const uint64_t m = wave::ballot(emit);
       const uint32_t cnt = wave::popc64(m);
       if (p + cnt >= limit_words) {
@@ -229,7 +245,10 @@ __device__ __forceinline__ uint32_t encode_chunk(
       }
       p += cnt;
       if (active) {
-        x = ((x / freq) << kProbBits) + (x % freq) + base;
+        const uint32_t l = e >> 24;
+        const uint32_t t = __umulhi(magic, x);
+        const uint32_t quot = (t + ((x - t) >> (l ? 1u : 0u))) >> (l ? l - 1u : 0u);
+        x = (quot << kProbBits) + (x - quot * freq) + base;
       }
     }
   }
@@ -363,38 +382,50 @@ __device__ __forceinline__ uint32_t decode_chunk(
 
   uint32_t x = load_as<uint32_t>(in + kStateOffset + 4 * lane);
   const uint32_t groups = (n + 255) / 256;
+  uint32_t underflow = 0; /* uniform; a corrupt stream may ask for more words than there are */
   for (uint32_t q = 0; q < groups; ++q) {
     const uint32_t at = 256 * q + 4 * lane;
     uint32_t packed = 0;
+    if (256 * q + 256 <= n) {
+      /* whole group: every lane decodes 4 symbols */
 #pragma unroll
-    for (uint32_t r = 0; r < 4; ++r) {
-      const bool active = at + r < n;
-      const uint32_t e = table[x & (kProbScale - 1)];
-      uint32_t nx = ((e >> 8) & 0xfffu) * (x >> kProbBits) + (e >> 20);
-      const bool need = active && nx < kStateLow;
-      const uint64_t m = wave::ballot(need);
-      const uint32_t cnt = wave::popc64(m);
-      if (cnt > p) {
-        err = kErrInput;
-        return 0;
-      }
-      p -= cnt;
-      if (need) {
-        nx = (nx << 16) | ring[(p + wave::prefix_popc(m)) & (kRingWords - 1)];
-      }
-      if (active) {
-        x = nx;
+      for (uint32_t r = 0; r < 4; ++r) {
+        const uint32_t e = table[x & (kProbScale - 1)];
+        x = __umul24((e >> 8) & 0xfffu, x >> kProbBits) + (e >> 20); /* 12 x 22 bits */
+        const bool need = x < kStateLow;
+        const uint64_t m = wave::ballot(need);
+        const uint32_t cnt = wave::popc64(m);
+        underflow |= cnt > p ? 1u : 0u;
+        p -= cnt;
+        if (need) {
+          x = (x << 16) | ring[(p + wave::prefix_popc(m)) & (kRingWords - 1)];
+        }
         packed |= (e & 255u) << (8 * r);
       }
-    }
-    if (at + 4 <= n) {
       store_as<uint32_t>(out + at, packed);
     } else {
+#pragma unroll
       for (uint32_t r = 0; r < 4; ++r) {
-        if (at + r < n) {
-          out[at + r] = (uint8_t)(packed >> (8 * r));
+        const bool active = at + r < n;
+        const uint32_t e = table[x & (kProbScale - 1)];
+        uint32_t nx = __umul24((e >> 8) & 0xfffu, x >> kProbBits) + (e >> 20);
+        const bool need = active && nx < kStateLow;
+        const uint64_t m = wave::ballot(need);
+        const uint32_t cnt = wave::popc64(m);
+        underflow |= cnt > p ? 1u : 0u;
+        p -= cnt;
+        if (need) {
+          nx = (nx << 16) | ring[(p + wave::prefix_popc(m)) & (kRingWords - 1)];
+        }
+        if (active) {
+          x = nx;
+          out[at + r] = (uint8_t)e;
         }
       }
+    }
+    if (underflow) {
+      err = kErrInput;
+      return 0;
     }
     ring_fill(w, p);
   }

@@ -294,87 +294,80 @@ struct ManagerImpl
   bool compute_checksums() const { return policy == ComputeAndNoVerify || policy == ComputeAndVerifyIfPresent || policy == ComputeAndVerify; }
   bool verify_checksums() const { return policy == NoComputeAndVerifyIfPresent || policy == ComputeAndVerifyIfPresent || policy == ComputeAndVerify; }
 
+#define NVCOMP_FORMATS(X)                                  \
+  X(kLZ4, LZ4, nvcompBatchedLZ4Opts_t)                     \
+  X(kSnappy, Snappy, nvcompBatchedSnappyOpts_t)            \
+  X(kCascaded, Cascaded, nvcompBatchedCascadedOpts_t)      \
+  X(kBitcomp, Bitcomp, nvcompBatchedBitcompFormatOpts)     \
+  X(kANS, ANS, nvcompBatchedANSOpts_t)
+
   nvcompStatus_t max_chunk(size_t* out) const
   {
     switch (format) {
-    case BatchedManager::kLZ4: {
-      nvcompBatchedLZ4Opts_t o;
-      memcpy(&o, opts, sizeof(o));
-      return nvcompBatchedLZ4CompressGetMaxOutputChunkSize(chunk, o, out);
+#define X(ID, NAME, OPTS)                                                        \
+  case BatchedManager::ID: {                                                     \
+    OPTS o;                                                                      \
+    memcpy(&o, opts, sizeof(o));                                                 \
+    return nvcompBatched##NAME##CompressGetMaxOutputChunkSize(chunk, o, out);    \
+  }
+      NVCOMP_FORMATS(X)
+#undef X
     }
-    case BatchedManager::kSnappy: {
-      nvcompBatchedSnappyOpts_t o;
-      memcpy(&o, opts, sizeof(o));
-      return nvcompBatchedSnappyCompressGetMaxOutputChunkSize(chunk, o, out);
-    }
-    default: {
-      nvcompBatchedCascadedOpts_t o;
-      memcpy(&o, opts, sizeof(o));
-      return nvcompBatchedCascadedCompressGetMaxOutputChunkSize(chunk, o, out);
-    }
-    }
+    return nvcompErrorInvalidValue;
   }
 
   nvcompStatus_t compress_temp(size_t n, size_t* out) const
   {
     switch (format) {
-    case BatchedManager::kLZ4: {
-      nvcompBatchedLZ4Opts_t o;
-      memcpy(&o, opts, sizeof(o));
-      return nvcompBatchedLZ4CompressGetTempSize(n, chunk, o, out);
+#define X(ID, NAME, OPTS)                                                   \
+  case BatchedManager::ID: {                                                \
+    OPTS o;                                                                 \
+    memcpy(&o, opts, sizeof(o));                                            \
+    return nvcompBatched##NAME##CompressGetTempSize(n, chunk, o, out);      \
+  }
+      NVCOMP_FORMATS(X)
+#undef X
     }
-    case BatchedManager::kSnappy: {
-      nvcompBatchedSnappyOpts_t o;
-      memcpy(&o, opts, sizeof(o));
-      return nvcompBatchedSnappyCompressGetTempSize(n, chunk, o, out);
-    }
-    default: {
-      nvcompBatchedCascadedOpts_t o;
-      memcpy(&o, opts, sizeof(o));
-      return nvcompBatchedCascadedCompressGetTempSize(n, chunk, o, out);
-    }
-    }
+    return nvcompErrorInvalidValue;
   }
 
   nvcompStatus_t decompress_temp(size_t n, size_t* out) const
   {
     switch (format) {
-    case BatchedManager::kLZ4: return nvcompBatchedLZ4DecompressGetTempSize(n, chunk, out);
-    case BatchedManager::kSnappy: return nvcompBatchedSnappyDecompressGetTempSize(n, chunk, out);
-    default: return nvcompBatchedCascadedDecompressGetTempSize(n, chunk, out);
+#define X(ID, NAME, OPTS) \
+  case BatchedManager::ID: return nvcompBatched##NAME##DecompressGetTempSize(n, chunk, out);
+      NVCOMP_FORMATS(X)
+#undef X
     }
+    return nvcompErrorInvalidValue;
   }
 
   nvcompStatus_t compress_async(const void* const* in_ptrs, const size_t* in_sizes, size_t n, void* t, size_t tb,
                                 void* const* out_ptrs, size_t* out_sizes) const
   {
     switch (format) {
-    case BatchedManager::kLZ4: {
-      nvcompBatchedLZ4Opts_t o;
-      memcpy(&o, opts, sizeof(o));
-      return nvcompBatchedLZ4CompressAsync(in_ptrs, in_sizes, chunk, n, t, tb, out_ptrs, out_sizes, o, stream);
+#define X(ID, NAME, OPTS)                                                                                          \
+  case BatchedManager::ID: {                                                                                       \
+    OPTS o;                                                                                                        \
+    memcpy(&o, opts, sizeof(o));                                                                                   \
+    return nvcompBatched##NAME##CompressAsync(in_ptrs, in_sizes, chunk, n, t, tb, out_ptrs, out_sizes, o, stream); \
+  }
+      NVCOMP_FORMATS(X)
+#undef X
     }
-    case BatchedManager::kSnappy: {
-      nvcompBatchedSnappyOpts_t o;
-      memcpy(&o, opts, sizeof(o));
-      return nvcompBatchedSnappyCompressAsync(in_ptrs, in_sizes, chunk, n, t, tb, out_ptrs, out_sizes, o, stream);
-    }
-    default: {
-      nvcompBatchedCascadedOpts_t o;
-      memcpy(&o, opts, sizeof(o));
-      return nvcompBatchedCascadedCompressAsync(in_ptrs, in_sizes, chunk, n, t, tb, out_ptrs, out_sizes, o, stream);
-    }
-    }
+    return nvcompErrorInvalidValue;
   }
 
   nvcompStatus_t decompress_async(const void* const* cp, const size_t* cs, const size_t* caps, size_t* actual, size_t n,
                                   void* t, size_t tb, void* const* op, nvcompStatus_t* st) const
   {
     switch (format) {
-    case BatchedManager::kLZ4: return nvcompBatchedLZ4DecompressAsync(cp, cs, caps, actual, n, t, tb, op, st, stream);
-    case BatchedManager::kSnappy: return nvcompBatchedSnappyDecompressAsync(cp, cs, caps, actual, n, t, tb, op, st, stream);
-    default: return nvcompBatchedCascadedDecompressAsync(cp, cs, caps, actual, n, t, tb, op, st, stream);
+#define X(ID, NAME, OPTS) \
+  case BatchedManager::ID: return nvcompBatched##NAME##DecompressAsync(cp, cs, caps, actual, n, t, tb, op, st, stream);
+      NVCOMP_FORMATS(X)
+#undef X
     }
+    return nvcompErrorInvalidValue;
   }
 
   Header read_header(const uint8_t* comp_buffer) const
@@ -563,9 +556,10 @@ std::shared_ptr<nvcompManagerBase> create_manager(
   }
   size_t opts_bytes;
   switch (h.format) {
-  case BatchedManager::kLZ4: opts_bytes = sizeof(nvcompBatchedLZ4Opts_t); break;
-  case BatchedManager::kSnappy: opts_bytes = sizeof(nvcompBatchedSnappyOpts_t); break;
-  case BatchedManager::kCascaded: opts_bytes = sizeof(nvcompBatchedCascadedOpts_t); break;
+#define X(ID, NAME, OPTS) \
+  case BatchedManager::ID: opts_bytes = sizeof(OPTS); break;
+    NVCOMP_FORMATS(X)
+#undef X
   default: throw std::runtime_error("nvcomp: create_manager: unknown format id in the buffer header");
   }
   return std::make_shared<BatchedManager>(

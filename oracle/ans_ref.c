@@ -15,7 +15,7 @@
 
 #include <string.h>
 
-#define ANS_PROB_BITS 11
+#define ANS_PROB_BITS 10
 #define ANS_SCALE (1u << ANS_PROB_BITS)
 #define ANS_LOW (1u << 16)
 #define ANS_HEADER 12

@@ -108,6 +108,8 @@ inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v);
 inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
 inline int __clz(unsigned v) { return v ? __builtin_clz(v) : 32; }
 inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
+inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 
 template <typename T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <typename T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }

@@ -15,7 +15,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_functions():
     names = set()
-    for h in ("lz4.h", "snappy.h", "cascaded.h"):
+    for h in ("lz4.h", "snappy.h", "cascaded.h", "bitcomp.h", "ans.h"):
         text = open(os.path.join(REPO, "include", "nvcomp", h)).read()
         names |= set(re.findall(r"nvcompStatus_t\s+(nvcompBatched\w+)\s*\(", text))
     return sorted(names)
@@ -30,7 +30,7 @@ def lib():
 
 def test_every_declared_symbol_is_exported(lib):
     names = declared_functions()
-    assert len(names) == 6 * 3 + 4  # six entry points per format + the *GetTempSizeEx pairs
+    assert len(names) == 6 * 5 + 4  # six entry points per format + the LZ4/Snappy *GetTempSizeEx pairs
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
 
@@ -44,12 +44,17 @@ def test_host_only_queries_work_without_gpu(lib):
     assert out.value == 76490  # == snappy::MaxCompressedLength(65536)
     assert lib.nvcompBatchedLZ4DecompressGetTempSize(1000, 65536, C.byref(out)) == 0
     assert lib.nvcompBatchedCascadedDecompressGetTempSize(1000, 65536, C.byref(out)) == 0 and out.value == 4000
+    assert lib.nvcompBatchedANSCompressGetMaxOutputChunkSize(65536, _lib.ANSOpts(0), C.byref(out)) == 0
+    assert out.value == 65552  # stored form + 12-byte header, rounded to 8
+    assert lib.nvcompBatchedBitcompCompressGetMaxOutputChunkSize(65536, _lib.BitcompOpts(0, 5), C.byref(out)) == 0
+    assert out.value == 12 + 8 * (32 + 8192) + 4  # 8 full blocks of 2048 uint32 at width 32, rounded to 8
     assert lib.nvcompBatchedLZ4CompressGetTempSize(10, 65536, _lib.LZ4Opts(0), None) == _lib.NvcompStatus.ErrorInvalidValue
 
 
 def test_struct_and_enum_layout():
     assert C.sizeof(_lib.LZ4Opts) == 4 and C.sizeof(_lib.SnappyOpts) == 4
     assert C.sizeof(_lib.CascadedOpts) == 24 and _lib.CascadedOpts.type.offset == 8
+    assert C.sizeof(_lib.BitcompOpts) == 8 and _lib.BitcompOpts.data_type.offset == 4 and C.sizeof(_lib.ANSOpts) == 4
     text = open(os.path.join(REPO, "include", "nvcomp", "shared_types.h")).read()
     for name, val in (("nvcompSuccess", 0), ("nvcompErrorCannotDecompress", 12), ("nvcompErrorBadChecksum", 13),
                       ("nvcompErrorAlignment", 17), ("NVCOMP_TYPE_CHAR", 0), ("NVCOMP_TYPE_ULONGLONG", 7)):

@@ -58,7 +58,7 @@ def test_ragged_sizes(backend, oracle):
 
 def test_extreme_histograms(backend, oracle):
     rng = np.random.RandomState(2)
-    one = np.full(65536, 7, dtype=np.uint8)                       # a single symbol: freq 2048, no words at all
+    one = np.full(65536, 7, dtype=np.uint8)                       # a single symbol: freq 1024, no words at all
     two = (rng.rand(65536) < 0.001).astype(np.uint8) * 200        # one dominant symbol and a rare one
     rare = np.zeros(65536, dtype=np.uint8)
     rare[rng.choice(65536, 255, replace=False)] = np.arange(1, 256, dtype=np.uint8)  # 255 symbols seen once each
@@ -85,7 +85,7 @@ def test_corrupt_streams(backend, oracle):
         elif i == 3:
             b[4] ^= 0x40  # uncompressed size field
         elif i == 4:
-            b[16] ^= 0x01  # a frequency: the table no longer sums to 2048
+            b[16] ^= 0x01  # a frequency: the table no longer sums to 1024
         elif i == 5:
             b[530] ^= 0x20  # a final state
         elif i == 6:

@@ -70,9 +70,11 @@ def test_examples_on_gpu(built_programs, sample_files):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prog,extra", [("benchmark_lz4_chunked", []), ("benchmark_snappy_chunked", []),
-                                         ("benchmark_cascaded_chunked", ["-t", "int"])])
+                                         ("benchmark_cascaded_chunked", ["-t", "int"]),
+                                         ("benchmark_ans_chunked", []), ("benchmark_bitcomp_chunked", ["-t", "int"]),
+                                         ("benchmark_bitcomp_chunked", ["-t", "int", "-a", "1"])])
 def test_chunked_harness_on_gpu(built_programs, sample_files, prog, extra):
-    f = sample_files["col.int32"] if "cascaded" in prog else sample_files["table.txt"]
+    f = sample_files["col.int32"] if "cascaded" in prog or "bitcomp" in prog else sample_files["table.txt"]
     out = run([f"benchmarks/bin/{prog}", "-f", f, "-i", "2", "-x", "4"] + extra)
     lines = out.strip().splitlines()
     assert lines[0] == "----------" and lines[1] == "files: 1"
@@ -86,9 +88,10 @@ def test_chunked_harness_on_gpu(built_programs, sample_files, prog, extra):
 
 @pytest.mark.gpu
 def test_hlif_and_synth_benchmarks_on_gpu(built_programs, sample_files):
-    for fmt in ("lz4", "snappy", "cascaded"):
-        f = sample_files["col.int32"] if fmt == "cascaded" else sample_files["table.txt"]
-        out = run(["benchmarks/bin/benchmark_hlif", fmt, "-f", f, "-n", "2"] + (["-t", "int"] if fmt == "cascaded" else []))
+    for fmt in ("lz4", "snappy", "cascaded", "bitcomp", "ans"):
+        numeric = fmt in ("cascaded", "bitcomp")
+        f = sample_files["col.int32"] if numeric else sample_files["table.txt"]
+        out = run(["benchmarks/bin/benchmark_hlif", fmt, "-f", f, "-n", "2"] + (["-t", "int"] if numeric else []))
         assert "decompression throughput (GB/s):" in out and "compressed ratio:" in out
     out = run(["benchmarks/bin/benchmark_snappy_synth", "-b", "500", "-w", "2", "-i", "3"])
     assert "decompression throughput (GB/s):" in out
