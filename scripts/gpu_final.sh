@@ -19,6 +19,16 @@ done
 for algo in lz4 snappy; do for ds in silesia_style text int32; do
   timeout 200 python scripts/bench_roundtrip.py --algo $algo --dataset $ds --unique-mib 32 --mib 1024 >> "$OUT/roundtrip.jsonl" 2>> "$OUT/roundtrip.err"
 done; done
+for ds in silesia_style text table float_csv int32 lowcard zeros noise; do
+  timeout 200 python scripts/bench_roundtrip.py --algo ans --dataset $ds --unique-mib 32 --mib 1024 >> "$OUT/roundtrip.jsonl" 2>> "$OUT/roundtrip.err"
+done
+for spec in "int32 0,4" "int32 1,4" "float32 0,4" "int32 0,6" "int32 0,2" "silesia_style 0,1" "zeros 0,1"; do
+  set -- $spec
+  timeout 200 python scripts/bench_roundtrip.py --algo bitcomp --dataset $1 --opts $2 --unique-mib 32 --mib 1024 >> "$OUT/roundtrip.jsonl" 2>> "$OUT/roundtrip.err"
+done
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_ans" -o r -- python scripts/bench_roundtrip.py --algo ans --dataset silesia_style --unique-mib 32 --mib 1024 > "$OUT/trace_ans.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_bitcomp" -o r -- python scripts/bench_roundtrip.py --algo bitcomp --dataset int32 --opts 0,4 --unique-mib 32 --mib 1024 > "$OUT/trace_bitcomp.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_cascaded" -o r -- python scripts/bench_roundtrip.py --algo cascaded --dataset int32 --unique-mib 32 --mib 1024 > "$OUT/trace_cascaded.log" 2>&1
 B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
 run_pmc() { local name=$1; shift
   timeout 300 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -o r -- $B > "$OUT/pmc_$name.log" 2>&1; echo "pmc $name rc=$?" >> "$OUT/rc.txt"; }
