@@ -113,3 +113,9 @@ def test_opts_validation(backend):
     assert lib.nvcompBatchedANSCompressGetTempSize(1, 65536, ANSOpts(3), C.byref(out)) == NvcompStatus.ErrorInvalidValue
     assert lib.nvcompBatchedANSCompressGetMaxOutputChunkSize((1 << 24) + 1, ANSOpts(0), C.byref(out)) \
         == NvcompStatus.ErrorChunkSizeTooLarge
+
+
+def test_large_chunk(backend, oracle):
+    """Chunks well beyond 64 KiB (the API allows up to nvcompANSCompressionMaxAllowedChunkSize = 16 MiB)."""
+    big = datasets.text((1 << 20) + 12345, 9)
+    roundtrip(backend, oracle, [big, datasets.lowcard(300000, 1)])

@@ -130,3 +130,10 @@ def test_opts_validation(backend):
         assert lib.nvcompBatchedBitcompCompressGetTempSize(1, 65536, bad, C.byref(out)) == NvcompStatus.ErrorInvalidValue
     assert lib.nvcompBatchedBitcompCompressGetMaxOutputChunkSize((1 << 24) + 1, BitcompOpts(0, 1), C.byref(out)) \
         == NvcompStatus.ErrorChunkSizeTooLarge
+
+
+def test_large_chunk(backend, oracle):
+    """Chunks well beyond 64 KiB (up to nvcompBitcompCompressionMaxAllowedChunkSize = 16 MiB are accepted)."""
+    big = datasets.int32_column((1 << 20) + 4 * 777, 9)
+    roundtrip(backend, oracle, [big], 0, 4)
+    roundtrip(backend, oracle, [big[: 300000]], 1, 6)

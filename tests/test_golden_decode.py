@@ -24,3 +24,21 @@ def test_decode_golden(backend, kind, fmt):
     for o, r in zip(outs, recs):
         assert hashlib.sha256(o.tobytes()).hexdigest() == r["sha256"]
     assert codec.get_decompress_size(comp).tolist() == [r["bytes"] for r in recs]
+
+
+OWN = json.load(open(os.path.join(GOLDEN, "own_manifest.json")))
+
+
+@pytest.mark.parametrize("rec", OWN["streams"], ids=[s["file"] for s in OWN["streams"]])
+def test_own_format_golden(backend, oracle, rec):
+    """Cascaded / Bitcomp / ANS streams committed by scripts/make_golden_own.py: the HIP compressor must
+    reproduce them byte for byte and the HIP decompressor must invert them (layout pinned across rounds)."""
+    stream = np.fromfile(os.path.join(GOLDEN, rec["file"]), dtype=np.uint8)
+    assert hashlib.sha256(stream.tobytes()).hexdigest() == rec["stream_sha256"]
+    rc, chunk = oracle.lz4_decompress(np.fromfile(os.path.join(GOLDEN, rec["source"]), dtype=np.uint8), rec["bytes"])
+    assert rc == 0 and hashlib.sha256(chunk.tobytes()).hexdigest() == rec["sha256"]
+    codec = backend.codec(rec["format"], tuple(rec["opts"]))
+    (made,) = codec.compress([chunk])
+    assert np.array_equal(made, stream), "compressed bytes differ from the committed golden stream"
+    outs, actual, status = codec.decompress([stream], [rec["bytes"]], comp_align=8, out_align=8)
+    assert status[0] == 0 and actual[0] == rec["bytes"] and np.array_equal(outs[0], chunk)
