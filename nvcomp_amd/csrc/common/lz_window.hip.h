@@ -53,6 +53,11 @@ constexpr uint32_t kInRing = NVCOMP_LZW_INRING;     /* bytes of compressed-strea
 constexpr uint32_t kInBlock = 1024;  /* ring refill granule: 64 lanes x 16 bytes */
 constexpr uint32_t kOutLds = kOutWin + 32;
 constexpr uint32_t kInLds = kInRing + 16; /* first 16 bytes mirrored after the end */
+/* Profiling builds only (wrong output by construction): bit mask of execute stages to leave out.
+ * 1 = HBM flush stores, 2 = far-match HBM loads, 4 = literal copies, 8 = in-window match rounds, 16 = far data into LDS */
+#ifndef NVCOMP_LZW_ABLATE_EXEC
+#define NVCOMP_LZW_ABLATE_EXEC 0
+#endif
 #ifndef NVCOMP_LZW_PCHASE
 #define NVCOMP_LZW_PCHASE 1 /* 1: jump-table token chase (below); 0: the serial v_readlane walk */
 #endif
@@ -215,7 +220,7 @@ constexpr uint32_t kUnknownDelta = 1u << 28; /* chunk sizes are < 2^28 */
 struct Chase
 {
   uint32_t wb;    /* virtual position of window slot 0 */
-  uint32_t nx[4]; /* nx[j] lane l: delta of position wb + 64 j + l */
+  uint32_t nx[4]; /* nx[k] lane l: delta of position wb + 4 l + k */
   uint32_t q;     /* virtual position of the next token */
   uint8_t* tab;   /* LDS, kChaseLds bytes */
 };
@@ -227,6 +232,10 @@ __device__ __forceinline__ void chase_init(Chase& c, uint32_t q, uint8_t* lds)
   c.tab = lds;
 }
 
+/* Lane l of a build owns the 4 consecutive window positions 4 l .. 4 l + 3: their token
+ * bytes come from two dword reads of the ring and their table entries are written as one dword.
+ * A window is "interior" when every byte a delta may look at is resident and before the end of
+ * the chunk; the format's `fast` delta then needs no bounds tests at all. */
 template <class Delta>
 __device__ __forceinline__ void chase_build(Chase& c, const InRing& r, Delta delta)
 {
@@ -234,28 +243,49 @@ __device__ __forceinline__ void chase_build(Chase& c, const InRing& r, Delta del
   c.wb = c.q;
   const uint32_t room = r.vend - c.wb; /* c.q < vend */
   const uint32_t limit = room < kChaseWin ? room : kChaseWin;
-  uint32_t a[4];
+  const uint32_t reach = c.wb + kChaseWin + Delta::kReach;
+  const bool interior = c.wb >= r.lo && reach <= r.hi && reach <= r.vend;
+  const uint32_t base = c.wb + 4 * lane;
+  if (interior) {
+    /* 8 stream bytes from `base` on, from three aligned dwords (a misaligned ds_read_b32 costs 16x) */
+    const uint32_t a0 = base & ~3u;
+    const uint32_t d0 = *(const uint32_t*)(r.ring + (a0 & (kInRing - 1)));
+    const uint32_t d1 = *(const uint32_t*)(r.ring + ((a0 + 4) & (kInRing - 1)));
+    const uint32_t d2 = *(const uint32_t*)(r.ring + ((a0 + 8) & (kInRing - 1)));
+    const uint32_t w0 = wave::align_bytes(d1, d0, base & 3u);
+    const uint32_t w1 = wave::align_bytes(d2, d1, base & 3u);
+    const uint64_t w = ((uint64_t)w1 << 32) | w0;
 #pragma unroll
-  for (uint32_t j = 0; j < 4; ++j) {
-    const uint32_t p = 64 * j + lane;
-    c.nx[j] = delta(r, c.wb + p);
-    a[j] = p + c.nx[j] < limit ? c.nx[j] : 255u; /* the successor must be a token inside the window */
-    c.tab[p] = (uint8_t)a[j];
+    for (uint32_t k = 0; k < 4; ++k) {
+      c.nx[k] = delta.fast(r, base + k, w >> (8 * k));
+    }
+  } else {
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      c.nx[k] = delta(r, base + k);
+    }
   }
+  uint32_t a[4];
+  uint32_t packed = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 4; ++k) {
+    a[k] = 4 * lane + k + c.nx[k] < limit ? c.nx[k] : 255u; /* the successor must be a token inside the window */
+    packed |= a[k] << (8 * k);
+  }
+  *(uint32_t*)(c.tab + 4 * lane) = packed;
   wave::sync();
 #pragma unroll
   for (uint32_t i = 1; i < kChaseLevels; ++i) {
-    const uint8_t* prev = c.tab + (i - 1) * kChaseWin;
-    uint8_t* cur = c.tab + i * kChaseWin;
+    const uint8_t* prev = c.tab + (i - 1) * kChaseWin + 4 * lane;
+    packed = 0;
 #pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) {
-      const uint32_t p = 64 * j + lane;
+    for (uint32_t k = 0; k < 4; ++k) {
       /* a == 255 reads past its table (into the next one, still inside kChaseLds): the sum saturates anyway */
-      const uint32_t b = prev[p + a[j]];
-      const uint32_t sum = a[j] + b;
-      a[j] = sum < 255u ? sum : 255u; /* valid sums are <= 254: p + sum < 256 */
-      cur[p] = (uint8_t)a[j];
+      const uint32_t sum = a[k] + prev[k + a[k]];
+      a[k] = sum < 255u ? sum : 255u; /* valid sums are <= 254: position + sum < 256 */
+      packed |= a[k] << (8 * k);
     }
+    *(uint32_t*)(c.tab + i * kChaseWin + 4 * lane) = packed;
     wave::sync();
   }
 }
@@ -272,19 +302,16 @@ __device__ __forceinline__ uint32_t chase_tokens(
       chase_build(c, r, delta);
       LZW_T(1);
     }
-    /* lane n: the n-th token from c.q, if it lies in this window */
+    /* lane n: the n-th token from c.q, if it lies in this window (branch-free: every lane reads every level) */
     uint32_t pos = c.q - c.wb;
     bool valid = true;
 #pragma unroll
     for (uint32_t i = 0; i < kChaseLevels; ++i) {
-      if ((lane >> i) & 1u) {
-        const uint32_t a = c.tab[i * kChaseWin + pos];
-        if (a == 255u) {
-          valid = false;
-        } else {
-          pos += a;
-        }
-      }
+      const uint32_t a = c.tab[i * kChaseWin + pos];
+      const bool step = valid && ((lane >> i) & 1u) != 0;
+      const bool out = step && a == 255u;
+      valid = valid && !out;
+      pos += step && !out ? a : 0u;
     }
     const uint32_t count = wave::popc64(wave::ballot(valid)); /* a prefix of the lanes; lane 0 always */
     const uint32_t room = 64 - k;
@@ -299,9 +326,9 @@ __device__ __forceinline__ uint32_t chase_tokens(
     } else {
       /* the window's chain is used up: leave through the last token's own delta */
       const uint32_t last = wave::read_lane(pos, count - 1);
-      const uint32_t sel = last >> 6;
+      const uint32_t sel = last & 3u;
       const uint32_t v = sel == 0 ? c.nx[0] : sel == 1 ? c.nx[1] : sel == 2 ? c.nx[2] : c.nx[3];
-      const uint32_t d = wave::read_lane(v, last & 63u);
+      const uint32_t d = wave::read_lane(v, last >> 2);
       c.q = d >= kUnknownDelta ? slow(r, c.wb + last) : c.wb + last + d;
     }
     LZW_T(2);
@@ -318,6 +345,7 @@ struct OutWindow
   uint32_t align;    /* out & 15: window index = position - wbase + align */
   uint32_t wbase;    /* output position of window index `align` (multiple of 16) */
   uint32_t valid_lo; /* positions >= valid_lo (and < op) are present in the window */
+  uint32_t flushed;  /* positions < flushed are in HBM; valid_lo <= flushed <= op, op - flushed < 16 between batches */
 };
 
 __device__ __forceinline__ void out_init(OutWindow& w, uint8_t* out, uint8_t* lds)
@@ -327,6 +355,7 @@ __device__ __forceinline__ void out_init(OutWindow& w, uint8_t* out, uint8_t* ld
   w.align = (uint32_t)((uintptr_t)out & 15u);
   w.wbase = 0;
   w.valid_lo = 0;
+  w.flushed = 0;
 }
 
 __device__ __forceinline__ uint8_t* out_at(const OutWindow& w, uint32_t pos)
@@ -372,7 +401,7 @@ __device__ __forceinline__ void out_make_room(OutWindow& w, uint32_t op)
 
 /* Flush window bytes of output positions [from, to) to HBM: byte stores up to
  * the first 16-byte boundary, aligned 16-byte lane stores, byte stores for the tail. */
-__device__ __forceinline__ void out_flush(const OutWindow& w, uint32_t from, uint32_t to)
+__device__ __forceinline__ void out_flush_range(const OutWindow& w, uint32_t from, uint32_t to)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   const uint32_t a_from = from + w.align; /* absolute-address-congruent coordinates */
@@ -396,6 +425,27 @@ __device__ __forceinline__ void out_flush(const OutWindow& w, uint32_t from, uin
   }
 }
 
+/* Per-batch flush: only whole 16-byte blocks go out; the last op % 16 bytes wait in the window for the
+ * next batch (sub-dword global stores cost a memory request each). After the first flush `flushed` sits on
+ * a 16-byte boundary of the output address, so a batch issues aligned 16-byte stores only. */
+__device__ __forceinline__ void out_flush(OutWindow& w, uint32_t op_end)
+{
+  const uint32_t a_to = (op_end + w.align) & ~15u; /* address-congruent coordinate of the last whole block's end */
+  if (a_to > w.flushed + w.align) {
+    if (!(NVCOMP_LZW_ABLATE_EXEC & 1)) out_flush_range(w, w.flushed, a_to - w.align);
+    w.flushed = a_to - w.align;
+  }
+}
+
+/* Everything up to op_end, tail bytes included (end of the chunk, or before HBM-to-HBM copies). */
+__device__ __forceinline__ void out_flush_all(OutWindow& w, uint32_t op_end)
+{
+  if (op_end > w.flushed) {
+    out_flush_range(w, w.flushed, op_end);
+    w.flushed = op_end;
+  }
+}
+
 /* ---- LDS copies ------------------------------------------------------------ */
 
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p)
@@ -412,6 +462,13 @@ __device__ __forceinline__ uint32_t steps_for(bool participates, uint32_t len)
   }
   return wave::ballot(participates && len > 8) ? 4u : 2u;
 }
+
+/* Note on alignment: a ds_read_b32 / ds_write_b32 with any misaligned lane serialises the wave instruction
+ * on gfx950 (64 cycles instead of 4, scripts/microbench/lds_unaligned.hip). A variant of the copies below
+ * that reads aligned dwords, realigns with v_alignbyte_b32 and writes aligned dwords + head/tail bytes
+ * halved the LDS busy time but added 48 % VALU instructions and was 13 % slower (profiles/
+ * r01_exec_ablation.json): the decoder is bound by instruction issue, not by the LDS pipe, so the
+ * misaligned dword moves stay. The token chase, which reads the ring with uniform phase, uses aligned reads. */
 
 /* Per-lane copy of len (4..32) bytes in `steps` dword moves whose offsets are
  * clamped to len-4: the last moves simply repeat the final dword, so there is no
@@ -561,10 +618,10 @@ __device__ __forceinline__ uint32_t execute_window_batch(
   /* ---- far matches: sources older than the window, read from HBM ---- */
   const uint32_t match_src = match_dst - s.match_off;
   const bool is_near = my_match != 0 && match_src >= ow.valid_lo;
-  const bool far_lane = my_match >= 4 && !is_near && my_match <= kMatchShort && match_src + my_match <= op;
-  uint32_t far_data[8];
+  const bool far_lane = my_match >= 4 && !is_near && my_match <= kMatchShort && match_src + my_match <= ow.flushed;
+  uint32_t far_data[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const uint32_t far_steps = steps_for(far_lane, my_match);
-  if (far_lane) {
+  if (far_lane && !(NVCOMP_LZW_ABLATE_EXEC & 2)) {
 #ifdef NVCOMP_LZW_FAR_ABLATE /* profiling builds only (wrong output): far reads folded onto the chunk's first KiB */
     const uint8_t* src = ow.out + (match_src & 1023u);
 #else
@@ -580,7 +637,7 @@ __device__ __forceinline__ uint32_t execute_window_batch(
   }
 
   /* ---- literals ---- */
-  {
+  if (!(NVCOMP_LZW_ABLATE_EXEC & 4)) {
     const bool resident = in_resident(ir, s.lit_src, s.lit_src + my_lit);
     const bool lit_lane = my_lit >= 4 && my_lit <= kLitShort && resident;
     const bool lit_tiny = my_lit != 0 && my_lit < 4 && resident;
@@ -632,7 +689,7 @@ __device__ __forceinline__ uint32_t execute_window_batch(
 
   LZW_T(6);
   /* ---- far match data into the window ---- */
-  if (far_lane) {
+  if (far_lane && !(NVCOMP_LZW_ABLATE_EXEC & 16)) {
     uint8_t* dst = out_at(ow, match_dst);
     if (far_steps == 2) {
       store_dwords_clamped<2>(dst, far_data, my_match);
@@ -648,7 +705,7 @@ __device__ __forceinline__ uint32_t execute_window_batch(
   /* ---- remaining matches, oldest first: multi-round resolution in LDS ---- */
   {
     const bool near_lane = is_near && my_match >= 4 && my_match <= kMatchShort && s.match_off >= 4;
-    uint64_t pending = wave::ballot(my_match != 0 && !far_lane);
+    uint64_t pending = (NVCOMP_LZW_ABLATE_EXEC & 8) ? 0ull : wave::ballot(my_match != 0 && !far_lane);
     const uint64_t near_mask = wave::ballot(near_lane);
     const uint64_t lane_bit = 1ull << lane;
     LZ_STAT("match_far_lanes", wave::popc64(wave::ballot(far_lane)));
@@ -665,10 +722,9 @@ __device__ __forceinline__ uint32_t execute_window_batch(
         if (fsrc >= ow.valid_lo) {
           lds_match_copy(out_at(ow, hw), foff, flen);
         } else {
-          /* Source starts behind the window. Output before op is in HBM (flushed);
-           * hw >= op, so at most the first min(flen, op - fsrc) <= foff source bytes
-           * come from HBM and everything after them is already in the window. */
-          const uint32_t n_hbm = fsrc + flen <= op ? flen : op - fsrc;
+          /* Source starts behind the window: bytes below valid_lo come from HBM (they were flushed
+           * before the window let go of them), everything from valid_lo on is in the window. */
+          const uint32_t n_hbm = fsrc + flen <= ow.valid_lo ? flen : ow.valid_lo - fsrc;
           copy_to_lds(out_at(ow, hw), ow.out + fsrc, n_hbm);
           wave::sync();
           if (n_hbm < flen) {
@@ -699,7 +755,7 @@ __device__ __forceinline__ uint32_t execute_window_batch(
   }
 
   LZW_T(8);
-  out_flush(ow, op, op + total);
+  out_flush(ow, op + total);
   LZW_T(9);
   wave::sync(); /* later far reads of this wave must see the flushed bytes */
   op += total;

@@ -210,6 +210,12 @@ __device__ __forceinline__ uint32_t popc64(uint64_t m)
   return (uint32_t)__builtin_popcountll(m);
 }
 
+/* Bytes [shift, shift + 4) of the 8-byte value hi:lo, shift in 0..3 (v_alignbyte_b32). */
+__device__ __forceinline__ uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t shift)
+{
+  return __builtin_amdgcn_alignbyte(hi, lo, shift);
+}
+
 /* Number of set bits of m below the calling lane (v_mbcnt_lo/hi). */
 __device__ __forceinline__ uint32_t prefix_popc(uint64_t m)
 {

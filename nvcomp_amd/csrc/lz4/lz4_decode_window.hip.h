@@ -157,7 +157,22 @@ __device__ __forceinline__ uint32_t chase(Chase& c, const lzw::InRing& r, uint32
 #if NVCOMP_LZW_PCHASE
 struct DeltaFn
 {
+  /* a delta looks at most this far past its position: token, 2 length bytes, 15 + 254 literals, offset, length byte */
+  static constexpr uint32_t kReach = 280;
   __device__ __forceinline__ uint32_t operator()(const lzw::InRing& r, uint32_t p) const { return token_delta(r, p); }
+  /* interior window: `w` = the stream bytes from p on (token in bits 0-7, the byte behind it in 8-15) */
+  __device__ __forceinline__ uint32_t fast(const lzw::InRing& r, uint32_t p, uint64_t w) const
+  {
+    const uint32_t t = (uint32_t)w & 0xffu;
+    const uint32_t e1 = (uint32_t)(w >> 8) & 0xffu;
+    const uint32_t lit_code = t >> 4;
+    const bool lit_ext = lit_code == 15;
+    const uint32_t d0 = 3 + lit_code + (lit_ext ? e1 + 1u : 0u); /* to the byte a match-length extension would use */
+    const bool m_ext = (t & 15u) == 15u;
+    const uint32_t e2 = r.ring[(p + d0) & (lzw::kInRing - 1)];
+    const bool unknown = (lit_ext && e1 == 255) || (m_ext && e2 == 255);
+    return unknown ? kUnknown : d0 + (m_ext ? 1u : 0u);
+  }
 };
 struct SlowFn
 {
@@ -305,6 +320,8 @@ __device__ __forceinline__ uint32_t decode_chunk(
           return 0;
         }
       }
+      lzw::out_flush_all(ow, op); /* the HBM-to-HBM copies below read what the window still held back */
+      wave::sync();
       lz::wave_copy(out + op, ir.base + lsrc, llen);
       wave::sync();
       if (mlen) {
@@ -313,12 +330,14 @@ __device__ __forceinline__ uint32_t decode_chunk(
       op += llen + mlen;
       ow.wbase = op & ~15u;
       ow.valid_lo = op;
+      ow.flushed = op;
       take = 1;
     }
     /* drop the executed sequences, keep the rest for the next round */
     seqpos = wave::shuffle(seqpos, (lane + take) & 63u);
     count -= take;
   }
+  lzw::out_flush_all(ow, op);
   return op;
 }
 

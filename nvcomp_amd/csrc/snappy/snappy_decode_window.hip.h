@@ -33,7 +33,9 @@ __device__ __forceinline__ uint32_t tag_delta(const lzw::InRing& r, uint32_t p)
   const uint8_t* ring = r.ring;
   const uint32_t m = lzw::kInRing - 1;
   const uint32_t t = ring[p & m];
-  const uint32_t w = lzw::ld32(ring + ((p + 1) & m));
+  /* the 4 bytes behind the tag from two aligned dwords (a misaligned ds_read_b32 costs 16x) */
+  const uint32_t fa = (p + 1) & ~3u;
+  const uint32_t w = wave::align_bytes(*(const uint32_t*)(ring + ((fa + 4) & m)), *(const uint32_t*)(ring + (fa & m)), (p + 1) & 3u);
   const uint32_t kind = t & 3u;
   const uint32_t code = t >> 2;
   const uint32_t nb = code >= 60 ? code - 59 : 0u; /* bytes of an explicit literal length */
@@ -137,7 +139,22 @@ __device__ __forceinline__ uint32_t chase(Chase& c, const lzw::InRing& r, uint32
 #if NVCOMP_LZW_PCHASE
 struct DeltaFn
 {
+  static constexpr uint32_t kReach = 8; /* a delta looks at the tag and the 4 bytes behind it */
   __device__ __forceinline__ uint32_t operator()(const lzw::InRing& r, uint32_t p) const { return tag_delta(r, p); }
+  /* interior window: `w` = the stream bytes from p on (tag in bits 0-7, a literal's length field in 8-39) */
+  __device__ __forceinline__ uint32_t fast(const lzw::InRing&, uint32_t, uint64_t w) const
+  {
+    const uint32_t t = (uint32_t)w & 0xffu;
+    const uint32_t field = (uint32_t)(w >> 8);
+    const uint32_t kind = t & 3u;
+    const uint32_t code = t >> 2;
+    const uint32_t nb = code >= 60 ? code - 59 : 0u;
+    const uint32_t ext = nb == 4 ? field : (field & ((1u << (8 * nb)) - 1u));
+    const uint32_t lit_delta = 2 + nb + (nb ? ext : code);
+    const uint32_t copy_delta = kind == 3 ? 5u : kind + 1;
+    const bool unknown = kind == 0 && nb && ext >= 0x7fffff00u;
+    return unknown ? kUnknown : (kind == 0 ? lit_delta : copy_delta);
+  }
 };
 struct SlowFn
 {
@@ -288,6 +305,8 @@ __device__ __forceinline__ uint32_t decode_chunk(
           return 0;
         }
       }
+      lzw::out_flush_all(ow, op); /* the HBM-to-HBM copies below read what the window still held back */
+      wave::sync();
       lz::wave_copy(out + op, ir.base + lsrc, llen);
       wave::sync();
       if (mlen) {
@@ -296,6 +315,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
       op += llen + mlen;
       ow.wbase = op & ~15u;
       ow.valid_lo = op;
+      ow.flushed = op;
       take = 1;
     }
     seqpos = wave::shuffle(seqpos, (lane + take) & 63u);
@@ -305,6 +325,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
     err |= lz::kErrInput;
     return 0;
   }
+  lzw::out_flush_all(ow, op);
   return op;
 }
 

@@ -166,6 +166,10 @@ inline void sync() { emu::wave_rendezvous(kSync, 0, 0); }
 
 inline uint32_t ctz64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
 inline uint32_t popc64(uint64_t m) { return (uint32_t)__builtin_popcountll(m); }
+inline uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t shift)
+{
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (shift & 3u)));
+}
 inline uint32_t prefix_popc(uint64_t m)
 {
   const uint32_t l = (uint32_t)lane_id();
