@@ -58,6 +58,9 @@ constexpr uint32_t kInLds = kInRing + 16; /* first 16 bytes mirrored after the e
 #ifndef NVCOMP_LZW_ABLATE_EXEC
 #define NVCOMP_LZW_ABLATE_EXEC 0
 #endif
+#ifndef NVCOMP_LZW_FAR_ALIGNED
+#define NVCOMP_LZW_FAR_ALIGNED 1 /* far-match data enters the window with aligned LDS accesses only */
+#endif
 #ifndef NVCOMP_LZW_PCHASE
 #define NVCOMP_LZW_PCHASE 1 /* 1: jump-table token chase (below); 0: the serial v_readlane walk */
 #endif
@@ -509,6 +512,55 @@ __device__ __forceinline__ void store_dwords_clamped(uint8_t* dst, const uint32_
   }
 }
 
+/* Far-match data (registers) into the window with aligned accesses only: dst sits h = 1..4 bytes into the
+ * aligned frame that starts at dst - h (h = 4: dst itself is aligned). d[] = the match's sequential dwords,
+ * l4 = its last 4 bytes. Up to 3 head bytes, whole aligned dwords, up to 3 tail bytes. */
+template <uint32_t STEPS>
+__device__ __forceinline__ void far_store_aligned(uint8_t* dst, const uint32_t (&d)[8], uint32_t l4, uint32_t len, bool on)
+{
+  const uint32_t a = (uint32_t)((uintptr_t)dst & 3u);
+  const uint32_t h = a ? a : 4u;
+  uint8_t* frame = dst - h;
+  const uint32_t end = on ? h + len : 0u; /* frame bytes [h, end) */
+  const uint32_t sh = 4u - h;
+  const uint32_t v0 = wave::align_bytes(d[0], 0u, sh);
+#pragma unroll
+  for (uint32_t b = 1; b < 4; ++b) {
+    if (b >= h && b < end) {
+      frame[b] = (uint8_t)(v0 >> (8 * b));
+    }
+  }
+#pragma unroll
+  for (uint32_t j = 1; j <= STEPS; ++j) {
+    const uint32_t v = wave::align_bytes(j < STEPS ? d[j < 8 ? j : 7] : 0u, d[j - 1], sh);
+    if (4 * j + 4 <= end) {
+      *(uint32_t*)(frame + 4 * j) = v;
+    }
+  }
+  const uint32_t tc = end & 3u;
+  uint8_t* tp = frame + (end & ~3u);
+  const uint32_t tv = l4 >> (8 * ((4u - tc) & 3u));
+#pragma unroll
+  for (uint32_t b = 0; b < 3; ++b) {
+    if (b < tc) {
+      tp[b] = (uint8_t)(tv >> (8 * b));
+    }
+  }
+}
+
+/* sequential (unclamped) dwords of a far match plus its last 4 bytes; reads up to 3 bytes past the match */
+template <uint32_t STEPS>
+__device__ __forceinline__ void far_load_seq(uint32_t (&buf)[8], uint32_t& l4, const uint8_t* src, uint32_t len)
+{
+#pragma unroll
+  for (uint32_t i = 0; i < STEPS; ++i) {
+    if (4 * i < len) {
+      buf[i] = wave::gload_u32(src + 4 * i);
+    }
+  }
+  l4 = wave::gload_u32(src + len - 4);
+}
+
 /* 1..3 byte runs (Snappy copies, short literal runs). */
 __device__ __forceinline__ void copy_tiny(uint8_t* dst, const uint8_t* src, uint32_t len)
 {
@@ -618,7 +670,13 @@ __device__ __forceinline__ uint32_t execute_window_batch(
   /* ---- far matches: sources older than the window, read from HBM ---- */
   const uint32_t match_src = match_dst - s.match_off;
   const bool is_near = my_match != 0 && match_src >= ow.valid_lo;
+#if NVCOMP_LZW_FAR_ALIGNED
+  const bool far_lane = my_match >= 4 && !is_near && my_match <= kMatchShort && match_src + my_match <= ow.flushed
+                        && (uint64_t)match_src + my_match + 3 <= out_cap; /* the dword loads may run 3 bytes past the match */
+  uint32_t far_l4 = 0;
+#else
   const bool far_lane = my_match >= 4 && !is_near && my_match <= kMatchShort && match_src + my_match <= ow.flushed;
+#endif
   uint32_t far_data[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const uint32_t far_steps = steps_for(far_lane, my_match);
   if (far_lane && !(NVCOMP_LZW_ABLATE_EXEC & 2)) {
@@ -627,6 +685,15 @@ __device__ __forceinline__ uint32_t execute_window_batch(
 #else
     const uint8_t* src = ow.out + match_src;
 #endif
+#if NVCOMP_LZW_FAR_ALIGNED
+    if (far_steps == 2) {
+      far_load_seq<2>(far_data, far_l4, src, my_match);
+    } else if (far_steps == 4) {
+      far_load_seq<4>(far_data, far_l4, src, my_match);
+    } else {
+      far_load_seq<8>(far_data, far_l4, src, my_match);
+    }
+#else
     if (far_steps == 2) {
       load_dwords_clamped<2>(far_data, src, my_match);
     } else if (far_steps == 4) {
@@ -634,6 +701,7 @@ __device__ __forceinline__ uint32_t execute_window_batch(
     } else {
       load_dwords_clamped<8>(far_data, src, my_match);
     }
+#endif
   }
 
   /* ---- literals ---- */
@@ -689,6 +757,18 @@ __device__ __forceinline__ uint32_t execute_window_batch(
 
   LZW_T(6);
   /* ---- far match data into the window ---- */
+#if NVCOMP_LZW_FAR_ALIGNED
+  if (wave::ballot(far_lane) && !(NVCOMP_LZW_ABLATE_EXEC & 16)) {
+    uint8_t* dst = out_at(ow, far_lane ? match_dst : ow.wbase);
+    if (far_steps == 2) {
+      far_store_aligned<2>(dst, far_data, far_l4, my_match, far_lane);
+    } else if (far_steps == 4) {
+      far_store_aligned<4>(dst, far_data, far_l4, my_match, far_lane);
+    } else {
+      far_store_aligned<8>(dst, far_data, far_l4, my_match, far_lane);
+    }
+  }
+#else
   if (far_lane && !(NVCOMP_LZW_ABLATE_EXEC & 16)) {
     uint8_t* dst = out_at(ow, match_dst);
     if (far_steps == 2) {
@@ -699,6 +779,7 @@ __device__ __forceinline__ uint32_t execute_window_batch(
       store_dwords_clamped<8>(dst, far_data, my_match);
     }
   }
+#endif
   wave::sync();
   LZW_T(7);
 
