@@ -16,6 +16,17 @@ namespace snappyw {
  * pass (chunk sizes are < 2^28, so position + kUnknown never looks like a position). */
 constexpr uint32_t kUnknown = 1u << 28;
 
+/* A token of the chase is one copy element, or a literal element together with the copy element that
+ * follows it (when the literal element is at most kFuseMax bytes long and a copy does follow): the
+ * executor takes "literal run, then match" per lane, so fusing the two halves the sequences of the common
+ * literal-copy alternation. Chase, scalar fallback and parse apply the same rule. */
+constexpr uint32_t kFuseMax = 256;
+
+__device__ __forceinline__ uint32_t copy_size(uint32_t kind) /* kind 1..3 */
+{
+  return kind == 3 ? 5u : kind + 1;
+}
+
 #if !NVCOMP_LZW_PCHASE
 struct Chase
 {
@@ -43,8 +54,20 @@ __device__ __forceinline__ uint32_t tag_delta(const lzw::InRing& r, uint32_t p)
   const uint32_t lit_len = (nb ? ext : code); /* length - 1 */
   const uint32_t lit_delta = 1 + nb + lit_len + 1;
   const uint32_t copy_delta = kind == 3 ? 5u : kind + 1;
-  const bool unknown = p < r.lo || p + 5 > r.hi || p >= r.vend || (kind == 0 && nb && ext >= 0x7fffff00u);
-  return unknown ? kUnknown : (kind == 0 ? lit_delta : copy_delta);
+  bool unknown = p < r.lo || p + 5 > r.hi || p >= r.vend || (kind == 0 && nb && ext >= 0x7fffff00u);
+  uint32_t delta = kind == 0 ? lit_delta : copy_delta;
+  if (!unknown && kind == 0 && lit_delta <= kFuseMax) {
+    const uint32_t p2 = p + lit_delta;
+    if (p2 < r.vend) {
+      if (p2 >= r.hi) {
+        unknown = true;
+      } else {
+        const uint32_t k2 = ring[p2 & m] & 3u;
+        delta += k2 ? copy_size(k2) : 0u;
+      }
+    }
+  }
+  return unknown ? kUnknown : delta;
 }
 
 #if !NVCOMP_LZW_PCHASE
@@ -66,7 +89,7 @@ __device__ __forceinline__ uint32_t chase_slow_next(const lzw::InRing& r, uint32
   const uint32_t t = lzw::in_byte_uniform(r, q);
   const uint32_t kind = t & 3u;
   if (kind != 0) {
-    return q + (kind == 3 ? 5u : kind + 1);
+    return q + copy_size(kind);
   }
   uint32_t len = t >> 2;
   uint32_t pos = q + 1;
@@ -84,7 +107,12 @@ __device__ __forceinline__ uint32_t chase_slow_next(const lzw::InRing& r, uint32
   if (len >= vend - pos) {
     return vend + 1;
   }
-  return pos + len + 1;
+  const uint32_t p2 = pos + len + 1;
+  if (p2 - q <= kFuseMax && p2 < vend) {
+    const uint32_t k2 = lzw::in_byte_uniform(r, p2) & 3u;
+    return p2 + (k2 ? copy_size(k2) : 0u);
+  }
+  return p2;
 }
 
 #if !NVCOMP_LZW_PCHASE
@@ -139,10 +167,10 @@ __device__ __forceinline__ uint32_t chase(Chase& c, const lzw::InRing& r, uint32
 #if NVCOMP_LZW_PCHASE
 struct DeltaFn
 {
-  static constexpr uint32_t kReach = 8; /* a delta looks at the tag and the 4 bytes behind it */
+  static constexpr uint32_t kReach = 8 + kFuseMax + 8; /* tag + length field, and the tag behind a fusable literal */
   __device__ __forceinline__ uint32_t operator()(const lzw::InRing& r, uint32_t p) const { return tag_delta(r, p); }
   /* interior window: `w` = the stream bytes from p on (tag in bits 0-7, a literal's length field in 8-39) */
-  __device__ __forceinline__ uint32_t fast(const lzw::InRing&, uint32_t, uint64_t w) const
+  __device__ __forceinline__ uint32_t fast(const lzw::InRing& r, uint32_t p, uint64_t w) const
   {
     const uint32_t t = (uint32_t)w & 0xffu;
     const uint32_t field = (uint32_t)(w >> 8);
@@ -153,7 +181,9 @@ struct DeltaFn
     const uint32_t lit_delta = 2 + nb + (nb ? ext : code);
     const uint32_t copy_delta = kind == 3 ? 5u : kind + 1;
     const bool unknown = kind == 0 && nb && ext >= 0x7fffff00u;
-    return unknown ? kUnknown : (kind == 0 ? lit_delta : copy_delta);
+    const uint32_t k2 = r.ring[(p + lit_delta) & (lzw::kInRing - 1)] & 3u; /* harmless when not a literal */
+    const uint32_t fused = lit_delta <= kFuseMax && k2 ? copy_size(k2) : 0u;
+    return unknown ? kUnknown : (kind == 0 ? lit_delta + fused : copy_delta);
   }
 };
 struct SlowFn
@@ -173,15 +203,14 @@ __device__ __forceinline__ void parse(const lzw::InRing& r, uint32_t p, bool act
     return;
   }
   const uint32_t vend = r.vend;
-  const uint32_t t = lzw::in_byte(r, p);
-  const uint32_t kind = t & 3u;
+  uint32_t t = lzw::in_byte(r, p);
+  uint32_t kind = t & 3u;
   uint32_t pos = p + 1;
-  const uint32_t avail = vend - pos;
   if (kind == 0) {
     uint32_t len = t >> 2;
     if (len >= 60) {
       const uint32_t nb = len - 59;
-      if (avail < nb) {
+      if (vend - pos < nb) {
         bad = true;
         return;
       }
@@ -197,10 +226,20 @@ __device__ __forceinline__ void parse(const lzw::InRing& r, uint32_t p, bool act
     }
     s.lit_src = pos;
     s.lit_len = len + 1;
-    return;
+    pos += len + 1;
+    /* the copy element behind a short literal element belongs to the same token (kFuseMax rule) */
+    if (pos - p > kFuseMax || pos >= vend) {
+      return;
+    }
+    t = lzw::in_byte(r, pos);
+    kind = t & 3u;
+    if (kind == 0) {
+      return;
+    }
+    ++pos;
   }
   const uint32_t need = kind == 3 ? 4u : kind;
-  if (avail < need) {
+  if (vend - pos < need) {
     bad = true;
     return;
   }
