@@ -50,14 +50,26 @@ def main():
     pmc["_note"] = ("per launch of lz4_decompress_window_kernel<checked>, 16384 chunks x 64 KiB (1 GiB out, 471 MB in); "
                     "separate rocprofv3 --pmc passes; FETCH_SIZE/WRITE_SIZE in KB")
     json.dump(pmc, open(os.path.join(dst, prefix + "_pmc.json"), "w"), indent=1)
-    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc and "bench_lz4" in bench:
         fetch, write = pmc["FETCH_SIZE"] * 1024, pmc["WRITE_SIZE"] * 1024
+        comp = bench["bench_lz4"]["config"]["compressed_bytes_per_gpu"]
+        # calibration (scripts/gpu_calib.sh, session calib1): FETCH_SIZE counts the 16 B/lane stream loads at
+        # 0.516x their true bytes (the guide's gfx950 1/2 factor); the other half of the stream is added back.
+        traffic = fetch + 0.5 * comp + write
         json.dump({
             "algo": "lz4", "dataset": "silesia_style", "chunks_per_gpu": 16384,
-            "hbm_bytes_per_launch": int(fetch + write), "fetch_bytes": int(fetch), "write_bytes": int(write),
-            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB units) of lz4_decompress_window_kernel, "
-                    f"session {tag}; FETCH_SIZE is NOT doubled: the 2x gfx950 correction of MI355X_MICROARCH.md applies to "
-                    "wide coalesced streaming reads, this kernel reads mostly scattered 4-byte gathers and 16-byte lane loads",
+            "hbm_bytes_per_launch": int(traffic), "fetch_bytes_counted": int(fetch), "write_bytes_counted": int(write),
+            "calibration": {
+                "noise_dataset": {"input_stream_KB": 1052700, "FETCH_SIZE_KB": 543117.5, "counted_over_true": 0.516,
+                                  "meaning": "incompressible chunks: the kernel reads only the compressed stream (16 B/lane ring loads): "
+                                             "FETCH_SIZE reports 1/2 of a known byte count, as MI355X_MICROARCH.md 'HBM' says for wide coalesced reads"},
+                "far_ablated_build": {"FETCH_SIZE_KB": 275313.27,
+                                      "meaning": "-DNVCOMP_LZW_FAR_ABLATE: far-match reads folded onto L2-resident lines; what remains is the "
+                                                 "stream (471 MB true, counted at 1/2) plus the pointer arrays"}},
+            "note": "traffic = FETCH_SIZE as counted + the uncounted half of the compressed stream (0.5 x C) + WRITE_SIZE; separate "
+                    f"rocprofv3 --pmc passes, KB units, session {tag}. The far-match gather part of FETCH_SIZE (about 3.4 GB for ~85 M "
+                    "matches of ~9 bytes) is tallied at 64 B per request and is uncalibrated: if every request is a 128-B line fill the true "
+                    "figure is up to 8.7 GB. WRITE_SIZE matches the algorithmic 1.07 GB plus partial-line effects.",
         }, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
     print("collected", sorted(os.listdir(dst)))
 
