@@ -49,6 +49,13 @@ __device__ __forceinline__ uint32_t ld_u32(const uint8_t* p)
   return v;
 }
 
+__device__ __forceinline__ wave::u32x4 ld_u32x4(const uint8_t* p) /* any alignment */
+{
+  wave::u32x4 v;
+  __builtin_memcpy(&v, p, 16);
+  return v;
+}
+
 __device__ __forceinline__ void st_u32(uint8_t* p, uint32_t v)
 {
   __builtin_memcpy(p, &v, 4);

@@ -130,17 +130,31 @@ __device__ __forceinline__ uint32_t encode_chunk(
         }
       }
 
-      /* ---- every hit lane measures its own match (dword compares, capped) ---- */
+      /* ---- every hit lane measures its own match (16-byte compares, capped): the candidate side of these
+       * loads is scattered, one L1 tag lookup per lane and load, so fewer and wider loads is what counts ---- */
       uint32_t mlen = 0;
       if (found) {
         const uint32_t room = match_end - pos; /* >= 4 for an eligible position */
         uint32_t cap = room < kLaneCap ? room : kLaneCap;
         mlen = kMinMatch;
+        while (mlen + 16 <= cap) {
+          const wave::u32x4 a = lz::ld_u32x4(src + pos + mlen);
+          const wave::u32x4 b = lz::ld_u32x4(src + cand + mlen);
+          const uint32_t x0 = a.x ^ b.x, x1 = a.y ^ b.y, x2 = a.z ^ b.z, x3 = a.w ^ b.w;
+          if ((x0 | x1 | x2 | x3) != 0) {
+            const uint32_t first = x0 ? 0u : x1 ? 1u : x2 ? 2u : 3u;
+            const uint32_t x = x0 ? x0 : x1 ? x1 : x2 ? x2 : x3;
+            mlen += 4 * first + ((uint32_t)__builtin_ctz(x) >> 3);
+            cap = 0; /* stop */
+            break;
+          }
+          mlen += 16;
+        }
         while (mlen + 4 <= cap) {
           const uint32_t x = lz::ld_u32(src + pos + mlen) ^ lz::ld_u32(src + cand + mlen);
           if (x != 0) {
             mlen += (uint32_t)__builtin_ctz(x) >> 3;
-            cap = 0; /* stop */
+            cap = 0;
             break;
           }
           mlen += 4;
