@@ -32,7 +32,10 @@
 
 namespace lzm {
 
-constexpr uint32_t kHashBits = 12;
+#ifndef NVCOMP_LZM_HASH_BITS
+#define NVCOMP_LZM_HASH_BITS 12
+#endif
+constexpr uint32_t kHashBits = NVCOMP_LZM_HASH_BITS;
 constexpr uint32_t kHashSize = 1u << kHashBits;
 constexpr uint32_t kMinMatch = 4;
 constexpr uint32_t kLaneCap = 36; /* per-lane match measurement: 4 + 8 dword compares */
