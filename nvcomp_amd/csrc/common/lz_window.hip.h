@@ -27,9 +27,9 @@
 namespace lzw {
 
 /* Tunables (overridable with -D for the A/B builds of scripts/build_variants.sh). */
-/* Defaults from the MI355X sweep of profiles/r01_window_variants.json: a small
- * window at full occupancy (8 waves/SIMD, 4 KiB of LDS per wave) beats a large
- * one -- the decoder is instruction-issue bound, not LDS- or HBM-bound. */
+/* Defaults from the MI355X sweeps of profiles/r01_window_variants.json and
+ * r01_pchase_variants.json: a small window at 6-8 waves/SIMD beats a large one -- the decoder
+ * is instruction-issue bound, not LDS- or HBM-bound; 6, 7 and 8 waves/SIMD measure the same. */
 #ifndef NVCOMP_LZW_OUTWIN
 #define NVCOMP_LZW_OUTWIN 2048
 #endif
