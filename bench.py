@@ -44,11 +44,15 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--algo", choices=["lz4", "snappy"], default="lz4")
+    p.add_argument("--algo", choices=["lz4", "snappy", "cascaded", "bitcomp", "ans"], default="lz4",
+                   help="lz4 is the headline (BASELINE.json configs[1]); cascaded/bitcomp/ans are this library's own stream "
+                        "formats: their inputs are made by the HIP compressor (checked against the CPU model) outside the timed region")
+    p.add_argument("--opts", default="", help="cascaded: chunk_size,type,num_RLEs,num_deltas,use_bp; bitcomp: algo,type")
     p.add_argument("--mib-per-gpu", type=int, default=1024, help="uncompressed MiB decoded per GPU per step")
     p.add_argument("--unique-mib", type=int, default=64, help="unique MiB generated + CPU-compressed per rank")
     p.add_argument("--unique-kib", type=int, default=0, help="(tests) unique KiB per rank, overrides --unique-mib/--mib-per-gpu")
-    p.add_argument("--dataset", default="silesia_style")
+    p.add_argument("--dataset", default=None,
+                   help="nvcomp_amd.datasets generator; default silesia_style (int32 for cascaded / bitcomp: BASELINE.json configs[3])")
     p.add_argument("--producer", choices=["hc", "fast", "port"], default="hc",
                    help="CPU compressor making the inputs: liblz4 HC-12 / liblz4 default / oracle port")
     p.add_argument("--unchecked", action="store_true", help="statuses=NULL fast path (reported separately)")
@@ -210,8 +214,14 @@ def run_case(args, ctx):
     from nvcomp_amd.batched import DeviceBatch
 
     rank, world, lib, dev, rt = ctx["rank"], ctx["world"], ctx["lib"], ctx["dev"], ctx["rt"]
-    fmt = "LZ4" if args.algo == "lz4" else "Snappy"
-    codec = nvcomp_amd.BatchedCodec(lib, dev, fmt)
+    fmt = {"lz4": "LZ4", "snappy": "Snappy", "cascaded": "Cascaded", "bitcomp": "Bitcomp", "ans": "ANS"}[args.algo]
+    own_format = args.algo in OWN_FORMAT_OPTS
+    opts = None
+    if own_format:
+        opts = tuple(int(x) for x in args.opts.split(",")) if args.opts else OWN_FORMAT_OPTS[args.algo]
+    if args.dataset is None:
+        args.dataset = "int32" if args.algo in ("cascaded", "bitcomp") else "silesia_style"
+    codec = nvcomp_amd.BatchedCodec(lib, dev, fmt, opts)
     threads = len(os.sched_getaffinity(0))
 
     # ---- build the batch (untimed) ----
@@ -222,15 +232,24 @@ def run_case(args, ctx):
     gen = getattr(datasets, args.dataset) if hasattr(datasets, args.dataset) else datasets.CLASSES[args.dataset]
     data = gen(unique, rank)
     chunks = datasets.split_chunks(data, CHUNK)
-    comp, producer = cpu_compress(oracle, args.algo, chunks, args.producer, threads)
+    if own_format:
+        comp, producer = own_format_compress(oracle, codec, args.algo, opts, chunks)
+    else:
+        comp, producer = cpu_compress(oracle, args.algo, chunks, args.producer, threads)
     n_unique = len(chunks)
     replicas = 1 if args.unique_kib else max(1, (args.mib_per_gpu << 20) // unique)
     n = n_unique * replicas
     comp_sizes = np.array([c.size for c in comp], dtype=np.uint64)
+    if own_format:  # Cascaded wants 4-byte aligned compressed chunks: pack on 8-byte boundaries
+        padded = [np.concatenate([c, np.zeros((-c.size) % 8, dtype=np.uint8)]) for c in comp]
+    else:  # tight-packed, unaligned (examples/BatchData.h:97-103)
+        padded = comp
+    pad_sizes = np.array([c.size for c in padded], dtype=np.uint64)
     comp_offs = np.zeros(n_unique, dtype=np.uint64)
-    comp_offs[1:] = np.cumsum(comp_sizes)[:-1]  # tight-packed, unaligned (examples/BatchData.h:97-103)
+    comp_offs[1:] = np.cumsum(pad_sizes)[:-1]
     comp_total = int(comp_sizes.sum())
-    comp_host = np.concatenate(comp)
+    comp_host = np.concatenate(padded)
+    slab_stride = int(pad_sizes.sum())
     raw_sizes = np.array([c.size for c in chunks], dtype=np.uint64)
     raw_offs = np.arange(n_unique, dtype=np.uint64) * np.uint64(CHUNK)
 
@@ -243,7 +262,7 @@ def run_case(args, ctx):
         return (offs[None, :] + rep + np.uint64(base_ptr)).reshape(-1)
 
     comp_batch = DeviceBatch(
-        comp_slab, dev.upload(tile(comp_offs, comp_total, dev.ptr(comp_slab)).view(np.uint8)),
+        comp_slab, dev.upload(tile(comp_offs, slab_stride, dev.ptr(comp_slab)).view(np.uint8)),
         dev.upload(np.tile(comp_sizes, replicas).view(np.uint8)), None, np.tile(comp_sizes, replicas), n)
     out_batch = DeviceBatch(
         out_slab, dev.upload(tile(raw_offs, unique, dev.ptr(out_slab)).view(np.uint8)),
@@ -302,10 +321,12 @@ def run_case(args, ctx):
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u8",
+        "dtype": (f"u{8 * _WIDTH[opts[1]]}" if args.algo in ("cascaded", "bitcomp") else "u8"),
         "data": "synthetic",
         "config": {
-            "workload": f"{fmt} batched decompress, CPU-compressed 64 KiB chunks (BASELINE.json configs[1])",
+            "workload": (f"{fmt} batched decompress, 64 KiB chunks, inputs from this library's HIP compressor"
+                         + (" (BASELINE.json configs[3])" if args.algo == "cascaded" else "")) if own_format else
+                        f"{fmt} batched decompress, CPU-compressed 64 KiB chunks (BASELINE.json configs[1])",
             "dataset": args.dataset,
             "producer": producer,
             "chunk_bytes": CHUNK,
@@ -331,7 +352,7 @@ def run_case(args, ctx):
                 traffic = None
         result["roofline"] = {
             "bound": "hbm",
-            "kernel": f"{args.algo}_decompress_window_kernel",
+            "kernel": f"{args.algo}_decompress_kernel" if own_format else f"{args.algo}_decompress_window_kernel",
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
@@ -368,6 +389,9 @@ def run_case(args, ctx):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # The reference's CPU path (liblz4 / snappy decoders) on this box's host cores over a
         # bounded sample of the same chunk arrays: the unique set, best of 5.
+        if own_format:
+            result["cpu_baseline"] = own_format_cpu_baseline(oracle, args.algo, comp, chunks, threads)
+            return finish(result, args, world, rt, data)
         use_ref = oracle.have_ref()
         code = oracle.LZ4_DEC if args.algo == "lz4" else oracle.SNAPPY_DEC
         # bounded sample: the unique set repeated so that every thread gets >= 16 MiB per run
@@ -385,6 +409,10 @@ def run_case(args, ctx):
                       + ("liblz4 LZ4_decompress_safe" if (use_ref and args.algo == "lz4") else
                          "libsnappy RawUncompress" if use_ref else "oracle/ C port"),
         }
+    return finish(result, args, world, rt, data)
+
+
+def finish(result, args, world, rt, data):
     if world > 1:
         digests = [None] * world
         rt.dist.all_gather_object(digests, shard_digest(data))
@@ -393,6 +421,56 @@ def run_case(args, ctx):
         result["value"] = None
         result["data"] = "DRY RUN on the CPU emulation of the kernels: not a measurement"
     return result
+
+
+# default options of the own-format codecs (cascaded: benchmark_cascaded_chunked.cu:35-36 run with -t int)
+OWN_FORMAT_OPTS = {"cascaded": (4096, 4, 2, 1, 1), "bitcomp": (0, 4), "ans": (0,)}
+_WIDTH = [1, 1, 2, 2, 4, 4, 8, 8]
+
+
+def _own_model(oracle, algo, opts):
+    if algo == "cascaded":
+        return (lambda c: oracle.cascaded_compress(c, *opts)), oracle.cascaded_decompress
+    if algo == "bitcomp":
+        return (lambda c: oracle.bitcomp_compress(c, opts[0], _WIDTH[opts[1]])), oracle.bitcomp_decompress
+    return oracle.ans_compress, oracle.ans_decompress
+
+
+def own_format_compress(oracle, codec, algo, opts, chunks):
+    """Inputs of an own-format decode run: the HIP compressor's output (outside every timed region); the first
+    chunks must equal the CPU model's bytes and decode with it."""
+    comp = []
+    for i in range(0, len(chunks), 512):
+        comp.extend(codec.compress(chunks[i: i + 512]))
+    enc, dec = _own_model(oracle, algo, opts)
+    for c, cc in list(zip(chunks, comp))[:4]:
+        assert np.array_equal(cc, enc(c)), "HIP compressor output differs from the CPU model"
+        rc, back = dec(cc, c.size)
+        assert rc == 0 and np.array_equal(back, c)
+    return comp, f"this library's HIP {algo} compressor, opts {tuple(opts)}"
+
+
+def own_format_cpu_baseline(oracle, algo, comp, chunks, threads):
+    """The CPU model of the stream (oracle/*_ref.c: a scalar port, written for clarity) on a bounded sample."""
+    import concurrent.futures as cf
+
+    _, dec = _own_model(oracle, algo, OWN_FORMAT_OPTS[algo])
+    k = min(len(comp), 4 * threads)
+    sample = list(zip(comp[:k], chunks[:k]))
+
+    def one(item):
+        rc, out = dec(item[0], item[1].size)
+        return rc == 0 and out.size == item[1].size
+
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(max_workers=threads) as ex:  # ctypes releases the GIL inside the C model
+        ok = all(ex.map(one, sample))
+    secs = time.perf_counter() - t0
+    assert ok
+    raw = sum(c.size for c in chunks[:k])
+    return {"value": round(raw / secs / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
+            "sample": f"{raw >> 20} MiB ({k} chunks) of the same workload, one pass, oracle/{algo}_ref.c "
+                      "(scalar CPU model of this library's own stream; the reference has no CPU implementation of it)"}
 
 
 def shard_digest(data):

@@ -25,7 +25,8 @@ def main():
     dst = os.path.join(REPO, "profiles")
     os.makedirs(dst, exist_ok=True)
     bench = {}
-    for name in ("bench_lz4", "bench_lz4_unchecked", "bench_lz4_direct", "bench_lz4_serial", "bench_snappy"):
+    for name in ("bench_lz4", "bench_lz4_unchecked", "bench_lz4_direct", "bench_lz4_serial", "bench_snappy", "bench_cascaded",
+                 "bench_bitcomp", "bench_ans"):
         p = os.path.join(src, name + ".json")
         if os.path.exists(p):
             bench[name] = json.load(open(p))

@@ -40,3 +40,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_snappy" -o r -- python bench.py --algo snappy --steps 5 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/trace_snappy.log" 2>&1
 find "$OUT" -name "*.csv" -size +8M -delete
 cat "$OUT/rc.txt"; tail -3 "$OUT/pytest_gpu.log"; cat "$OUT/bench_lz4.json"
+for a in cascaded bitcomp ans; do
+  timeout 400 python bench.py --algo $a > "$OUT/bench_$a.json" 2> "$OUT/bench_$a.err"; echo "bench $a rc=$?" >> "$OUT/rc.txt"
+done
+tail -3 "$OUT/rc.txt"
