@@ -219,8 +219,6 @@ def run_case(args, ctx):
     opts = None
     if own_format:
         opts = tuple(int(x) for x in args.opts.split(",")) if args.opts else OWN_FORMAT_OPTS[args.algo]
-    if args.dataset is None:
-        args.dataset = "int32" if args.algo in ("cascaded", "bitcomp") else "silesia_style"
     codec = nvcomp_amd.BatchedCodec(lib, dev, fmt, opts)
     threads = len(os.sched_getaffinity(0))
 
@@ -604,6 +602,8 @@ def run_allgather_case(args, ctx):
 
 def main():
     args = parse_args()
+    if args.dataset is None:
+        args.dataset = "int32" if args.algo in ("cascaded", "bitcomp") else "silesia_style"
     ctx = setup_runtime(args)
     result = run_allgather_case(args, ctx) if args.allgather else run_case(args, ctx)
     if args.dry_run_emu and args.allgather:
