@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) bitcomp_decompress_kernel
   if (in_len64 > 0xffffffffull - 64) {
     err = bitcomp::kErrInput;
   } else {
-    produced = bitcomp::decode_chunk<CHECKED>(in, (uint32_t)in_len64, out, (uint32_t)cap64, err);
+    /* the stream is validated whether or not the caller wants statuses: the checks are a few scalar compares per block */
+    produced = bitcomp::decode_chunk<true>(in, (uint32_t)in_len64, out, (uint32_t)cap64, err);
   }
   if (wave::lane_id() == 0) {
     if (actual_bytes != nullptr) {

@@ -1,0 +1,79 @@
+"""Corrupted-stream fuzz for every decoder: random bit flips, byte splats, truncations and extensions of valid
+streams. A decoder may accept or reject a damaged stream, but it must never write outside the capacity it was
+given (canary bytes behind every output slot), must agree with the CPU oracle on accept/reject for the
+own-format codecs, and, when it accepts, must report a size within the capacity. The reference documents the
+same contract: invalid data yields a per-chunk status, never a crash (doc/lowlevel_c_quickstart.md:140,
+CHANGELOG.md:160-164)."""
+import numpy as np
+import pytest
+
+from nvcomp_amd import datasets
+from nvcomp_amd._lib import NvcompStatus
+
+
+def damage(rng, stream):
+    b = stream.copy()
+    kind = rng.randint(0, 6)
+    if b.size == 0:
+        return b
+    if kind == 0:  # single bit flips
+        for _ in range(int(rng.randint(1, 4))):
+            b[rng.randint(0, b.size)] ^= 1 << rng.randint(0, 8)
+    elif kind == 1:  # splat a run of random bytes
+        at = rng.randint(0, b.size)
+        n = min(int(rng.choice([1, 2, 4, 16, 64])), b.size - at)
+        b[at:at + n] = rng.randint(0, 256, size=n)
+    elif kind == 2:  # truncate
+        b = b[: rng.randint(0, b.size)]
+    elif kind == 3:  # header damage
+        b[rng.randint(0, min(16, b.size))] = rng.randint(0, 256)
+    elif kind == 4:  # 0xFF run (length-extension bytes of the LZ formats)
+        at = rng.randint(0, b.size)
+        n = min(int(rng.choice([2, 8, 300])), b.size - at)
+        b[at:at + n] = 0xFF
+    else:  # garbage appended
+        b = np.concatenate([b, rng.randint(0, 256, size=int(rng.choice([1, 7, 100]))).astype(np.uint8)])
+    return b
+
+
+def valid_streams(oracle, fmt, chunks):
+    if fmt == "LZ4":
+        return [oracle.lz4_compress(c) for c in chunks], oracle.lz4_decompress, None
+    if fmt == "Snappy":
+        return [oracle.snappy_compress(c) for c in chunks], oracle.snappy_decompress, None
+    if fmt == "Cascaded":
+        return [oracle.cascaded_compress(c, 4096, 5, 2, 1, 1) for c in chunks], oracle.cascaded_decompress, (4096, 5, 2, 1, 1)
+    if fmt == "Bitcomp":
+        return [oracle.bitcomp_compress(c, 0, 2) for c in chunks], oracle.bitcomp_decompress, (0, 3)
+    return [oracle.ans_compress(c) for c in chunks], oracle.ans_decompress, (0,)
+
+
+@pytest.mark.parametrize("fmt", ["LZ4", "Snappy", "Cascaded", "Bitcomp", "ANS"])
+def test_corrupt_streams_are_contained(backend, oracle, fmt):
+    rng = np.random.RandomState(["LZ4", "Snappy", "Cascaded", "Bitcomp", "ANS"].index(fmt) * 101 + 17)
+    n = 96 if backend.name == "gpu" else 24
+    gens = [datasets.text, datasets.int32_column, datasets.lowcard, datasets.table_rows]
+    chunks = [gens[i % 4](int(rng.choice([600, 4096, 20000, 65536])), i) for i in range(n)]
+    good, dec, opts = valid_streams(oracle, fmt, chunks)
+    bad = [damage(rng, g) for g in good]
+    caps = [c.size for c in chunks]
+    codec = backend.codec(fmt, opts)
+    align = 8 if fmt == "Cascaded" else 1
+    outs, actual, status = codec.decompress(bad, caps, comp_align=align, out_align=align)  # canaries checked inside
+    own = fmt in ("Cascaded", "Bitcomp", "ANS")
+    for i, (b, cap) in enumerate(zip(bad, caps)):
+        rc, ref = dec(b, cap)
+        if status[i] == NvcompStatus.Success:
+            assert actual[i] <= cap
+            if own or rc == 0:
+                # the own-format models are exact about validity; for LZ4/Snappy an accepted stream must decode alike
+                assert rc == 0, f"{fmt} chunk {i}: HIP decoder accepted a stream the CPU oracle rejects"
+                assert actual[i] == ref.size and np.array_equal(outs[i][: ref.size], ref)
+        else:
+            assert actual[i] == 0
+            if own:
+                assert rc != 0, f"{fmt} chunk {i}: HIP decoder rejected a stream the CPU oracle accepts"
+    if own:
+        # these decoders validate regardless of `device_statuses`; for LZ4/Snappy a NULL status array turns the
+        # bounds checks off by contract ("OOB error checking is disabled", doc/lowlevel_c_quickstart.md:140)
+        codec.decompress(bad, caps, checked=False, comp_align=align, out_align=align)
