@@ -17,8 +17,11 @@
 namespace {
 
 constexpr uint32_t kHeaderBytes = 20;
-constexpr uint32_t kFastBudget = 16 * 1024; /* LDS per wave of the first decode pass (4 waves per workgroup) */
-constexpr uint32_t kBigBudget = 64 * 1024;  /* second pass: one wave per workgroup */
+/* Decode runs three passes with growing LDS per wave; a sub-chunk's need follows from its actual stream counts
+ * (casc::decompress_sub), so compressible data is decoded by the first pass at full occupancy. */
+constexpr uint32_t kSmallBudget = 5 * 1024; /* pass 0: 4 waves per workgroup, 8 workgroups per CU */
+constexpr uint32_t kFastBudget = 16 * 1024; /* pass 1: 4 waves per workgroup */
+constexpr uint32_t kBigBudget = 64 * 1024;  /* pass 2: one wave per workgroup; also the compressor's limit */
 
 void clear_stale_error()
 {
@@ -133,8 +136,8 @@ __global__ void cascaded_compress_kernel(
   }
 }
 
-/* pass 0: every chunk whose streams fit kFastBudget of LDS; the others are flagged in
- * `todo` and decoded by pass 1 (one wave per workgroup, kBigBudget). */
+/* pass p decodes the chunks with todo == p (pass 0: all) whose streams fit its LDS budget and hands the others
+ * on by setting todo = p + 1. */
 __global__ void cascaded_decompress_kernel(
     const void* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes,
@@ -155,7 +158,7 @@ __global__ void cascaded_decompress_kernel(
     return;
   }
   const uint32_t lane = (uint32_t)wave::lane_id();
-  if (pass == 1 && wave::uniform(todo[chunk]) == 0) {
+  if (pass != 0 && wave::uniform(todo[chunk]) != pass) {
     return;
   }
   const uint8_t* src = wave::uniform_ptr((const uint8_t*)comp_ptrs[chunk]);
@@ -199,20 +202,12 @@ __global__ void cascaded_decompress_kernel(
       err = casc::kErrAlign;
       break;
     }
-    if (casc::lds_bytes_per_wave(sub, w, num_rles) > lds_per_wave) {
-      if (pass == 0) {
-        deferred = true;
-      } else {
-        err = casc::kErrInput; /* larger than anything the compressor accepts */
-      }
-      break;
-    }
     const uint32_t* table = (const uint32_t*)(src + kHeaderBytes);
     const uint8_t* payload = src + kHeaderBytes + 4 * (size_t)num_sub;
     const uint32_t pay_len = (uint32_t)(src_len - kHeaderBytes - 4 * (size_t)num_sub);
-    const Carve c = carve(lds + (size_t)wv * lds_per_wave, sub, w, num_rles);
+    uint8_t* slice = lds + (size_t)wv * lds_per_wave;
     uint32_t begin = 0;
-    for (uint32_t s = 0; s < num_sub && !err; ++s) {
+    for (uint32_t s = 0; s < num_sub && !err && !deferred; ++s) {
       const uint32_t end = wave::uniform(table[s]);
       const uint32_t off = s * sub;
       const uint32_t bytes = n_bytes - off < sub ? n_bytes - off : sub;
@@ -220,26 +215,28 @@ __global__ void cascaded_decompress_kernel(
         err = casc::kErrInput;
         break;
       }
-      bool ok;
+      uint32_t rc;
       switch (w) {
       case 1:
-        ok = casc::decompress_sub<uint8_t>(payload + begin, end - begin, dst + off, bytes, num_rles, num_deltas,
-                                           (uint8_t*)c.a, (uint8_t*)c.b, c.pool, c.marks, c.meta);
+        rc = casc::decompress_sub<uint8_t>(payload + begin, end - begin, dst + off, bytes, num_rles, num_deltas, slice, lds_per_wave);
         break;
       case 2:
-        ok = casc::decompress_sub<uint16_t>(payload + begin, end - begin, dst + off, bytes, num_rles, num_deltas,
-                                            (uint16_t*)c.a, (uint16_t*)c.b, c.pool, c.marks, c.meta);
+        rc = casc::decompress_sub<uint16_t>(payload + begin, end - begin, dst + off, bytes, num_rles, num_deltas, slice, lds_per_wave);
         break;
       case 4:
-        ok = casc::decompress_sub<uint32_t>(payload + begin, end - begin, dst + off, bytes, num_rles, num_deltas,
-                                            (uint32_t*)c.a, (uint32_t*)c.b, c.pool, c.marks, c.meta);
+        rc = casc::decompress_sub<uint32_t>(payload + begin, end - begin, dst + off, bytes, num_rles, num_deltas, slice, lds_per_wave);
         break;
       default:
-        ok = casc::decompress_sub<uint64_t>(payload + begin, end - begin, dst + off, bytes, num_rles, num_deltas,
-                                            (uint64_t*)c.a, (uint64_t*)c.b, c.pool, c.marks, c.meta);
+        rc = casc::decompress_sub<uint64_t>(payload + begin, end - begin, dst + off, bytes, num_rles, num_deltas, slice, lds_per_wave);
         break;
       }
-      if (!ok) {
+      if (rc == casc::kSubNeedLds) {
+        if (pass < 2) {
+          deferred = true; /* whatever was already written is decoded again by the next pass */
+        } else {
+          err = casc::kErrInput; /* larger than anything the compressor accepts */
+        }
+      } else if (rc != casc::kSubOk) {
         err = casc::kErrInput;
       }
       begin = end;
@@ -248,8 +245,8 @@ __global__ void cascaded_decompress_kernel(
     produced = n_bytes;
   } while (false);
   if (lane == 0) {
-    if (pass == 0) {
-      todo[chunk] = deferred ? 1u : 0u;
+    if (pass == 0 || deferred) {
+      todo[chunk] = deferred ? pass + 1 : 0u;
     }
     if (!deferred) {
       if (actual_bytes != nullptr) {
@@ -395,13 +392,17 @@ nvcompStatus_t nvcompBatchedCascadedDecompressAsync(
   }
   uint32_t* todo = (uint32_t*)device_temp_ptr;
   clear_stale_error();
-  hipLaunchKernelGGL(cascaded_decompress_kernel, dim3((unsigned)((batch_size + 3) / 4)), dim3(256), 4 * kFastBudget,
+  hipLaunchKernelGGL(cascaded_decompress_kernel, dim3((unsigned)((batch_size + 3) / 4)), dim3(256), 4 * kSmallBudget,
                      stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
                      device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 0u,
+                     kSmallBudget, 4u);
+  hipLaunchKernelGGL(cascaded_decompress_kernel, dim3((unsigned)((batch_size + 3) / 4)), dim3(256), 4 * kFastBudget,
+                     stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
+                     device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 1u,
                      kFastBudget, 4u);
   hipLaunchKernelGGL(cascaded_decompress_kernel, dim3((unsigned)batch_size), dim3(64), kBigBudget, stream,
                      device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
-                     device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 1u,
+                     device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 2u,
                      kBigBudget, 1u);
   return launch_status();
 }

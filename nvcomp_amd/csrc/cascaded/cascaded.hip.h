@@ -464,53 +464,84 @@ __device__ __forceinline__ uint32_t compress_sub(
   return pos;
 }
 
+/* Result of decompress_sub. */
+constexpr uint32_t kSubOk = 0;
+constexpr uint32_t kSubBad = 1;     /* malformed stream */
+constexpr uint32_t kSubNeedLds = 2; /* valid so far, but its streams do not fit `budget`: decode it in a larger pass */
+
+__device__ __forceinline__ uint32_t align16(uint32_t v)
+{
+  return (v + 15u) & ~15u;
+}
+
+/* Decode one sub-chunk with the calling wave. `lds`/`budget`: this wave's LDS slice. The slice is carved from
+ * the stream's ACTUAL counts (LayerMeta first, then two value buffers of counts[0] elements, the run pools and
+ * the marks of the final expansion), so well-compressed data needs a few KiB where the worst case needs
+ * 3.5 x the sub-chunk; the last RLE layer expands straight into `dst` (HBM). */
 template <typename T>
-__device__ __forceinline__ bool decompress_sub(
-    const uint8_t* src, uint32_t avail, uint8_t* dst, uint32_t bytes, uint32_t num_rles, uint32_t num_deltas, T* A, T* B,
-    uint16_t* pool, uint16_t* marks, LayerMeta* meta)
+__device__ __forceinline__ uint32_t decompress_sub(
+    const uint8_t* src, uint32_t avail, uint8_t* dst, uint32_t bytes, uint32_t num_rles, uint32_t num_deltas, uint8_t* lds,
+    uint32_t budget)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   const uint32_t w = sizeof(T);
   const uint32_t n = bytes / w;
   if (avail < 4) {
-    return false;
+    return kSubBad;
   }
   const uint32_t first = *(const uint32_t*)src;
   if (first == kRawMarker) {
     if (avail < 4 + bytes) {
-      return false;
+      return kSubBad;
     }
     for (uint32_t i = lane; i < bytes; i += 64) {
       dst[i] = src[4 + i];
     }
-    return true;
+    return kSubOk;
   }
   if (first != n || avail < 4 + 4 * num_rles) {
-    return false;
+    return kSubBad;
   }
+  LayerMeta* meta = (LayerMeta*)lds;
   uint32_t* counts = meta->counts;
   uint32_t* run_off = meta->run_off;
   uint32_t pos = 4;
   uint32_t prev = n;
   uint32_t pool_used = 0;
+  uint32_t top = n; /* most elements a value buffer holds: counts[0], or n without RLE layers */
   for (uint32_t l = 0; l < num_rles; ++l) {
     const uint32_t cl = wave::uniform(*(const uint32_t*)(src + pos));
     pos += 4;
     if (cl > prev || (cl == 0 && prev != 0)) {
-      return false;
+      return kSubBad;
     }
     prev = cl;
+    if (l == 0) {
+      top = cl;
+    }
     if (lane == 0) {
       counts[l] = cl;
       run_off[l] = pool_used;
     }
     pool_used += cl;
   }
+  const uint32_t val_bytes = align16(top * w);
+  const uint32_t n_bufs = num_rles >= 2 ? 2u : 1u;
+  const uint32_t pool_bytes = align16(2 * pool_used);
+  const uint32_t marks_bytes = num_rles ? align16(2 * n) : 0u;
+  const uint32_t meta_bytes = align16((uint32_t)sizeof(LayerMeta));
+  if (meta_bytes + n_bufs * val_bytes + pool_bytes + marks_bytes > budget) {
+    return kSubNeedLds;
+  }
+  T* A = (T*)(lds + meta_bytes);
+  T* B = (T*)(lds + meta_bytes + val_bytes); /* only touched when n_bufs == 2 */
+  uint16_t* pool = (uint16_t*)(lds + meta_bytes + n_bufs * val_bytes);
+  uint16_t* marks = (uint16_t*)(lds + meta_bytes + n_bufs * val_bytes + pool_bytes);
   wave::sync();
   for (uint32_t l = 0; l < num_rles; ++l) {
     uint32_t used;
     if (!unpack_stream<uint16_t>(src + pos, avail - pos, pool + run_off[l], counts[l], 2, used)) {
-      return false;
+      return kSubBad;
     }
     pos += used;
   }
@@ -518,7 +549,7 @@ __device__ __forceinline__ bool decompress_sub(
   {
     uint32_t used;
     if (!unpack_stream<T>(src + pos, avail - pos, A, c, w, used)) {
-      return false;
+      return kSubBad;
     }
   }
   wave::sync();
@@ -531,8 +562,9 @@ __device__ __forceinline__ bool decompress_sub(
     }
     if (l < num_rles) {
       const uint32_t target = l == 0 ? n : counts[l - 1];
-      if (!rle_decode(cur, pool + run_off[l], c, oth, target, marks)) {
-        return false;
+      /* the outermost layer writes the sub-chunk itself */
+      if (!rle_decode(cur, pool + run_off[l], c, l == 0 ? (T*)dst : oth, target, marks)) {
+        return kSubBad;
       }
       c = target;
       T* t = cur;
@@ -540,11 +572,13 @@ __device__ __forceinline__ bool decompress_sub(
       oth = t;
     }
   }
-  T* out = (T*)dst;
-  for (uint32_t i = lane; i < n; i += 64) {
-    out[i] = cur[i];
+  if (num_rles == 0) {
+    T* out = (T*)dst;
+    for (uint32_t i = lane; i < n; i += 64) {
+      out[i] = cur[i];
+    }
   }
-  return true;
+  return kSubOk;
 }
 
 /* LDS bytes one wave needs for a given configuration (host + device agree). */
