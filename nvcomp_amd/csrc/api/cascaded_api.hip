@@ -43,30 +43,6 @@ bool opts_ok(const nvcompBatchedCascadedOpts_t& o)
          && o.chunk_size >= 256 && o.chunk_size <= 16384 && o.chunk_size % w == 0;
 }
 
-struct Carve
-{
-  uint8_t* a;
-  uint8_t* b;
-  uint16_t* pool;
-  uint16_t* marks;
-  casc::LayerMeta* meta;
-};
-
-__device__ __forceinline__ Carve carve(uint8_t* lds, uint32_t sub_bytes, uint32_t width, uint32_t num_rles)
-{
-  const uint32_t n = sub_bytes / width;
-  const uint32_t vals = (sub_bytes + 15u) & ~15u;
-  const uint32_t rl = num_rles ? num_rles : 1;
-  const uint32_t pool = (2u * n * rl + 15u) & ~15u;
-  Carve c;
-  c.a = lds;
-  c.b = lds + vals;
-  c.pool = (uint16_t*)(lds + 2 * vals);
-  c.marks = (uint16_t*)(lds + 2 * vals + pool);
-  c.meta = (casc::LayerMeta*)(lds + 2 * vals + pool + ((2u * n + 15u) & ~15u));
-  return c;
-}
-
 __global__ void cascaded_compress_kernel(
     const void* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
@@ -74,6 +50,9 @@ __global__ void cascaded_compress_kernel(
     void* const* __restrict__ out_ptrs,
     size_t* out_bytes,
     casc::Params p,
+    uint32_t* todo,
+    uint32_t pass,
+    uint32_t last_pass,
     uint32_t lds_per_wave,
     uint32_t waves_per_block)
 {
@@ -81,6 +60,9 @@ __global__ void cascaded_compress_kernel(
   const uint32_t wv = wave::uniform(threadIdx.x >> 6);
   const size_t chunk = (size_t)blockIdx.x * waves_per_block + wv;
   if (chunk >= batch_size) {
+    return;
+  }
+  if (pass != 0 && wave::uniform(todo[chunk]) != pass) {
     return;
   }
   const uint8_t* src = wave::uniform_ptr((const uint8_t*)in_ptrs[chunk]);
@@ -91,6 +73,9 @@ __global__ void cascaded_compress_kernel(
   if (n_bytes % w != 0) { /* contract: chunk sizes are multiples of the element size */
     if (lane == 0) {
       out_bytes[chunk] = 0;
+      if (pass == 0 && todo != nullptr) {
+        todo[chunk] = 0;
+      }
     }
     return;
   }
@@ -105,24 +90,21 @@ __global__ void cascaded_compress_kernel(
   }
   uint32_t* table = (uint32_t*)(dst + kHeaderBytes);
   uint8_t* payload = dst + kHeaderBytes + 4 * (size_t)num_sub;
-  const Carve c = carve(lds + (size_t)wv * lds_per_wave, p.sub_bytes, w, p.num_rles);
+  uint8_t* slice = lds + (size_t)wv * lds_per_wave;
   uint32_t pay = 0;
+  bool deferred = false;
   for (uint32_t s = 0; s < num_sub; ++s) {
     const uint32_t off = s * p.sub_bytes;
     const uint32_t bytes = n_bytes - off < p.sub_bytes ? n_bytes - off : p.sub_bytes;
     uint32_t sz;
     switch (w) {
-    case 1:
-      sz = casc::compress_sub<uint8_t>(src + off, bytes, payload + pay, p, (uint8_t*)c.a, (uint8_t*)c.b, c.pool, c.meta);
-      break;
-    case 2:
-      sz = casc::compress_sub<uint16_t>(src + off, bytes, payload + pay, p, (uint16_t*)c.a, (uint16_t*)c.b, c.pool, c.meta);
-      break;
-    case 4:
-      sz = casc::compress_sub<uint32_t>(src + off, bytes, payload + pay, p, (uint32_t*)c.a, (uint32_t*)c.b, c.pool, c.meta);
-      break;
-    default:
-      sz = casc::compress_sub<uint64_t>(src + off, bytes, payload + pay, p, (uint64_t*)c.a, (uint64_t*)c.b, c.pool, c.meta);
+    case 1: sz = casc::compress_sub<uint8_t>(src + off, bytes, payload + pay, p, slice, lds_per_wave); break;
+    case 2: sz = casc::compress_sub<uint16_t>(src + off, bytes, payload + pay, p, slice, lds_per_wave); break;
+    case 4: sz = casc::compress_sub<uint32_t>(src + off, bytes, payload + pay, p, slice, lds_per_wave); break;
+    default: sz = casc::compress_sub<uint64_t>(src + off, bytes, payload + pay, p, slice, lds_per_wave); break;
+    }
+    if (sz == casc::kSubNeedsLds) {
+      deferred = true; /* the whole chunk is compressed again by the next pass; the host sized the last pass for the worst case */
       break;
     }
     pay += sz;
@@ -132,7 +114,14 @@ __global__ void cascaded_compress_kernel(
     wave::sync();
   }
   if (lane == 0) {
-    out_bytes[chunk] = kHeaderBytes + 4 * (size_t)num_sub + pay;
+    if (deferred && pass < last_pass) {
+      todo[chunk] = pass + 1;
+    } else {
+      out_bytes[chunk] = deferred ? 0 : kHeaderBytes + 4 * (size_t)num_sub + pay;
+      if (pass == 0 && todo != nullptr) {
+        todo[chunk] = 0;
+      }
+    }
   }
 }
 
@@ -284,7 +273,7 @@ __global__ void cascaded_size_kernel(
 extern "C" {
 
 nvcompStatus_t nvcompBatchedCascadedCompressGetTempSize(
-    size_t /*batch_size*/, size_t max_uncompressed_chunk_bytes, nvcompBatchedCascadedOpts_t format_opts, size_t* temp_bytes)
+    size_t batch_size, size_t max_uncompressed_chunk_bytes, nvcompBatchedCascadedOpts_t format_opts, size_t* temp_bytes)
 {
   if (temp_bytes == nullptr || !opts_ok(format_opts)) {
     return nvcompErrorInvalidValue;
@@ -292,7 +281,7 @@ nvcompStatus_t nvcompBatchedCascadedCompressGetTempSize(
   if (max_uncompressed_chunk_bytes > nvcompCascadedCompressionMaxAllowedChunkSize) {
     return nvcompErrorChunkSizeTooLarge;
   }
-  *temp_bytes = 0; /* all intermediate streams live in LDS */
+  *temp_bytes = 4 * batch_size; /* one "repeat with a larger LDS slice" word per chunk */
   return nvcompSuccess;
 }
 
@@ -316,8 +305,8 @@ nvcompStatus_t nvcompBatchedCascadedCompressAsync(
     const size_t* device_uncompressed_bytes,
     size_t max_uncompressed_chunk_bytes,
     size_t batch_size,
-    void* /*device_temp_ptr*/,
-    size_t /*temp_bytes*/,
+    void* device_temp_ptr,
+    size_t temp_bytes,
     void* const* device_compressed_ptrs,
     size_t* device_compressed_bytes,
     nvcompBatchedCascadedOpts_t format_opts,
@@ -353,9 +342,22 @@ nvcompStatus_t nvcompBatchedCascadedCompressAsync(
   waves = waves > 4 ? 4 : waves;
   const unsigned grid = (unsigned)((batch_size + waves - 1) / waves);
   clear_stale_error();
+  uint32_t* todo = (uint32_t*)device_temp_ptr;
+  if (todo == nullptr || temp_bytes < 4 * batch_size || per_wave <= kSmallBudget) {
+    /* no flag words (or nothing to gain): one launch sized for the worst case */
+    hipLaunchKernelGGL(cascaded_compress_kernel, dim3(grid), dim3(64 * waves), per_wave * waves, stream,
+                       device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
+                       device_compressed_bytes, p, (uint32_t*)nullptr, 0u, 0u, per_wave, waves);
+    return launch_status();
+  }
+  /* pass 0: a small LDS slice at full occupancy; chunks whose streams overflow it are flagged and compressed
+   * again by pass 1, whose slice holds the worst case */
+  hipLaunchKernelGGL(cascaded_compress_kernel, dim3((unsigned)((batch_size + 3) / 4)), dim3(256), 4 * kSmallBudget, stream,
+                     device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
+                     device_compressed_bytes, p, todo, 0u, 1u, kSmallBudget, 4u);
   hipLaunchKernelGGL(cascaded_compress_kernel, dim3(grid), dim3(64 * waves), per_wave * waves, stream,
                      device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
-                     device_compressed_bytes, p, per_wave, waves);
+                     device_compressed_bytes, p, todo, 1u, 1u, per_wave, waves);
   return launch_status();
 }
 

@@ -222,9 +222,11 @@ __device__ __forceinline__ bool unpack_stream(const uint8_t* src, uint32_t avail
 
 /* ---- layers ---------------------------------------------------------------- */
 
+constexpr uint32_t kRleOverflow = 0xffffffffu;
+
 /* RLE of A[0..c) -> values in B, run lengths in runs; returns the new count. */
 template <typename T>
-__device__ __forceinline__ uint32_t rle_encode(const T* A, uint32_t c, T* B, uint16_t* runs)
+__device__ __forceinline__ uint32_t rle_encode(const T* A, uint32_t c, T* B, uint16_t* runs, uint32_t cap)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   uint32_t m = 0;
@@ -237,6 +239,9 @@ __device__ __forceinline__ uint32_t rle_encode(const T* A, uint32_t c, T* B, uin
     const bool head = in && (i == 0 || v != prev);
     const uint64_t mask = wave::ballot(head);
     const uint32_t rank = wave::popc64(mask & ((1ull << lane) - 1));
+    if (m + wave::popc64(mask) > cap) {
+      return kRleOverflow; /* more runs than B / runs can hold: the caller retries with a larger LDS slice */
+    }
     if (head) {
       B[m + rank] = v;
       runs[m + rank] = (uint16_t)i;
@@ -360,6 +365,8 @@ __device__ __forceinline__ bool rle_decode(const T* A, const uint16_t* runs, uin
 
 /* ---- sub-chunk codec ------------------------------------------------------- */
 
+constexpr uint32_t kSubNeedsLds = 0xffffffffu; /* compress_sub: the streams do not fit the LDS slice it was given */
+
 /* Per-wave bookkeeping of the layer loops, kept in LDS: indexing private arrays with the
  * run-time layer number would put them in scratch memory. */
 struct LayerMeta
@@ -371,40 +378,78 @@ struct LayerMeta
   uint64_t mins[9];
 };
 
+/* Compress one sub-chunk with the calling wave into dst; returns its size, or kSubNeedsLds when the
+ * intermediate streams do not fit the `budget` bytes of LDS at `lds` (nothing final has been decided then:
+ * the caller repeats the whole chunk in a pass with a larger slice). With at least one RLE layer the input is
+ * never staged: the first layer reads it from HBM and only its (values, runs) output lives in LDS, so a
+ * compressible sub-chunk needs a fraction of the worst case. */
 template <typename T>
 __device__ __forceinline__ uint32_t compress_sub(
-    const uint8_t* src, uint32_t bytes, uint8_t* dst, const Params& p, T* A, T* B, uint16_t* pool, LayerMeta* meta)
+    const uint8_t* src, uint32_t bytes, uint8_t* dst, const Params& p, uint8_t* lds, uint32_t budget)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   const uint32_t w = sizeof(T);
   const uint32_t n = bytes / w;
   const T* in = (const T*)src;
-  for (uint32_t i = lane; i < n; i += 64) {
-    A[i] = in[i];
+  LayerMeta* meta = (LayerMeta*)lds;
+  const uint32_t meta_bytes = (uint32_t)((sizeof(LayerMeta) + 15u) & ~15u);
+  if (budget < meta_bytes + 64) {
+    return kSubNeedsLds;
   }
-  wave::sync();
+  /* two value buffers of cap elements, run pools of num_rles * cap entries */
+  const uint32_t rl = p.num_rles;
+  uint32_t cap = ((budget - meta_bytes) / (2 * w + 2 * rl)) & ~7u;
+  cap = cap > n ? ((n + 7u) & ~7u) : cap;
+  if (cap == 0 || (rl == 0 && cap < n)) {
+    return kSubNeedsLds;
+  }
+  const uint32_t val_bytes = (cap * w + 15u) & ~15u;
+  if (meta_bytes + 2 * val_bytes + 2 * rl * cap > budget) {
+    cap -= 8; /* the two 16-byte roundings */
+    if (cap == 0 || (rl == 0 && cap < n)) {
+      return kSubNeedsLds;
+    }
+  }
+  T* A = (T*)(lds + meta_bytes);
+  T* B = (T*)(lds + meta_bytes + val_bytes);
+  uint16_t* pool = (uint16_t*)(lds + meta_bytes + 2 * val_bytes);
   const uint32_t layers = p.num_rles > p.num_deltas ? p.num_rles : p.num_deltas;
   uint32_t* counts = meta->counts;
   uint32_t* run_off = meta->run_off;
   uint32_t c = n;
   uint32_t pool_used = 0;
-  T* cur = A;
-  T* oth = B;
+  const T* cur = in; /* layer 0 reads the input where it lies */
+  T* free_buf = A;
+  T* other_buf = B;
+  if (rl == 0) {
+    for (uint32_t i = lane; i < n; i += 64) {
+      A[i] = in[i];
+    }
+    wave::sync();
+    cur = A;
+    free_buf = B;
+    other_buf = A;
+  }
   for (uint32_t l = 0; l < layers; ++l) {
     if (l < p.num_rles) {
-      c = rle_encode(cur, c, oth, pool + pool_used);
+      const uint32_t m = rle_encode(cur, c, free_buf, pool + pool_used, cap);
+      if (m == kRleOverflow) {
+        return kSubNeedsLds;
+      }
+      c = m;
       if (lane == 0) {
         run_off[l] = pool_used;
         counts[l] = c;
       }
       pool_used += c;
-      T* t = cur;
-      cur = oth;
-      oth = t;
+      cur = free_buf;
+      T* t = free_buf;
+      free_buf = other_buf;
+      other_buf = t;
       wave::sync();
     }
     if (l < p.num_deltas) {
-      delta_encode(cur, c);
+      delta_encode((T*)cur, c); /* cur is an LDS buffer here: layer 0 of a delta-only cascade staged the input */
     }
   }
   wave::sync();
@@ -425,7 +470,7 @@ __device__ __forceinline__ uint32_t compress_sub(
   {
     const bool as_signed = p.num_deltas > 0 ? true : type_signed(p.type);
     if (p.use_bp) {
-      Stream<T> s{cur};
+      Stream<T> s{(T*)cur};
       stream_range(s, c, w, as_signed, mins[8], bitsv[8]);
     } else {
       mins[8] = 0;
@@ -458,7 +503,7 @@ __device__ __forceinline__ uint32_t compress_sub(
     pos += pack_stream(dst + pos, s, counts[l], 2, mins[l], bitsv[l]);
   }
   {
-    Stream<T> s{cur};
+    Stream<T> s{(T*)cur};
     pos += pack_stream(dst + pos, s, c, w, mins[8], bitsv[8]);
   }
   return pos;
