@@ -334,10 +334,10 @@ nvcompStatus_t nvcompBatchedCascadedCompressAsync(
   p.num_deltas = (uint32_t)format_opts.num_deltas;
   p.use_bp = (uint32_t)format_opts.use_bp;
   const uint32_t w = 1u << (p.type >> 1);
-  const uint32_t per_wave = casc::lds_bytes_per_wave(p.sub_bytes, w, p.num_rles);
-  if (per_wave > kBigBudget) {
+  if (casc::lds_bytes_per_wave(p.sub_bytes, w, p.num_rles) > kBigBudget) { /* what the decoder may need */
     return nvcompErrorNotSupported;
   }
+  const uint32_t per_wave = (casc::compress_lds_per_wave(p.sub_bytes, w, p.num_rles) + 15u) & ~15u;
   uint32_t waves = kBigBudget / per_wave;
   waves = waves > 4 ? 4 : waves;
   const unsigned grid = (unsigned)((batch_size + waves - 1) / waves);

@@ -220,9 +220,42 @@ __device__ __forceinline__ bool unpack_stream(const uint8_t* src, uint32_t avail
   return true;
 }
 
+/* dst <- src, whole wave, non-overlapping: dwords when both sides are 4-byte aligned */
+__device__ __forceinline__ void copy_bytes(uint8_t* dst, const uint8_t* src, uint32_t bytes)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  uint32_t done = 0;
+  if ((((uintptr_t)dst | (uintptr_t)src) & 3u) == 0) {
+    const uint32_t words = bytes / 4;
+    for (uint32_t i = lane; i < words; i += 64) {
+      ((uint32_t*)dst)[i] = ((const uint32_t*)src)[i];
+    }
+    done = words * 4;
+  }
+  for (uint32_t i = done + lane; i < bytes; i += 64) {
+    dst[i] = src[i];
+  }
+}
+
 /* ---- layers ---------------------------------------------------------------- */
 
 constexpr uint32_t kRleOverflow = 0xffffffffu;
+
+/* Number of run heads in A[0..c): elements that differ from their predecessor (A may be HBM or LDS). */
+template <typename T>
+__device__ __forceinline__ uint32_t count_heads(const T* A, uint32_t c)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  uint32_t m = 0;
+  for (uint32_t base = 0; base < c; base += 64) {
+    const uint32_t i = base + lane;
+    const bool in = i < c;
+    const T v = in ? A[i] : (T)0;
+    const T prev = (in && i > 0) ? A[i - 1] : (T)0;
+    m += wave::popc64(wave::ballot(in && (i == 0 || v != prev)));
+  }
+  return m;
+}
 
 /* RLE of A[0..c) -> values in B, run lengths in runs; returns the new count. */
 template <typename T>
@@ -376,6 +409,8 @@ struct LayerMeta
   uint32_t bits[9];
   uint32_t pad;
   uint64_t mins[9];
+  uint32_t ident[8];   /* RLE layer l found no runs: values pass through, every run length is 1 */
+  uint32_t src_off[8]; /* decode: where layer l's run stream starts inside the sub-chunk */
 };
 
 /* Compress one sub-chunk with the calling wave into dst; returns its size, or kSubNeedsLds when the
@@ -396,60 +431,91 @@ __device__ __forceinline__ uint32_t compress_sub(
   if (budget < meta_bytes + 64) {
     return kSubNeedsLds;
   }
-  /* two value buffers of cap elements, run pools of num_rles * cap entries */
   const uint32_t rl = p.num_rles;
-  uint32_t cap = ((budget - meta_bytes) / (2 * w + 2 * rl)) & ~7u;
-  cap = cap > n ? ((n + 7u) & ~7u) : cap;
-  if (cap == 0 || (rl == 0 && cap < n)) {
-    return kSubNeedsLds;
-  }
-  const uint32_t val_bytes = (cap * w + 15u) & ~15u;
-  if (meta_bytes + 2 * val_bytes + 2 * rl * cap > budget) {
-    cap -= 8; /* the two 16-byte roundings */
-    if (cap == 0 || (rl == 0 && cap < n)) {
-      return kSubNeedsLds;
-    }
-  }
-  T* A = (T*)(lds + meta_bytes);
-  T* B = (T*)(lds + meta_bytes + val_bytes);
-  uint16_t* pool = (uint16_t*)(lds + meta_bytes + 2 * val_bytes);
-  const uint32_t layers = p.num_rles > p.num_deltas ? p.num_rles : p.num_deltas;
+  const uint32_t layers = rl > p.num_deltas ? rl : p.num_deltas;
   uint32_t* counts = meta->counts;
   uint32_t* run_off = meta->run_off;
+  uint32_t* ident = meta->ident;
+  /* Layer 0 reads the input from HBM and the two value buffers hold layer outputs, `cap` elements each. A layer
+   * whose output does not fit is either hopeless for this slice (kSubNeedsLds) or found no runs at all: then it is
+   * the identity (values pass through, all run lengths 1), uses no LDS and, with bit-packing, its run stream is
+   * just a header. After an identity layer 0 the input is staged whole as soon as something has to modify it. */
+  const bool can_skip = p.use_bp != 0;
+  uint8_t* area = lds + meta_bytes;
+  const uint32_t area_bytes = budget - meta_bytes;
+  uint32_t cap = (area_bytes / (2 * w + 2 * (rl ? rl : 1))) & ~7u;
+  cap = cap > n ? ((n + 7u) & ~7u) : cap;
+  uint32_t val_bytes = (cap * w + 15u) & ~15u;
+  if (2 * val_bytes + 2 * rl * cap > area_bytes) {
+    cap = cap >= 8 ? cap - 8 : 0;
+    val_bytes = (cap * w + 15u) & ~15u;
+  }
+  T* free_buf = (T*)area;
+  T* other_buf = (T*)(area + val_bytes);
+  uint16_t* pool = (uint16_t*)(area + 2 * val_bytes);
   uint32_t c = n;
   uint32_t pool_used = 0;
-  const T* cur = in; /* layer 0 reads the input where it lies */
-  T* free_buf = A;
-  T* other_buf = B;
-  if (rl == 0) {
-    for (uint32_t i = lane; i < n; i += 64) {
-      A[i] = in[i];
-    }
-    wave::sync();
-    cur = A;
-    free_buf = B;
-    other_buf = A;
-  }
+  const T* cur = in; /* HBM until a layer encodes it or a delta stages it */
+  bool cur_in_hbm = true;
   for (uint32_t l = 0; l < layers; ++l) {
-    if (l < p.num_rles) {
-      const uint32_t m = rle_encode(cur, c, free_buf, pool + pool_used, cap);
+    if (l < rl) {
+      uint32_t m = cap ? rle_encode(cur, c, free_buf, pool + pool_used, cap) : kRleOverflow;
+      bool id = false;
       if (m == kRleOverflow) {
-        return kSubNeedsLds;
+        if (!(can_skip && count_heads(cur, c) == c)) {
+          return kSubNeedsLds;
+        }
+        id = true;
+        if (cur_in_hbm) {
+          /* re-carve: one buffer for the staged input, what is left for one more value buffer and the pools */
+          const uint32_t stage_bytes = (n * w + 15u) & ~15u;
+          if (stage_bytes > area_bytes) {
+            return kSubNeedsLds;
+          }
+          cap = ((area_bytes - stage_bytes) / (w + 2 * rl)) & ~7u;
+          cap = cap > n ? ((n + 7u) & ~7u) : cap;
+          if (cap && stage_bytes + ((cap * w + 15u) & ~15u) + 2 * rl * cap > area_bytes) {
+            cap -= 8;
+          }
+          free_buf = (T*)(area + stage_bytes);
+          other_buf = (T*)area; /* free once a real layer has consumed the staged input */
+          pool = (uint16_t*)(area + stage_bytes + ((cap * w + 15u) & ~15u));
+        }
+      } else {
+        c = m;
+        pool_used += c;
+        cur = free_buf;
+        cur_in_hbm = false;
+        T* t = free_buf;
+        free_buf = other_buf;
+        other_buf = t;
       }
-      c = m;
       if (lane == 0) {
-        run_off[l] = pool_used;
+        ident[l] = id ? 1u : 0u;
+        run_off[l] = id ? pool_used : pool_used - c;
         counts[l] = c;
       }
-      pool_used += c;
-      cur = free_buf;
-      T* t = free_buf;
-      free_buf = other_buf;
-      other_buf = t;
       wave::sync();
     }
     if (l < p.num_deltas) {
-      delta_encode((T*)cur, c); /* cur is an LDS buffer here: layer 0 of a delta-only cascade staged the input */
+      if (cur_in_hbm) { /* nothing but identity layers (or none) so far: stage the input */
+        if (((n * w + 15u) & ~15u) > area_bytes) {
+          return kSubNeedsLds;
+        }
+        T* staged = (T*)area;
+        for (uint32_t i = lane; i < n; i += 64) {
+          staged[i] = in[i];
+        }
+        wave::sync();
+        cur = staged;
+        cur_in_hbm = false;
+        if (rl == 0 || free_buf == staged) { /* no re-carve happened (delta-only cascade): keep the staged buffer apart */
+          free_buf = (T*)(area + ((n * w + 15u) & ~15u));
+          other_buf = staged;
+          cap = 0;
+        }
+      }
+      delta_encode((T*)cur, c);
     }
   }
   wave::sync();
@@ -458,7 +524,13 @@ __device__ __forceinline__ uint32_t compress_sub(
   uint32_t* bitsv = meta->bits;
   uint32_t sz = 4 + 4 * p.num_rles;
   for (uint32_t l = 0; l < p.num_rles; ++l) {
-    if (p.use_bp) {
+    if (ident[l]) { /* all run lengths are 1: what stream_range finds for them, without the stream */
+      if (lane == 0) {
+        mins[l] = counts[l] ? 1 : 0;
+        bitsv[l] = 0;
+      }
+      wave::sync();
+    } else if (p.use_bp) {
       Stream<uint16_t> s{pool + run_off[l]};
       stream_range(s, counts[l], 2, false, mins[l], bitsv[l]);
     } else {
@@ -486,8 +558,9 @@ __device__ __forceinline__ uint32_t compress_sub(
     }
     /* raw bytes, zero padded to a multiple of 4 */
     const uint32_t padded = raw_sz - 4;
-    for (uint32_t i = lane; i < padded; i += 64) {
-      dst[4 + i] = i < bytes ? src[i] : (uint8_t)0;
+    copy_bytes(dst + 4, src, bytes);
+    if (lane < padded - bytes) {
+      dst[4 + bytes + lane] = 0;
     }
     return raw_sz;
   }
@@ -534,14 +607,18 @@ __device__ __forceinline__ uint32_t decompress_sub(
   if (avail < 4) {
     return kSubBad;
   }
-  const uint32_t first = *(const uint32_t*)src;
+  /* the first 256 bytes of the sub-chunk in one coalesced load: all of its header words (a compressible
+   * sub-chunk fits entirely), read back with v_readlane instead of a dependent HBM round trip each */
+  const uint32_t head = 4 * lane + 4 <= avail ? *(const uint32_t*)(src + 4 * lane) : 0u;
+  auto word_at = [&](uint32_t byte_pos) -> uint32_t {
+    return byte_pos < 256 ? wave::read_lane(head, byte_pos >> 2) : wave::uniform(*(const uint32_t*)(src + byte_pos));
+  };
+  const uint32_t first = word_at(0);
   if (first == kRawMarker) {
     if (avail < 4 + bytes) {
       return kSubBad;
     }
-    for (uint32_t i = lane; i < bytes; i += 64) {
-      dst[i] = src[4 + i];
-    }
+    copy_bytes(dst, src + 4, bytes);
     return kSubOk;
   }
   if (first != n || avail < 4 + 4 * num_rles) {
@@ -550,45 +627,84 @@ __device__ __forceinline__ uint32_t decompress_sub(
   LayerMeta* meta = (LayerMeta*)lds;
   uint32_t* counts = meta->counts;
   uint32_t* run_off = meta->run_off;
+  uint32_t* ident = meta->ident;
+  uint32_t* src_off = meta->src_off;
+  const uint32_t meta_bytes = align16((uint32_t)sizeof(LayerMeta));
+  if (budget < meta_bytes) {
+    return kSubNeedLds;
+  }
   uint32_t pos = 4;
   uint32_t prev = n;
-  uint32_t pool_used = 0;
-  uint32_t top = n; /* most elements a value buffer holds: counts[0], or n without RLE layers */
   for (uint32_t l = 0; l < num_rles; ++l) {
-    const uint32_t cl = wave::uniform(*(const uint32_t*)(src + pos));
+    const uint32_t cl = word_at(pos);
     pos += 4;
     if (cl > prev || (cl == 0 && prev != 0)) {
       return kSubBad;
     }
     prev = cl;
-    if (l == 0) {
-      top = cl;
-    }
     if (lane == 0) {
       counts[l] = cl;
+    }
+  }
+  wave::sync();
+  /* walk the run-stream headers: a layer whose runs are all 1 (bits 0, minimum 1, as many runs as outputs) is the
+   * identity -- its values pass through and it needs neither its runs nor an expansion buffer */
+  uint32_t pool_used = 0;    /* run entries that must be unpacked */
+  uint32_t inner_real = 0;   /* expanding layers below the outermost one: they expand into LDS */
+  uint32_t marks_elems = 0;  /* largest expansion target */
+  for (uint32_t l = 0; l < num_rles; ++l) {
+    if (avail - pos < 12) {
+      return kSubBad;
+    }
+    const uint32_t bits = word_at(pos);
+    const uint32_t mn_lo = word_at(pos + 4);
+    const uint32_t mn_hi = word_at(pos + 8);
+    if (bits > 64) {
+      return kSubBad;
+    }
+    const uint32_t cl = counts[l];
+    const uint32_t target = l == 0 ? n : counts[l - 1];
+    const uint64_t words = ((uint64_t)cl * bits + 31) / 32;
+    if ((avail - pos - 12) / 4 < words) {
+      return kSubBad;
+    }
+    const bool id = bits == 0 && mn_lo == 1 && mn_hi == 0 && cl == target;
+    if (lane == 0) {
+      ident[l] = id ? 1u : 0u;
+      src_off[l] = pos;
       run_off[l] = pool_used;
     }
-    pool_used += cl;
+    if (!id) {
+      pool_used += cl;
+      inner_real += l > 0 ? 1u : 0u;
+      marks_elems = target > marks_elems ? target : marks_elems;
+    }
+    pos += 12 + 4 * (uint32_t)words;
   }
+  wave::sync();
+  /* value buffers: the outermost expanding layer writes to HBM when it is layer 0, so a buffer holds at most
+   * counts[0] elements then; without that it holds the n elements of the sub-chunk */
+  const bool outer_to_hbm = num_rles != 0 && ident[0] == 0;
+  const uint32_t top = outer_to_hbm ? counts[0] : n;
   const uint32_t val_bytes = align16(top * w);
-  const uint32_t n_bufs = num_rles >= 2 ? 2u : 1u;
+  const uint32_t n_bufs = inner_real ? 2u : 1u;
   const uint32_t pool_bytes = align16(2 * pool_used);
-  const uint32_t marks_bytes = num_rles ? align16(2 * n) : 0u;
-  const uint32_t meta_bytes = align16((uint32_t)sizeof(LayerMeta));
-  if (meta_bytes + n_bufs * val_bytes + pool_bytes + marks_bytes > budget) {
+  const uint32_t marks_bytes = align16(2 * marks_elems);
+  if ((uint64_t)meta_bytes + (uint64_t)n_bufs * val_bytes + pool_bytes + marks_bytes > budget) {
     return kSubNeedLds;
   }
   T* A = (T*)(lds + meta_bytes);
   T* B = (T*)(lds + meta_bytes + val_bytes); /* only touched when n_bufs == 2 */
   uint16_t* pool = (uint16_t*)(lds + meta_bytes + n_bufs * val_bytes);
   uint16_t* marks = (uint16_t*)(lds + meta_bytes + n_bufs * val_bytes + pool_bytes);
-  wave::sync();
   for (uint32_t l = 0; l < num_rles; ++l) {
+    if (ident[l]) {
+      continue;
+    }
     uint32_t used;
-    if (!unpack_stream<uint16_t>(src + pos, avail - pos, pool + run_off[l], counts[l], 2, used)) {
+    if (!unpack_stream<uint16_t>(src + src_off[l], avail - src_off[l], pool + run_off[l], counts[l], 2, used)) {
       return kSubBad;
     }
-    pos += used;
   }
   uint32_t c = num_rles ? counts[num_rles - 1] : n;
   {
@@ -601,23 +717,25 @@ __device__ __forceinline__ uint32_t decompress_sub(
   const uint32_t layers = num_rles > num_deltas ? num_rles : num_deltas;
   T* cur = A;
   T* oth = B;
+  bool in_hbm = false;
   for (uint32_t l = layers; l-- > 0;) {
     if (l < num_deltas) {
       delta_decode(cur, c);
     }
-    if (l < num_rles) {
+    if (l < num_rles && !ident[l]) {
       const uint32_t target = l == 0 ? n : counts[l - 1];
-      /* the outermost layer writes the sub-chunk itself */
+      /* layer 0 writes the sub-chunk itself */
       if (!rle_decode(cur, pool + run_off[l], c, l == 0 ? (T*)dst : oth, target, marks)) {
         return kSubBad;
       }
+      in_hbm = l == 0;
       c = target;
       T* t = cur;
       cur = oth;
       oth = t;
     }
   }
-  if (num_rles == 0) {
+  if (!in_hbm) {
     T* out = (T*)dst;
     for (uint32_t i = lane; i < n; i += 64) {
       out[i] = cur[i];
@@ -635,6 +753,14 @@ __host__ __device__ inline uint32_t lds_bytes_per_wave(uint32_t sub_bytes, uint3
   const uint32_t pool = (2u * n * rl + 15u) & ~15u;
   const uint32_t marks = (2u * n + 15u) & ~15u;
   return 2 * vals + pool + marks + 192; /* + LayerMeta */
+}
+
+/* Worst case of compress_sub: LayerMeta, two value buffers of n elements, num_rles run pools of n entries. */
+__host__ __device__ inline uint32_t compress_lds_per_wave(uint32_t sub_bytes, uint32_t width, uint32_t num_rles)
+{
+  const uint32_t n = sub_bytes / width;
+  const uint32_t cap = (n + 7u) & ~7u;
+  return ((uint32_t)((sizeof(LayerMeta) + 15u) & ~15u)) + 2 * ((cap * width + 15u) & ~15u) + 2 * num_rles * cap + 32;
 }
 
 } // namespace casc
