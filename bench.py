@@ -52,7 +52,7 @@ def parse_args():
     p.add_argument("--unique-mib", type=int, default=64, help="unique MiB generated + CPU-compressed per rank")
     p.add_argument("--unique-kib", type=int, default=0, help="(tests) unique KiB per rank, overrides --unique-mib/--mib-per-gpu")
     p.add_argument("--dataset", default=None,
-                   help="nvcomp_amd.datasets generator; default silesia_style (int32 for cascaded / bitcomp: BASELINE.json configs[3])")
+                   help="nvcomp_amd.datasets generator; default silesia_style (float_columns for cascaded / bitcomp: BASELINE.json configs[3])")
     p.add_argument("--producer", choices=["hc", "fast", "port"], default="hc",
                    help="CPU compressor making the inputs: liblz4 HC-12 / liblz4 default / oracle port")
     p.add_argument("--unchecked", action="store_true", help="statuses=NULL fast path (reported separately)")
@@ -603,7 +603,8 @@ def run_allgather_case(args, ctx):
 def main():
     args = parse_args()
     if args.dataset is None:
-        args.dataset = "int32" if args.algo in ("cascaded", "bitcomp") else "silesia_style"
+        # BASELINE.json configs[3]: "int32 columnar floats" -> float columns shaped like the reference's ExampleFloatData.csv
+        args.dataset = "float_columns" if args.algo in ("cascaded", "bitcomp") else "silesia_style"
     ctx = setup_runtime(args)
     result = run_allgather_case(args, ctx) if args.allgather else run_case(args, ctx)
     if args.dry_run_emu and args.allgather:

@@ -135,6 +135,30 @@ def float32_column(size: int, seed: int = 0) -> np.ndarray:
     return x.astype(np.float32).view(np.uint8)[:size].copy()
 
 
+def float_columns(size: int, seed: int = 0) -> np.ndarray:
+    """The shape of the reference's ExampleFloatData.csv columns after text_to_binary.py (BASELINE.json configs[3],
+    "int32 columnar floats"): 4001-row blocks of a 0.01-step ramp, a slowly varying signal with 9 significant digits
+    and a second, flatter one, as float32; the blocks repeat with a drifting phase like `-x` duplication would not --
+    so that chunks differ. No two neighbours are equal, the deltas are small and smooth."""
+    rng = np.random.RandomState(seed + 606)
+    rows = 4001
+    blocks = size // (4 * rows) + 1
+    out = np.empty(blocks * rows, dtype=np.float32)
+    for b in range(blocks):
+        t = np.arange(rows, dtype=np.float64) * 0.01
+        kind = b % 3
+        if kind == 0:
+            col = t + 40.0 * (b // 3)
+        elif kind == 1:
+            ph = rng.rand() * 6.28
+            col = 0.5 + 0.07 * np.sin(0.31 * t + ph) + 0.011 * np.sin(2.7 * t + 2 * ph) + 1e-5 * rng.randn(rows)
+        else:
+            ph = rng.rand() * 6.28
+            col = 2.29 + 0.004 * np.cos(0.11 * t + ph) + 2e-6 * np.cumsum(rng.randn(rows))
+        out[b * rows: (b + 1) * rows] = col.astype(np.float32)
+    return out.view(np.uint8)[:size].copy()
+
+
 def int32_column(size: int, seed: int = 0) -> np.ndarray:
     """Sorted keys with runs (low-cardinality dimension column), int32."""
     rng = np.random.RandomState(seed + 505)
@@ -149,6 +173,7 @@ CLASSES: Dict[str, Callable[[int, int], np.ndarray]] = {
     "float_csv": float_csv,
     "float32": float32_column,
     "int32": int32_column,
+    "float_columns": float_columns,
     "lowcard": lowcard,
     "zeros": zeros,
     "noise": noise,

@@ -13,7 +13,7 @@ NVCOMP_AMD_LZ4_DECODE=direct timeout 300 python bench.py --steps 5 --warmup 1 --
 NVCOMP_AMD_LZ4_DECODE=serial timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/bench_lz4_serial.json" 2> "$OUT/bench_lz4_serial.err"
 timeout 400 python bench.py --algo snappy > "$OUT/bench_snappy.json" 2> "$OUT/bench_snappy.err"; echo "bench snappy rc=$?" >> "$OUT/rc.txt"
 timeout 600 python scripts/bench_sweep.py --out "$OUT/sweep.jsonl" --mib 512 --unique-mib 32 --steps 5 > "$OUT/sweep.log" 2>&1; echo "sweep rc=$?" >> "$OUT/rc.txt"
-for ds in int32 float32 lowcard; do
+for ds in int32 float_columns float32 lowcard noise; do
   timeout 200 python scripts/bench_roundtrip.py --algo cascaded --dataset $ds --mib 1024 --unique-mib 32 >> "$OUT/roundtrip.jsonl" 2>> "$OUT/roundtrip.err"
 done
 for algo in lz4 snappy; do for ds in silesia_style text int32; do
@@ -22,7 +22,7 @@ done; done
 for ds in silesia_style text table float_csv int32 lowcard zeros noise; do
   timeout 200 python scripts/bench_roundtrip.py --algo ans --dataset $ds --unique-mib 32 --mib 1024 >> "$OUT/roundtrip.jsonl" 2>> "$OUT/roundtrip.err"
 done
-for spec in "int32 0,4" "int32 1,4" "float32 0,4" "int32 0,6" "int32 0,2" "silesia_style 0,1" "zeros 0,1"; do
+for spec in "int32 0,4" "int32 1,4" "float32 0,4" "float_columns 0,4" "int32 0,6" "int32 0,2" "silesia_style 0,1" "zeros 0,1"; do
   set -- $spec
   timeout 200 python scripts/bench_roundtrip.py --algo bitcomp --dataset $1 --opts $2 --unique-mib 32 --mib 1024 >> "$OUT/roundtrip.jsonl" 2>> "$OUT/roundtrip.err"
 done
