@@ -19,9 +19,11 @@ namespace {
 constexpr uint32_t kHeaderBytes = 20;
 /* Decode runs three passes with growing LDS per wave; a sub-chunk's need follows from its actual stream counts
  * (casc::decompress_sub), so compressible data is decoded by the first pass at full occupancy. */
-constexpr uint32_t kSmallBudget = 5 * 1024; /* pass 0: 4 waves per workgroup, 8 workgroups per CU */
-constexpr uint32_t kFastBudget = 16 * 1024; /* pass 1: 4 waves per workgroup */
-constexpr uint32_t kBigBudget = 64 * 1024;  /* pass 2: one wave per workgroup; also the compressor's limit */
+constexpr uint32_t kSmallBudget = 5 * 1024;       /* pass 0: 4 waves per workgroup, 8 workgroups per CU */
+constexpr uint32_t kMidBudget = 8 * 1024 + 512;   /* compress pass 1: a 4 KiB sub-chunk and two full run pools: 4 workgroups per CU */
+constexpr uint32_t kFastBudget = 16 * 1024;       /* decode pass 1: 4 waves per workgroup (two value buffers: a variant that expands in
+                                                     place at twice the occupancy measured 30 % slower, the decoder is latency-bound) */
+constexpr uint32_t kBigBudget = 64 * 1024;        /* last pass: one wave per workgroup; also the compressor's limit */
 
 void clear_stale_error()
 {
@@ -334,7 +336,7 @@ nvcompStatus_t nvcompBatchedCascadedCompressAsync(
   p.num_deltas = (uint32_t)format_opts.num_deltas;
   p.use_bp = (uint32_t)format_opts.use_bp;
   const uint32_t w = 1u << (p.type >> 1);
-  if (casc::lds_bytes_per_wave(p.sub_bytes, w, p.num_rles) > kBigBudget) { /* what the decoder may need */
+  if (casc::decompress_lds_per_wave(p.sub_bytes, w, p.num_rles) + 64 > kBigBudget) { /* what the decoder may need */
     return nvcompErrorNotSupported;
   }
   const uint32_t per_wave = (casc::compress_lds_per_wave(p.sub_bytes, w, p.num_rles) + 15u) & ~15u;
@@ -350,14 +352,20 @@ nvcompStatus_t nvcompBatchedCascadedCompressAsync(
                        device_compressed_bytes, p, (uint32_t*)nullptr, 0u, 0u, per_wave, waves);
     return launch_status();
   }
-  /* pass 0: a small LDS slice at full occupancy; chunks whose streams overflow it are flagged and compressed
-   * again by pass 1, whose slice holds the worst case */
+  /* pass 0: a small LDS slice at full occupancy; chunks whose streams overflow it are flagged and compressed again by
+   * the next pass; the last pass holds the worst case */
+  const uint32_t last = per_wave > kMidBudget ? 2u : 1u;
   hipLaunchKernelGGL(cascaded_compress_kernel, dim3((unsigned)((batch_size + 3) / 4)), dim3(256), 4 * kSmallBudget, stream,
                      device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
-                     device_compressed_bytes, p, todo, 0u, 1u, kSmallBudget, 4u);
+                     device_compressed_bytes, p, todo, 0u, last, kSmallBudget, 4u);
+  if (last == 2) {
+    hipLaunchKernelGGL(cascaded_compress_kernel, dim3((unsigned)((batch_size + 3) / 4)), dim3(256), 4 * kMidBudget, stream,
+                       device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
+                       device_compressed_bytes, p, todo, 1u, last, kMidBudget, 4u);
+  }
   hipLaunchKernelGGL(cascaded_compress_kernel, dim3(grid), dim3(64 * waves), per_wave * waves, stream,
                      device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
-                     device_compressed_bytes, p, todo, 1u, 1u, per_wave, waves);
+                     device_compressed_bytes, p, todo, last, last, per_wave, waves);
   return launch_status();
 }
 

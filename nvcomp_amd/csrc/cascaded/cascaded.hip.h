@@ -259,6 +259,7 @@ __device__ __forceinline__ uint32_t count_heads(const T* A, uint32_t c)
 
 /* RLE of A[0..c) -> values in B, run lengths in runs; returns the new count. */
 template <typename T>
+/* B == A is allowed (compaction in place). */
 __device__ __forceinline__ uint32_t rle_encode(const T* A, uint32_t c, T* B, uint16_t* runs, uint32_t cap)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
@@ -275,6 +276,7 @@ __device__ __forceinline__ uint32_t rle_encode(const T* A, uint32_t c, T* B, uin
     if (m + wave::popc64(mask) > cap) {
       return kRleOverflow; /* more runs than B / runs can hold: the caller retries with a larger LDS slice */
     }
+    wave::sync(); /* B may be A (in place: outputs land at or below the positions just read) */
     if (head) {
       B[m + rank] = v;
       runs[m + rank] = (uint16_t)i;
@@ -436,59 +438,40 @@ __device__ __forceinline__ uint32_t compress_sub(
   uint32_t* counts = meta->counts;
   uint32_t* run_off = meta->run_off;
   uint32_t* ident = meta->ident;
-  /* Layer 0 reads the input from HBM and the two value buffers hold layer outputs, `cap` elements each. A layer
-   * whose output does not fit is either hopeless for this slice (kSubNeedsLds) or found no runs at all: then it is
-   * the identity (values pass through, all run lengths 1), uses no LDS and, with bit-packing, its run stream is
-   * just a header. After an identity layer 0 the input is staged whole as soon as something has to modify it. */
+  /* One value buffer V of n elements and the run pools behind it. Layer 0 reads the input from HBM and compacts
+   * it into V; later layers compact V in place. A layer that finds no runs is the identity: its runs are dropped
+   * and, with bit-packing, its run stream is just a header (the bytes are what the general path would write).
+   * kSubNeedsLds when V or the run pool does not fit `budget`. */
   const bool can_skip = p.use_bp != 0;
   uint8_t* area = lds + meta_bytes;
   const uint32_t area_bytes = budget - meta_bytes;
-  uint32_t cap = (area_bytes / (2 * w + 2 * (rl ? rl : 1))) & ~7u;
-  cap = cap > n ? ((n + 7u) & ~7u) : cap;
-  uint32_t val_bytes = (cap * w + 15u) & ~15u;
-  if (2 * val_bytes + 2 * rl * cap > area_bytes) {
-    cap = cap >= 8 ? cap - 8 : 0;
-    val_bytes = (cap * w + 15u) & ~15u;
+  const uint32_t v_bytes = (n * w + 15u) & ~15u;
+  if (v_bytes > area_bytes) {
+    return kSubNeedsLds;
   }
-  T* free_buf = (T*)area;
-  T* other_buf = (T*)(area + val_bytes);
-  uint16_t* pool = (uint16_t*)(area + 2 * val_bytes);
+  T* V = (T*)area;
+  uint16_t* pool = (uint16_t*)(area + v_bytes);
+  const uint32_t pool_cap = (area_bytes - v_bytes) / 2;
   uint32_t c = n;
   uint32_t pool_used = 0;
-  const T* cur = in; /* HBM until a layer encodes it or a delta stages it */
-  bool cur_in_hbm = true;
+  const T* cur = in; /* HBM until layer 0 (or a delta) has put the data into V */
   for (uint32_t l = 0; l < layers; ++l) {
     if (l < rl) {
-      uint32_t m = cap ? rle_encode(cur, c, free_buf, pool + pool_used, cap) : kRleOverflow;
-      bool id = false;
+      const uint32_t m = rle_encode(cur, c, V, pool + pool_used, pool_cap - pool_used);
+      bool id;
       if (m == kRleOverflow) {
-        if (!(can_skip && count_heads(cur, c) == c)) {
+        /* a partial compaction may have overwritten the head of V: only an input still in HBM can be recounted */
+        if (!(can_skip && cur == in && count_heads(cur, c) == c)) {
           return kSubNeedsLds;
         }
         id = true;
-        if (cur_in_hbm) {
-          /* re-carve: one buffer for the staged input, what is left for one more value buffer and the pools */
-          const uint32_t stage_bytes = (n * w + 15u) & ~15u;
-          if (stage_bytes > area_bytes) {
-            return kSubNeedsLds;
-          }
-          cap = ((area_bytes - stage_bytes) / (w + 2 * rl)) & ~7u;
-          cap = cap > n ? ((n + 7u) & ~7u) : cap;
-          if (cap && stage_bytes + ((cap * w + 15u) & ~15u) + 2 * rl * cap > area_bytes) {
-            cap -= 8;
-          }
-          free_buf = (T*)(area + stage_bytes);
-          other_buf = (T*)area; /* free once a real layer has consumed the staged input */
-          pool = (uint16_t*)(area + stage_bytes + ((cap * w + 15u) & ~15u));
-        }
       } else {
-        c = m;
-        pool_used += c;
-        cur = free_buf;
-        cur_in_hbm = false;
-        T* t = free_buf;
-        free_buf = other_buf;
-        other_buf = t;
+        id = can_skip && m == c; /* no runs: V holds the values unchanged, the runs (all 1) are dropped */
+        cur = V;
+        if (!id) {
+          c = m;
+          pool_used += m;
+        }
       }
       if (lane == 0) {
         ident[l] = id ? 1u : 0u;
@@ -498,24 +481,14 @@ __device__ __forceinline__ uint32_t compress_sub(
       wave::sync();
     }
     if (l < p.num_deltas) {
-      if (cur_in_hbm) { /* nothing but identity layers (or none) so far: stage the input */
-        if (((n * w + 15u) & ~15u) > area_bytes) {
-          return kSubNeedsLds;
-        }
-        T* staged = (T*)area;
+      if (cur == in) { /* nothing has moved the data into V yet */
         for (uint32_t i = lane; i < n; i += 64) {
-          staged[i] = in[i];
+          V[i] = in[i];
         }
         wave::sync();
-        cur = staged;
-        cur_in_hbm = false;
-        if (rl == 0 || free_buf == staged) { /* no re-carve happened (delta-only cascade): keep the staged buffer apart */
-          free_buf = (T*)(area + ((n * w + 15u) & ~15u));
-          other_buf = staged;
-          cap = 0;
-        }
+        cur = V;
       }
-      delta_encode((T*)cur, c);
+      delta_encode(V, c);
     }
   }
   wave::sync();
@@ -744,23 +717,18 @@ __device__ __forceinline__ uint32_t decompress_sub(
   return kSubOk;
 }
 
-/* LDS bytes one wave needs for a given configuration (host + device agree). */
-__host__ __device__ inline uint32_t lds_bytes_per_wave(uint32_t sub_bytes, uint32_t width, uint32_t num_rles)
-{
-  const uint32_t n = sub_bytes / width;
-  const uint32_t vals = (sub_bytes + 15u) & ~15u;
-  const uint32_t rl = num_rles ? num_rles : 1;
-  const uint32_t pool = (2u * n * rl + 15u) & ~15u;
-  const uint32_t marks = (2u * n + 15u) & ~15u;
-  return 2 * vals + pool + marks + 192; /* + LayerMeta */
-}
-
-/* Worst case of compress_sub: LayerMeta, two value buffers of n elements, num_rles run pools of n entries. */
+/* Worst case of compress_sub: LayerMeta, the value buffer of n elements, num_rles run pools of n entries. */
 __host__ __device__ inline uint32_t compress_lds_per_wave(uint32_t sub_bytes, uint32_t width, uint32_t num_rles)
 {
   const uint32_t n = sub_bytes / width;
-  const uint32_t cap = (n + 7u) & ~7u;
-  return ((uint32_t)((sizeof(LayerMeta) + 15u) & ~15u)) + 2 * ((cap * width + 15u) & ~15u) + 2 * num_rles * cap + 32;
+  return ((uint32_t)((sizeof(LayerMeta) + 15u) & ~15u)) + ((sub_bytes + 15u) & ~15u) + ((2 * num_rles * n + 15u) & ~15u);
+}
+
+/* Worst case of decompress_sub: LayerMeta, two value buffers, the run pools, the marks of an expansion. */
+__host__ __device__ inline uint32_t decompress_lds_per_wave(uint32_t sub_bytes, uint32_t width, uint32_t num_rles)
+{
+  const uint32_t n = sub_bytes / width;
+  return compress_lds_per_wave(sub_bytes, width, num_rles) + ((sub_bytes + 15u) & ~15u) + (num_rles ? ((2 * n + 15u) & ~15u) : 0u);
 }
 
 } // namespace casc
