@@ -199,22 +199,45 @@ __device__ __forceinline__ bool unpack_stream(const uint8_t* src, uint32_t avail
   }
   const uint64_t wmask = width_mask(w);
   const uint64_t vmask = bits == 64 ? ~0ull : ((1ull << bits) - 1);
-  for (uint32_t i = lane; i < count; i += 64) {
-    uint64_t x = 0;
-    if (bits) {
-      const uint64_t bit = (uint64_t)i * bits;
-      const uint32_t k = (uint32_t)(bit / 32);
-      const uint32_t sh = (uint32_t)(bit % 32);
-      x = (uint64_t)in[3 + k] >> sh;
-      if (sh + bits > 32) {
-        x |= (uint64_t)in[3 + k + 1] << (32 - sh);
+  /* 4 tiles per step: their (up to 12) loads are issued together -- one memory round trip instead of four */
+  for (uint32_t base = 0; base < count; base += 256) {
+    uint32_t w0[4], w1[4], w2[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      const uint32_t i = base + 64 * u + lane;
+      w0[u] = w1[u] = w2[u] = 0;
+      if (bits && i < count) {
+        const uint64_t bit = (uint64_t)i * bits;
+        const uint32_t k = (uint32_t)(bit / 32);
+        const uint32_t sh = (uint32_t)(bit % 32);
+        w0[u] = in[3 + k];
+        if (sh + bits > 32) {
+          w1[u] = in[3 + k + 1];
+        }
+        if (sh + bits > 64) {
+          w2[u] = in[3 + k + 2];
+        }
       }
-      if (sh + bits > 64) {
-        x |= (uint64_t)in[3 + k + 2] << (64 - sh);
-      }
-      x &= vmask;
     }
-    dst[i] = (T)((x + mn) & wmask);
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      const uint32_t i = base + 64 * u + lane;
+      if (i < count) {
+        uint64_t x = 0;
+        if (bits) {
+          const uint32_t sh = (uint32_t)(((uint64_t)i * bits) % 32);
+          x = (uint64_t)w0[u] >> sh;
+          if (sh + bits > 32) {
+            x |= (uint64_t)w1[u] << (32 - sh);
+          }
+          if (sh + bits > 64) {
+            x |= (uint64_t)w2[u] << (64 - sh);
+          }
+          x &= vmask;
+        }
+        dst[i] = (T)((x + mn) & wmask);
+      }
+    }
   }
   used = 12 + 4 * words;
   return true;
@@ -264,24 +287,35 @@ __device__ __forceinline__ uint32_t rle_encode(const T* A, uint32_t c, T* B, uin
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   uint32_t m = 0;
-  /* pass 1: compact run starts; runs[] temporarily holds the start index of each run */
-  for (uint32_t base = 0; base < c; base += 64) {
-    const uint32_t i = base + lane;
-    const bool in = i < c;
-    const T v = in ? A[i] : (T)0;
-    const T prev = (in && i > 0) ? A[i - 1] : (T)0;
-    const bool head = in && (i == 0 || v != prev);
-    const uint64_t mask = wave::ballot(head);
-    const uint32_t rank = wave::popc64(mask & ((1ull << lane) - 1));
-    if (m + wave::popc64(mask) > cap) {
-      return kRleOverflow; /* more runs than B / runs can hold: the caller retries with a larger LDS slice */
+  /* pass 1: compact run starts; runs[] temporarily holds the start index of each run. 4 tiles per step: their
+   * loads (the input may be HBM) are issued together, the compaction itself stays tile by tile. */
+  for (uint32_t base4 = 0; base4 < c; base4 += 256) {
+    T v4[4], p4[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      const uint32_t i = base4 + 64 * u + lane;
+      v4[u] = i < c ? A[i] : (T)0;
+      p4[u] = (i < c && i > 0) ? A[i - 1] : (T)0;
     }
-    wave::sync(); /* B may be A (in place: outputs land at or below the positions just read) */
-    if (head) {
-      B[m + rank] = v;
-      runs[m + rank] = (uint16_t)i;
+    wave::sync(); /* B may be A (in place): everything this step reads has been read; outputs land at or below it */
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      const uint32_t i = base4 + 64 * u + lane;
+      const bool in = i < c;
+      const T v = v4[u];
+      const bool head = in && (i == 0 || v != p4[u]);
+      const uint64_t mask = wave::ballot(head);
+      const uint32_t rank = wave::popc64(mask & ((1ull << lane) - 1));
+      if (m + wave::popc64(mask) > cap) {
+        return kRleOverflow; /* more runs than B / runs can hold: the caller retries with a larger LDS slice */
+      }
+      if (head) {
+        B[m + rank] = v;
+        runs[m + rank] = (uint16_t)i;
+      }
+      m += wave::popc64(mask);
     }
-    m += wave::popc64(mask);
+    wave::sync();
   }
   wave::sync();
   /* pass 2: start indices -> run lengths (start of the next run minus own start) */
@@ -321,62 +355,113 @@ __device__ __forceinline__ void delta_encode(T* A, uint32_t c)
   }
 }
 
-/* in place inclusive prefix sum (inverse delta) */
+/* wave-wide inclusive scan helpers in T's arithmetic, plus the value of lane 63 */
+template <typename T>
+__device__ __forceinline__ uint64_t scan_add_t(uint64_t v)
+{
+  return sizeof(T) <= 4 ? (uint64_t)wave::scan_add_inclusive((uint32_t)v) : scan_add64(v);
+}
+
+template <typename T>
+__device__ __forceinline__ uint64_t last_lane_t(uint64_t v)
+{
+  if (sizeof(T) <= 4) {
+    return (uint64_t)wave::read_lane((uint32_t)v, 63);
+  }
+  return ((uint64_t)wave::read_lane((uint32_t)(v >> 32), 63) << 32) | wave::read_lane((uint32_t)v, 63);
+}
+
+/* in place inclusive prefix sum (inverse delta). A lane owns 4 consecutive elements per step, so a step of 256
+ * elements costs one wave scan: the decoder is bound by its chains of dependent LDS accesses and scans, not by
+ * instruction count, and this cuts the chain 4x. */
 template <typename T>
 __device__ __forceinline__ void delta_decode(T* A, uint32_t c)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
+  if (c <= 64) { /* a well-compressed layer: one element per lane, one scan */
+    const uint64_t v = lane < c ? (uint64_t)A[lane] : 0;
+    const uint64_t incl = scan_add_t<T>(sizeof(T) <= 4 ? (uint64_t)(uint32_t)v : v);
+    wave::sync();
+    if (lane < c) {
+      A[lane] = (T)incl;
+    }
+    wave::sync();
+    return;
+  }
   uint64_t carry = 0;
-  for (uint32_t base = 0; base < c; base += 64) {
-    const uint32_t i = base + lane;
-    const uint64_t v = i < c ? (uint64_t)A[i] : 0;
-    uint64_t s;
-    if (sizeof(T) <= 4) {
-      s = (uint64_t)wave::scan_add_inclusive((uint32_t)v);
-    } else {
-      s = scan_add64(v);
+  for (uint32_t base = 0; base < c; base += 256) {
+    const uint32_t i0 = base + 4 * lane;
+    uint64_t v[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      v[k] = i0 + k < c ? (uint64_t)A[i0 + k] : 0;
     }
-    s += carry;
-    if (i < c) {
-      A[i] = (T)s;
+    v[1] += v[0];
+    v[2] += v[1];
+    v[3] += v[2];
+    const uint64_t incl = scan_add_t<T>(sizeof(T) <= 4 ? (uint64_t)(uint32_t)v[3] : v[3]);
+    const uint64_t before = incl - v[3] + carry;
+    wave::sync();
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      if (i0 + k < c) {
+        A[i0 + k] = (T)(v[k] + before);
+      }
     }
-    /* carry = total of this tile (lane 63's inclusive sum) */
-    if (sizeof(T) <= 4) {
-      carry = (uint64_t)wave::read_lane((uint32_t)s, 63);
-    } else {
-      carry = ((uint64_t)wave::read_lane((uint32_t)(s >> 32), 63) << 32) | wave::read_lane((uint32_t)s, 63);
-    }
+    carry += last_lane_t<T>(incl);
   }
   wave::sync();
 }
 
-/* Expand values A[0..c) with run lengths runs[0..c) into B[0..target).
- * marks: LDS scratch of `target` uint16. Returns false if the runs are inconsistent. */
+/* Expand values A[0..c) with run lengths runs[0..c) into B[0..target) (B may be HBM).
+ * marks: LDS scratch of `target` uint16 (rounded up to 4). Returns false if the runs are inconsistent.
+ * 4 consecutive entries per lane and step, as in delta_decode. */
 template <typename T>
 __device__ __forceinline__ bool rle_decode(const T* A, const uint16_t* runs, uint32_t c, T* B, uint32_t target,
                                            uint16_t* marks)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
-  for (uint32_t i = lane; i < target; i += 64) {
-    marks[i] = 0;
+  for (uint32_t i = lane; i < (target + 1) / 2; i += 64) {
+    ((uint32_t*)marks)[i] = 0;
   }
   wave::sync();
   /* exclusive scan of run lengths -> start of every run; mark it with (run index + 1) */
   uint32_t carry = 0;
   bool bad = false;
-  for (uint32_t base = 0; base < c; base += 64) {
-    const uint32_t j = base + lane;
-    const uint32_t r = j < c ? runs[j] : 0;
-    const uint32_t incl = wave::scan_add_inclusive(r) + carry;
-    const uint32_t start = incl - r;
-    if (j < c) {
+  if (c <= 64) { /* few runs: one per lane */
+    const uint32_t r = lane < c ? runs[lane] : 0;
+    const uint32_t incl = wave::scan_add_inclusive(r);
+    if (lane < c) {
       if (r == 0 || incl > target) {
         bad = true;
       } else {
-        marks[start] = (uint16_t)(j + 1);
+        marks[incl - r] = (uint16_t)(lane + 1);
       }
     }
     carry = wave::read_lane(incl, 63);
+  }
+  for (uint32_t base = 0; c > 64 && base < c; base += 256) {
+    const uint32_t j0 = base + 4 * lane;
+    uint32_t r[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      r[k] = j0 + k < c ? runs[j0 + k] : 0;
+    }
+    const uint32_t mine = r[0] + r[1] + r[2] + r[3];
+    const uint32_t incl = wave::scan_add_inclusive(mine);
+    uint32_t start = incl - mine + carry;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      if (j0 + k < c) {
+        if (r[k] == 0 || start + r[k] > target) {
+          bad = true;
+        } else {
+          marks[start] = (uint16_t)(j0 + k + 1);
+        }
+      }
+      start += r[k];
+    }
+    carry += wave::read_lane(incl, 63);
   }
   if (wave::ballot(bad) || carry != target) {
     return false;
@@ -384,15 +469,30 @@ __device__ __forceinline__ bool rle_decode(const T* A, const uint16_t* runs, uin
   wave::sync();
   /* running maximum of the marks = index of the run every output element belongs to */
   uint32_t run_carry = 0;
-  for (uint32_t base = 0; base < target; base += 64) {
-    const uint32_t i = base + lane;
-    const uint32_t mk = i < target ? marks[i] : 0;
-    uint32_t run = wave::scan_max_inclusive(mk);
-    run = run > run_carry ? run : run_carry;
-    if (i < target) {
-      B[i] = A[run - 1];
+  for (uint32_t base = 0; base < target; base += 256) {
+    const uint32_t i0 = base + 4 * lane;
+    uint32_t mk[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      mk[k] = i0 + k < target ? marks[i0 + k] : 0;
     }
-    run_carry = wave::read_lane(run, 63);
+    mk[1] = mk[1] > mk[0] ? mk[1] : mk[0];
+    mk[2] = mk[2] > mk[1] ? mk[2] : mk[1];
+    mk[3] = mk[3] > mk[2] ? mk[3] : mk[2];
+    const uint32_t incl = wave::scan_max_inclusive(mk[3]);
+    /* maximum over the lanes before this one = the inclusive maximum of the lane below */
+    uint32_t before = wave::shuffle(incl, (lane - 1) & 63u);
+    before = lane == 0 ? 0u : before;
+    before = before > run_carry ? before : run_carry;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      if (i0 + k < target) {
+        const uint32_t run = mk[k] > before ? mk[k] : before;
+        B[i0 + k] = A[run - 1];
+      }
+    }
+    const uint32_t last = wave::read_lane(incl, 63);
+    run_carry = last > run_carry ? last : run_carry;
   }
   wave::sync();
   return true;
