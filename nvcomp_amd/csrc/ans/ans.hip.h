@@ -184,12 +184,19 @@ __device__ __forceinline__ uint32_t encode_chunk(
   wave::sync();
   uint32_t* hist = table + 256 * (lane % kHistCopies);
   const uint32_t groups = (n + 255) / 256;
-  for (uint32_t q = 0; q < groups; ++q) {
-    const uint32_t v = load_group_dword(src, n, 256 * q, lane);
+  for (uint32_t q0 = 0; q0 < groups; q0 += 4) { /* 4 groups of loads in flight */
+    uint32_t v4[4];
 #pragma unroll
-    for (uint32_t r = 0; r < 4; ++r) {
-      if (256 * q + 4 * lane + r < n) {
-        atomicAdd(&hist[(v >> (8 * r)) & 255u], 1u);
+    for (uint32_t u = 0; u < 4; ++u) {
+      v4[u] = q0 + u < groups ? load_group_dword(src, n, 256 * (q0 + u), lane) : 0u;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+#pragma unroll
+      for (uint32_t r = 0; r < 4; ++r) {
+        if (256 * (q0 + u) + 4 * lane + r < n) {
+          atomicAdd(&hist[(v4[u] >> (8 * r)) & 255u], 1u);
+        }
       }
     }
   }
@@ -222,8 +229,14 @@ __device__ __forceinline__ uint32_t encode_chunk(
   uint8_t* words = dst + kWordsOffset;
   uint32_t x = kStateLow;
   uint32_t p = 0;
+  /* the input dword of the next group (q - 1) is fetched while this one is coded: the load never sits on the
+   * dependent chain of the states */
+  uint32_t v_next = load_group_dword(src, n, 256 * (groups - 1), lane);
   for (uint32_t q = groups; q-- > 0;) {
-    const uint32_t v = load_group_dword(src, n, 256 * q, lane);
+    const uint32_t v = v_next;
+    if (q > 0) {
+      v_next = load_group_dword(src, n, 256 * (q - 1), lane);
+    }
 #pragma unroll
     for (uint32_t rr = 0; rr < 4; ++rr) {
       const uint32_t r = 3 - rr;
