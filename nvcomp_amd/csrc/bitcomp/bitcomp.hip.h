@@ -13,7 +13,9 @@
  *                    D x 64 dwords, D = ceil(sum(widths) / 32)
  *   tail   := the n_bytes % S bytes that do not form an element, raw
  *
- * Row r of a block holds elements 64 r + l, l = lane. Its values (algo 0: zigzag of the
+ * For 4- and 8-byte elements row r of a block holds elements 64 r + l, l = lane; for 1- and 2-byte elements a
+ * lane owns E = 4 / S consecutive elements of a row (a dword), so a row is 64 E elements, a block 2048 E, and the
+ * lane's bit string carries its E values of a row one after the other. Its values (algo 0: zigzag of the
  * difference to the previous element of the chunk, modulo 2^(8S); algo 1: the element
  * itself) are stored with width[r] = bits of the row's largest value. Lane l owns its own
  * bit string -- its value of row 0, then row 1, ... LSB first -- cut into dwords; dword k
@@ -39,19 +41,27 @@ constexpr uint32_t kErrNone = 0;
 constexpr uint32_t kErrInput = 1;
 constexpr uint32_t kErrOutput = 2;
 
+/* elements of one lane in one row: a dword's worth for 1- and 2-byte types */
+__host__ __device__ inline uint32_t lane_elems(uint32_t elem_size)
+{
+  return elem_size < 4 ? 4 / elem_size : 1;
+}
+
 /* Worst case: every row at full width. Host and device. */
 __host__ __device__ inline size_t block_bound(size_t rows, uint32_t elem_size)
 {
-  return ((rows + 3) & ~(size_t)3) + (rows * 8 * elem_size + 31) / 32 * 256;
+  return ((rows + 3) & ~(size_t)3) + (rows * 8 * elem_size * lane_elems(elem_size) + 31) / 32 * 256;
 }
 
 __host__ __device__ inline size_t max_compressed_bytes(size_t n, uint32_t elem_size)
 {
   const size_t nelem = n / elem_size;
-  const size_t full = nelem / kBlockElems;
-  const size_t rest = nelem % kBlockElems;
-  return kHeaderBytes + full * block_bound(kRows, elem_size) + (rest ? block_bound((rest + 63) / 64, elem_size) : 0)
-         + n % elem_size;
+  const size_t row_elems = 64 * lane_elems(elem_size);
+  const size_t block_elems = row_elems * kRows;
+  const size_t full = nelem / block_elems;
+  const size_t rest = nelem % block_elems;
+  return kHeaderBytes + full * block_bound(kRows, elem_size)
+         + (rest ? block_bound((rest + row_elems - 1) / row_elems, elem_size) : 0) + n % elem_size;
 }
 
 template <class T>
@@ -161,6 +171,22 @@ struct BitWriter
   }
 };
 
+template <class T>
+struct PackedRow
+{
+  using type = T;
+};
+template <>
+struct PackedRow<uint8_t>
+{
+  using type = uint32_t;
+};
+template <>
+struct PackedRow<uint16_t>
+{
+  using type = uint32_t;
+};
+
 template <class T, bool DELTA>
 __device__ __forceinline__ uint32_t encode_chunk(const uint8_t* __restrict__ src, uint32_t n, uint8_t* __restrict__ dst)
 {
@@ -178,27 +204,68 @@ __device__ __forceinline__ uint32_t encode_chunk(const uint8_t* __restrict__ src
     dst[7] = 0;
     store_elem<uint32_t>(dst + 8, n);
   }
+  constexpr uint32_t E = S < 4 ? 4 / S : 1; /* elements of a lane per row */
+  constexpr uint32_t kRowElems = 64 * E;
+  constexpr uint32_t kBlock = kRowElems * kRows;
+  using Z = typename PackedRow<T>::type; /* a lane's values of one row: the element itself, or E small ones in a dword */
   uint32_t op = kHeaderBytes;
-  for (uint32_t base = 0; base < nelem; base += kBlockElems) {
-    const uint32_t count = nelem - base < kBlockElems ? nelem - base : kBlockElems;
-    const uint32_t rows = (count + 63) / 64;
-    T z[kRows];
+  for (uint32_t base = 0; base < nelem; base += kBlock) {
+    const uint32_t count = nelem - base < kBlock ? nelem - base : kBlock;
+    const uint32_t rows = (count + kRowElems - 1) / kRowElems;
+    Z z[kRows];
     uint32_t widths = 0; /* lane r: width of row r */
 #pragma unroll
     for (uint32_t r = 0; r < kRows; ++r) {
       z[r] = 0;
       if (r < rows) {
-        const uint32_t i = base + 64 * r + lane;
-        if (i < nelem) {
-          const T e = load_elem<T>(src + (size_t)i * S);
-          if (DELTA) {
-            const T prev = i ? load_elem<T>(src + (size_t)(i - 1) * S) : (T)0;
-            z[r] = zigzag<T>((T)(e - prev));
-          } else {
-            z[r] = e;
+        const uint32_t i = base + kRowElems * r + E * lane;
+        uint32_t width_here = 0;
+        if (E == 1) {
+          if (i < nelem) {
+            const T e = load_elem<T>(src + (size_t)i * S);
+            if (DELTA) {
+              const T prev = i ? load_elem<T>(src + (size_t)(i - 1) * S) : (T)0;
+              z[r] = (Z)zigzag<T>((T)(e - prev));
+            } else {
+              z[r] = (Z)e;
+            }
           }
+          width_here = bit_width<T>((T)z[r]);
+        } else {
+          /* E elements from one dword; their predecessors from the dword one element earlier */
+          uint32_t packed = 0;
+          if (i + E <= nelem) {
+            const uint32_t v = load_elem<uint32_t>(src + (size_t)i * S);
+            uint32_t pv = 0;
+            if (DELTA) {
+              pv = i ? load_elem<uint32_t>(src + (size_t)(i - 1) * S) : v << (8 * S);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < E; ++k) {
+              const T e = (T)(v >> (8 * S * k));
+              const T zz = DELTA ? zigzag<T>((T)(e - (T)(pv >> (8 * S * k)))) : e;
+              packed |= (uint32_t)zz << (8 * S * k);
+            }
+          } else {
+#pragma unroll
+            for (uint32_t k = 0; k < E; ++k) {
+              if (i + k < nelem) {
+                const T e = load_elem<T>(src + (size_t)(i + k) * S);
+                const T prev = (DELTA && i + k) ? load_elem<T>(src + (size_t)(i + k - 1) * S) : (T)0;
+                const T zz = DELTA ? zigzag<T>((T)(e - prev)) : e;
+                packed |= (uint32_t)zz << (8 * S * k);
+              }
+            }
+          }
+          z[r] = (Z)packed;
+          uint32_t any = packed; /* the OR of the E values has the width of the largest */
+#pragma unroll
+          for (uint32_t k = 1; k < E; ++k) {
+            any |= packed >> (8 * S * k);
+          }
+          width_here = bit_width<T>((T)any);
         }
-        const uint32_t w = wave::reduce_max(bit_width<T>(z[r]));
+        const uint32_t w = wave::reduce_max(width_here);
         widths = lane == r ? w : widths;
       }
     }
@@ -229,8 +296,13 @@ __device__ __forceinline__ uint32_t encode_chunk(const uint8_t* __restrict__ src
           if (w > 32) {
             bw.put((uint32_t)(v >> 32), w - 32);
           }
-        } else {
+        } else if (E == 1) {
           bw.put((uint32_t)z[r], w);
+        } else {
+#pragma unroll
+          for (uint32_t k = 0; k < E; ++k) {
+            bw.put((uint32_t)(T)((uint32_t)z[r] >> (8 * S * k)), w);
+          }
         }
       }
     }
@@ -252,13 +324,16 @@ __device__ __forceinline__ uint32_t decode_body(
 {
   constexpr uint32_t S = sizeof(T);
   constexpr uint32_t W = 8 * S;
+  constexpr uint32_t E = S < 4 ? 4 / S : 1; /* elements of a lane per row */
+  constexpr uint32_t kRowElems = 64 * E;
+  constexpr uint32_t kBlock = kRowElems * kRows;
   const uint32_t lane = (uint32_t)wave::lane_id();
   const uint32_t nelem = n / S;
   uint32_t ip = kHeaderBytes;
   T carry = 0;
-  for (uint32_t base = 0; base < nelem; base += kBlockElems) {
-    const uint32_t count = nelem - base < kBlockElems ? nelem - base : kBlockElems;
-    const uint32_t rows = (count + 63) / 64;
+  for (uint32_t base = 0; base < nelem; base += kBlock) {
+    const uint32_t count = nelem - base < kBlock ? nelem - base : kBlock;
+    const uint32_t rows = (count + kRowElems - 1) / kRowElems;
     if (CHECKED && (ip > in_len || in_len - ip < 4)) {
       err = kErrInput;
       return 0;
@@ -274,7 +349,7 @@ __device__ __forceinline__ uint32_t decode_body(
       err = kErrInput;
       return 0;
     }
-    const uint32_t total_bits = wave::reduce_add(widths);
+    const uint32_t total_bits = E * wave::reduce_add(widths);
     const uint32_t dwords = (total_bits + 31) / 32;
     const uint8_t* payload = in + ip + wbytes;
     if (CHECKED && (in_len - ip - wbytes) / 256u < dwords) {
@@ -284,10 +359,10 @@ __device__ __forceinline__ uint32_t decode_body(
     ip += wbytes + dwords * 256u;
 
     uint64_t acc = 0;
-    uint32_t fill = 0; /* uniform */
-    uint32_t row = 0;  /* uniform */
-    uint32_t part = 0; /* uniform; 64-bit elements are taken in two parts */
-    uint32_t lo = 0;
+    uint32_t fill = 0;   /* uniform */
+    uint32_t row = 0;    /* uniform */
+    uint32_t part = 0;   /* uniform: a 64-bit element is taken in two parts, a small-type row in E */
+    uint32_t held = 0;   /* the parts taken so far */
     uint32_t w = wave::read_lane(widths, 0);
 
     /* take every value that is complete in the accumulator */
@@ -306,27 +381,74 @@ __device__ __forceinline__ uint32_t decode_body(
         const uint32_t bits = (uint32_t)(acc & ((1ull << need) - 1ull));
         acc >>= need;
         fill -= need;
-        T v;
         if (S == 8) {
           if (part == 0) {
-            lo = bits;
+            held = bits;
             part = 1;
             continue;
           }
           part = 0;
-          v = (T)(((uint64_t)bits << 32) | lo);
+          const T v = (T)(((uint64_t)bits << 32) | held);
+          T e = v;
+          if (DELTA) {
+            const T incl = (T)(scan_add<T>(unzigzag<T>(v)) + carry);
+            carry = last_lane<T>(incl);
+            e = incl;
+          }
+          const uint32_t i = base + 64 * row + lane;
+          if (i < nelem) {
+            store_elem<T>(out + (size_t)i * S, e);
+          }
+        } else if (E == 1) {
+          const T v = (T)bits;
+          T e = v;
+          if (DELTA) {
+            const T incl = (T)(scan_add<T>(unzigzag<T>(v)) + carry);
+            carry = last_lane<T>(incl);
+            e = incl;
+          }
+          const uint32_t i = base + 64 * row + lane;
+          if (i < nelem) {
+            store_elem<T>(out + (size_t)i * S, e);
+          }
         } else {
-          v = (T)bits;
-        }
-        T e = v;
-        if (DELTA) {
-          const T incl = (T)(scan_add<T>(unzigzag<T>(v)) + carry);
-          carry = last_lane<T>(incl);
-          e = incl;
-        }
-        const uint32_t i = base + 64 * row + lane;
-        if (i < nelem) {
-          store_elem<T>(out + (size_t)i * S, e);
+          held |= bits << (8 * S * part);
+          if (part + 1 < E) {
+            ++part;
+            continue;
+          }
+          /* the lane's E values of this row are complete */
+          uint32_t vals = held;
+          held = 0;
+          part = 0;
+          if (DELTA) {
+            uint32_t sum[E];
+            uint32_t run = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < E; ++k) {
+              run += (uint32_t)unzigzag<T>((T)(vals >> (8 * S * k)));
+              sum[k] = run;
+            }
+            const uint32_t incl = wave::scan_add_inclusive(run & ((1u << W) - 1u));
+            const uint32_t before = incl - (run & ((1u << W) - 1u)) + (uint32_t)carry;
+            vals = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < E; ++k) {
+              vals |= (uint32_t)(T)(before + sum[k]) << (8 * S * k);
+            }
+            carry = (T)(wave::read_lane(incl, 63) + (uint32_t)carry);
+          }
+          const uint32_t i = base + kRowElems * row + E * lane;
+          if (i + E <= nelem) {
+            store_elem<uint32_t>(out + (size_t)i * S, vals);
+          } else {
+#pragma unroll
+            for (uint32_t k = 0; k < E; ++k) {
+              if (i + k < nelem) {
+                store_elem<T>(out + (size_t)(i + k) * S, (T)(vals >> (8 * S * k)));
+              }
+            }
+          }
         }
         ++row;
         w = wave::read_lane(widths, row & 63u);

@@ -18,7 +18,12 @@
 
 #define BC_HEADER 12
 #define BC_ROWS 32
-#define BC_BLOCK (64 * BC_ROWS)
+
+/* elements of one lane in one row: a dword's worth for 1- and 2-byte elements */
+static unsigned bc_lane_elems(unsigned s)
+{
+  return s < 4 ? 4 / s : 1;
+}
 
 static uint64_t bc_load(const uint8_t* p, unsigned s)
 {
@@ -54,15 +59,18 @@ static unsigned bc_pad4(unsigned n)
 
 static size_t bc_block_bound(size_t rows, size_t s)
 {
-  return ((rows + 3) & ~(size_t)3) + (rows * 8 * s + 31) / 32 * 256;
+  return ((rows + 3) & ~(size_t)3) + (rows * 8 * s * bc_lane_elems((unsigned)s) + 31) / 32 * 256;
 }
 
 size_t oracle_bitcomp_max_compressed(size_t n, int elem_size)
 {
   const size_t s = (size_t)elem_size;
   const size_t nelem = n / s;
-  const size_t full = nelem / BC_BLOCK, rest = nelem % BC_BLOCK;
-  return BC_HEADER + full * bc_block_bound(BC_ROWS, s) + (rest ? bc_block_bound((rest + 63) / 64, s) : 0) + n % s;
+  const size_t row_elems = 64 * bc_lane_elems((unsigned)s);
+  const size_t block = row_elems * BC_ROWS;
+  const size_t full = nelem / block, rest = nelem % block;
+  return BC_HEADER + full * bc_block_bound(BC_ROWS, s) + (rest ? bc_block_bound((rest + row_elems - 1) / row_elems, s) : 0)
+         + n % s;
 }
 
 /* value of element i as it is packed: algo 0 = zigzag(e[i] - e[i-1]) in W bits, algo 1 = e[i] */
@@ -125,23 +133,26 @@ size_t oracle_bitcomp_compress(const uint8_t* src, size_t n, uint8_t* dst, size_
   dst[6] = 0;
   dst[7] = 0;
   bc_store(dst + 8, n, 4);
+  const unsigned E = bc_lane_elems(s);
+  const size_t row_elems = 64 * (size_t)E;
+  const size_t block = row_elems * BC_ROWS;
   size_t op = BC_HEADER;
-  for (size_t base = 0; base < nelem; base += BC_BLOCK) {
-    const size_t count = nelem - base < BC_BLOCK ? nelem - base : BC_BLOCK;
-    const unsigned rows = (unsigned)((count + 63) / 64);
+  for (size_t base = 0; base < nelem; base += block) {
+    const size_t count = nelem - base < block ? nelem - base : block;
+    const unsigned rows = (unsigned)((count + row_elems - 1) / row_elems);
     unsigned widths[BC_ROWS];
     uint64_t total = 0;
     for (unsigned r = 0; r < rows; ++r) {
       unsigned w = 0;
-      for (unsigned l = 0; l < 64; ++l) {
-        const size_t i = base + 64 * r + l;
+      for (size_t j = 0; j < row_elems; ++j) {
+        const size_t i = base + row_elems * r + j;
         if (i < nelem) {
           const unsigned x = bc_width(bc_value(src, i, s, algo));
           w = x > w ? x : w;
         }
       }
       widths[r] = w;
-      total += w;
+      total += (uint64_t)w * E; /* bits of one lane's string */
     }
     if (total == 0) { /* zero block marker */
       dst[op] = 0xFF;
@@ -159,11 +170,13 @@ size_t oracle_bitcomp_compress(const uint8_t* src, size_t n, uint8_t* dst, size_
     for (unsigned l = 0; l < 64; ++l) {
       uint64_t pos = 0;
       for (unsigned r = 0; r < rows; ++r) {
-        const size_t i = base + 64 * r + l;
-        if (i < nelem) {
-          bc_put(payload, l, pos, bc_value(src, i, s, algo), widths[r]);
+        for (unsigned k = 0; k < E; ++k) { /* the lane's E consecutive elements of this row */
+          const size_t i = base + row_elems * r + (size_t)E * l + k;
+          if (i < nelem) {
+            bc_put(payload, l, pos, bc_value(src, i, s, algo), widths[r]);
+          }
+          pos += widths[r];
         }
-        pos += widths[r];
       }
     }
     op += wbytes + dwords * 256;
@@ -188,11 +201,14 @@ int oracle_bitcomp_decompress(const uint8_t* src, size_t src_len, uint8_t* dst, 
     return ORACLE_ERR_OUTPUT;
   }
   const size_t nelem = n / s;
+  const unsigned E = bc_lane_elems(s);
+  const size_t row_elems = 64 * (size_t)E;
+  const size_t block = row_elems * BC_ROWS;
   size_t ip = BC_HEADER;
   uint64_t prev = 0;
-  for (size_t base = 0; base < nelem; base += BC_BLOCK) {
-    const size_t count = nelem - base < BC_BLOCK ? nelem - base : BC_BLOCK;
-    const unsigned rows = (unsigned)((count + 63) / 64);
+  for (size_t base = 0; base < nelem; base += block) {
+    const size_t count = nelem - base < block ? nelem - base : block;
+    const unsigned rows = (unsigned)((count + row_elems - 1) / row_elems);
     if (src_len < ip || src_len - ip < 4) {
       return ORACLE_ERR_INPUT;
     }
@@ -210,7 +226,7 @@ int oracle_bitcomp_decompress(const uint8_t* src, size_t src_len, uint8_t* dst, 
         return ORACLE_ERR_INPUT;
       }
       row_pos[r] = total;
-      total += wd[r];
+      total += (uint64_t)wd[r] * E;
     }
     const size_t dwords = (size_t)((total + 31) / 32);
     if ((src_len - ip - wbytes) / 256 < dwords) {
@@ -218,8 +234,8 @@ int oracle_bitcomp_decompress(const uint8_t* src, size_t src_len, uint8_t* dst, 
     }
     const uint8_t* payload = src + ip + wbytes;
     for (size_t j = 0; j < count; ++j) { /* element order */
-      const unsigned r = (unsigned)(j / 64), l = (unsigned)(j % 64);
-      const uint64_t v = bc_get(payload, l, row_pos[r], wd[r]);
+      const unsigned r = (unsigned)(j / row_elems), l = (unsigned)((j % row_elems) / E), k = (unsigned)(j % E);
+      const uint64_t v = bc_get(payload, l, row_pos[r] + (uint64_t)k * wd[r], wd[r]);
       uint64_t e = v;
       if (algo == 0) {
         const uint64_t d = (v >> 1) ^ ((v & 1) ? ~0ull : 0ull);
