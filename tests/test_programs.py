@@ -106,3 +106,29 @@ def test_allgather_program_oversubscribed(built_programs, sample_files):
         out = run(["benchmarks/bin/benchmark_allgather", "-f", sample_files["table.txt"], "-g", "2", "-h", "4", "-c", comp,
                    "--oversubscribe"])
         assert float(out.split()[-1]) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", ["lz4", "snappy", "cascaded", "bitcomp", "ans"])
+def test_bench_contract_on_gpu(algo):
+    """bench.py prints exactly one JSON line with the driver's fields plus `roofline` and `cpu_baseline`, measures
+    through HIP events on its stream and verifies every decoded byte (small workload: 64 MiB per step)."""
+    import json
+    import sys
+
+    r = subprocess.run([sys.executable, "bench.py", "--algo", algo, "--steps", "3", "--warmup", "1", "--mib-per-gpu", "64",
+                        "--unique-mib", "8"], cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in res, key
+    assert res["n_gpus"] == 1 and res["steps"] == 3 and res["warmup"] == 1 and res["unit"] == "GB/s"
+    assert res["value"] > 1.0 and res["config"]["verified"] is True and "workload" in res["config"]
+    roof = res["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0 < roof["frac"] < 1
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    base = res["cpu_baseline"]
+    assert base["value"] > 0 and base["cores"] >= 1 and base["kind"] in ("reference", "port") and base["sample"]
