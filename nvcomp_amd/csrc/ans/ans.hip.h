@@ -7,16 +7,18 @@
  *
  *   chunk := 'A' 'N' 'S' 0x01 | u32 n_bytes | u8 mode | 0 0 0 | body
  *   mode 0 (stored):  body = the n_bytes raw bytes
- *   mode 1 (rANS):    body = u32 n_words | u16 freq[256] (sum 1024) | u32 state[64] | u16 words[n_words]
+ *   mode 1 (rANS):    body = u32 n_words | u16 freq[256] (sum 1024) | u32 state[128] | u16 words[n_words]
  *
- * Symbol i of the chunk belongs to lane (i % 256) / 4 and row 4 (i / 256) + i % 4: a lane
- * codes 4 consecutive bytes of every 256-byte group, so both directions move whole dwords,
- * coalesced over the wave. Every lane runs its own rANS state (32 bit, lower bound 2^16,
- * 10-bit probabilities, 16-bit renormalisation words). The encoder walks the rows from the
- * last to the first; in a row the lanes that must renormalise append their words to the
- * stream in lane order (ballot + prefix count). The decoder starts from the stored states at
- * the end of the word stream and walks the rows forward, taking the same groups back. A
- * chunk is stored when coding would not make it smaller, so no output exceeds n_bytes + 12.
+ * Symbol i of the chunk belongs to lane (i % 256) / 4; a lane codes 4 consecutive bytes of every 256-byte
+ * group, so both directions move whole dwords, coalesced over the wave. Every lane runs TWO rANS states
+ * (32 bit, lower bound 2^16, 10-bit probabilities, 16-bit renormalisation words): state A codes the even
+ * groups, state B the odd ones, and a row of the coder is one byte of an even group and the byte of the odd
+ * group behind it -- two independent dependency chains per lane, which is what hides the LDS latency of the
+ * table lookups (the decoder spent 72 % of its wave cycles waiting with one chain). The encoder walks the
+ * rows from the last to the first; in a row the lanes that must renormalise append their words to the stream,
+ * A's in lane order, then B's (ballot + prefix count). The decoder starts from the stored states at the end
+ * of the word stream and walks the rows forward, taking the same groups back. A chunk is stored when coding
+ * would not make it smaller, so no output exceeds n_bytes + 12.
  *
  * LDS per wave: compress 4 KiB (four histograms, then the symbol table in their place); decompress 4 KiB decode
  * table (one dword per slot: symbol | freq << 8 | (slot - start) << 20) + 1 KiB stream ring +
@@ -40,8 +42,8 @@ constexpr uint32_t kStateLow = 1u << 16;
 constexpr uint32_t kHeaderBytes = 12;
 constexpr uint32_t kFreqOffset = 16;
 constexpr uint32_t kStateOffset = kFreqOffset + 512;
-constexpr uint32_t kWordsOffset = kStateOffset + 256;
-constexpr uint32_t kMinCodedBytes = 1024; /* smaller chunks are always stored */
+constexpr uint32_t kWordsOffset = kStateOffset + 512; /* 64 A states, then 64 B states */
+constexpr uint32_t kMinCodedBytes = 2048; /* smaller chunks are always stored */
 constexpr uint32_t kRingWords = 512;
 constexpr uint32_t kHistCopies = 4; /* the lanes spread their LDS atomics over this many histograms */
 constexpr uint32_t kEncodeLds = 1024 * kHistCopies; /* >= the 2 KiB symbol table that replaces the histograms */
@@ -227,45 +229,63 @@ __device__ __forceinline__ uint32_t encode_chunk(
 
   const uint32_t limit_words = (n + kHeaderBytes - kWordsOffset) / 2; /* coded form must stay below the stored size */
   uint8_t* words = dst + kWordsOffset;
-  uint32_t x = kStateLow;
+  uint32_t xs[2] = {kStateLow, kStateLow}; /* A: even groups, B: odd groups */
   uint32_t p = 0;
-  /* the input dword of the next group (q - 1) is fetched while this one is coded: the load never sits on the
-   * dependent chain of the states */
-  uint32_t v_next = load_group_dword(src, n, 256 * (groups - 1), lane);
-  for (uint32_t q = groups; q-- > 0;) {
-    const uint32_t v = v_next;
+  const uint32_t pairs = (groups + 1) / 2;
+  /* the input dwords of the next pair of groups are fetched while this one is coded */
+  uint32_t v_next[2];
+  v_next[0] = load_group_dword(src, n, 256 * (2 * (pairs - 1)), lane);
+  v_next[1] = 2 * pairs - 1 < groups ? load_group_dword(src, n, 256 * (2 * pairs - 1), lane) : 0u;
+  for (uint32_t q = pairs; q-- > 0;) {
+    const uint32_t v[2] = {v_next[0], v_next[1]};
     if (q > 0) {
-      v_next = load_group_dword(src, n, 256 * (q - 1), lane);
+      v_next[0] = load_group_dword(src, n, 256 * (2 * q - 2), lane);
+      v_next[1] = load_group_dword(src, n, 256 * (2 * q - 1), lane);
     }
 #pragma unroll
     for (uint32_t rr = 0; rr < 4; ++rr) {
       const uint32_t r = 3 - rr;
-      const bool active = 256 * q + 4 * lane + r < n;
-      const uint32_t sym = (v >> (8 * r)) & 255u;
-      const uint32_t e = table[2 * sym];
-      const uint32_t magic = table[2 * sym + 1];
-      const uint32_t freq = e & 0xfffu;
-      const uint32_t base = (e >> 12) & 0xfffu;
-      const bool emit = active && (x >> (32 - kProbBits)) >= freq; /* x >= freq << (32 - kProbBits) */
-      const uint64_t m = wave::ballot(emit);
-      const uint32_t cnt = wave::popc64(m);
-      if (p + cnt >= limit_words) {
+      bool active[2], emit[2];
+      uint32_t e[2], magic[2];
+#pragma unroll
+      for (uint32_t h = 0; h < 2; ++h) {
+        active[h] = 256 * (2 * q + h) + 4 * lane + r < n;
+        const uint32_t sym = (v[h] >> (8 * r)) & 255u;
+        e[h] = table[2 * sym];
+        magic[h] = table[2 * sym + 1];
+        emit[h] = active[h] && (xs[h] >> (32 - kProbBits)) >= (e[h] & 0xfffu); /* x >= freq << (32 - kProbBits) */
+      }
+      const uint64_t m0 = wave::ballot(emit[0]);
+      const uint64_t m1 = wave::ballot(emit[1]);
+      const uint32_t c0 = wave::popc64(m0);
+      const uint32_t c1 = wave::popc64(m1);
+      if (p + c0 + c1 >= limit_words) {
         return store_raw(src, n, dst);
       }
-      if (emit) {
-        store_as<uint16_t>(words + 2 * (p + wave::prefix_popc(m)), (uint16_t)x);
-        x >>= 16;
+      if (emit[0]) {
+        store_as<uint16_t>(words + 2 * (p + wave::prefix_popc(m0)), (uint16_t)xs[0]);
+        xs[0] >>= 16;
       }
-      p += cnt;
-      if (active) {
-        const uint32_t l = e >> 24;
-        const uint32_t t = __umulhi(magic, x);
-        const uint32_t quot = (t + ((x - t) >> (l ? 1u : 0u))) >> (l ? l - 1u : 0u);
-        x = (quot << kProbBits) + (x - quot * freq) + base;
+      if (emit[1]) {
+        store_as<uint16_t>(words + 2 * (p + c0 + wave::prefix_popc(m1)), (uint16_t)xs[1]);
+        xs[1] >>= 16;
+      }
+      p += c0 + c1;
+#pragma unroll
+      for (uint32_t h = 0; h < 2; ++h) {
+        if (active[h]) {
+          const uint32_t freq = e[h] & 0xfffu;
+          const uint32_t base = (e[h] >> 12) & 0xfffu;
+          const uint32_t l = e[h] >> 24;
+          const uint32_t t = __umulhi(magic[h], xs[h]);
+          const uint32_t quot = (t + ((xs[h] - t) >> (l ? 1u : 0u))) >> (l ? l - 1u : 0u);
+          xs[h] = (quot << kProbBits) + (xs[h] - quot * freq) + base;
+        }
       }
     }
   }
-  store_as<uint32_t>(dst + kStateOffset + 4 * lane, x);
+  store_as<uint32_t>(dst + kStateOffset + 4 * lane, xs[0]);
+  store_as<uint32_t>(dst + kStateOffset + 256 + 4 * lane, xs[1]);
   if (lane == 0) {
     write_header(dst, n, 1);
     store_as<uint32_t>(dst + 12, p);
@@ -288,6 +308,9 @@ __device__ __forceinline__ void ring_fill(WordRing& w, uint32_t p)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   bool loaded = false;
+  if (w.lo > 0 && p < w.lo + 320) {
+    wave::sync(); /* every lane has taken its words of the last row: a refill may reuse slots just above p */
+  }
   while (w.lo > 0 && p < w.lo + 320) {
     w.lo -= 128;
     const uint32_t i = w.lo + 2 * lane;
@@ -393,46 +416,78 @@ __device__ __forceinline__ uint32_t decode_chunk(
   ring_fill(w, p);
   wave::sync();
 
-  uint32_t x = load_as<uint32_t>(in + kStateOffset + 4 * lane);
+  uint32_t xs[2];
+  xs[0] = load_as<uint32_t>(in + kStateOffset + 4 * lane);
+  xs[1] = load_as<uint32_t>(in + kStateOffset + 256 + 4 * lane);
   const uint32_t groups = (n + 255) / 256;
+  const uint32_t pairs = (groups + 1) / 2;
   uint32_t underflow = 0; /* uniform; a corrupt stream may ask for more words than there are */
-  for (uint32_t q = 0; q < groups; ++q) {
-    const uint32_t at = 256 * q + 4 * lane;
-    uint32_t packed = 0;
-    if (256 * q + 256 <= n) {
-      /* whole group: every lane decodes 4 symbols */
+  for (uint32_t q = 0; q < pairs; ++q) {
+    const uint32_t at0 = 512 * q + 4 * lane; /* the lane's bytes in the even group; +256 in the odd one */
+    if (512 * q + 512 <= n) {
+      /* whole pair of groups: every lane decodes 4 + 4 symbols, two independent chains */
+      uint32_t packed0 = 0, packed1 = 0;
 #pragma unroll
       for (uint32_t r = 0; r < 4; ++r) {
-        const uint32_t e = table[x & (kProbScale - 1)];
-        x = __umul24((e >> 8) & 0xfffu, x >> kProbBits) + (e >> 20); /* 12 x 22 bits */
-        const bool need = x < kStateLow;
-        const uint64_t m = wave::ballot(need);
-        const uint32_t cnt = wave::popc64(m);
+        const uint32_t e0 = table[xs[0] & (kProbScale - 1)];
+        const uint32_t e1 = table[xs[1] & (kProbScale - 1)];
+        xs[0] = __umul24((e0 >> 8) & 0xfffu, xs[0] >> kProbBits) + (e0 >> 20); /* 12 x 22 bits */
+        xs[1] = __umul24((e1 >> 8) & 0xfffu, xs[1] >> kProbBits) + (e1 >> 20);
+        const bool need0 = xs[0] < kStateLow;
+        const bool need1 = xs[1] < kStateLow;
+        const uint64_t m0 = wave::ballot(need0);
+        const uint64_t m1 = wave::ballot(need1);
+        const uint32_t c0 = wave::popc64(m0);
+        const uint32_t cnt = c0 + wave::popc64(m1);
         underflow |= cnt > p ? 1u : 0u;
         p -= cnt;
-        if (need) {
-          x = (x << 16) | ring[(p + wave::prefix_popc(m)) & (kRingWords - 1)];
+        if (need0) {
+          xs[0] = (xs[0] << 16) | ring[(p + wave::prefix_popc(m0)) & (kRingWords - 1)];
         }
-        packed |= (e & 255u) << (8 * r);
+        if (need1) {
+          xs[1] = (xs[1] << 16) | ring[(p + c0 + wave::prefix_popc(m1)) & (kRingWords - 1)];
+        }
+        packed0 |= (e0 & 255u) << (8 * r);
+        packed1 |= (e1 & 255u) << (8 * r);
+        if (r == 1) {
+          ring_fill(w, p); /* two rows take at most 256 words; the ring is kept 320 words ahead */
+        }
       }
-      store_as<uint32_t>(out + at, packed);
+      store_as<uint32_t>(out + at0, packed0);
+      store_as<uint32_t>(out + at0 + 256, packed1);
     } else {
 #pragma unroll
       for (uint32_t r = 0; r < 4; ++r) {
-        const bool active = at + r < n;
-        const uint32_t e = table[x & (kProbScale - 1)];
-        uint32_t nx = __umul24((e >> 8) & 0xfffu, x >> kProbBits) + (e >> 20);
-        const bool need = active && nx < kStateLow;
-        const uint64_t m = wave::ballot(need);
-        const uint32_t cnt = wave::popc64(m);
+        bool active[2], need[2];
+        uint32_t e[2], nx[2];
+#pragma unroll
+        for (uint32_t h = 0; h < 2; ++h) {
+          active[h] = at0 + 256 * h + r < n;
+          e[h] = table[xs[h] & (kProbScale - 1)];
+          nx[h] = __umul24((e[h] >> 8) & 0xfffu, xs[h] >> kProbBits) + (e[h] >> 20);
+          need[h] = active[h] && nx[h] < kStateLow;
+        }
+        const uint64_t m0 = wave::ballot(need[0]);
+        const uint64_t m1 = wave::ballot(need[1]);
+        const uint32_t c0 = wave::popc64(m0);
+        const uint32_t cnt = c0 + wave::popc64(m1);
         underflow |= cnt > p ? 1u : 0u;
         p -= cnt;
-        if (need) {
-          nx = (nx << 16) | ring[(p + wave::prefix_popc(m)) & (kRingWords - 1)];
+        if (need[0]) {
+          nx[0] = (nx[0] << 16) | ring[(p + wave::prefix_popc(m0)) & (kRingWords - 1)];
         }
-        if (active) {
-          x = nx;
-          out[at + r] = (uint8_t)e;
+        if (need[1]) {
+          nx[1] = (nx[1] << 16) | ring[(p + c0 + wave::prefix_popc(m1)) & (kRingWords - 1)];
+        }
+#pragma unroll
+        for (uint32_t h = 0; h < 2; ++h) {
+          if (active[h]) {
+            xs[h] = nx[h];
+            out[at0 + 256 * h + r] = (uint8_t)e[h];
+          }
+        }
+        if (r == 1) {
+          ring_fill(w, p);
         }
       }
     }
@@ -443,7 +498,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
     ring_fill(w, p);
   }
   /* a valid stream is consumed exactly and every state is back at its start value */
-  if (p != 0 || wave::ballot(x != kStateLow)) {
+  if (p != 0 || wave::ballot(xs[0] != kStateLow || xs[1] != kStateLow)) {
     err = kErrInput;
     return 0;
   }

@@ -21,8 +21,8 @@
 #define ANS_HEADER 12
 #define ANS_FREQ_OFF 16
 #define ANS_STATE_OFF (ANS_FREQ_OFF + 512)
-#define ANS_WORDS_OFF (ANS_STATE_OFF + 256)
-#define ANS_MIN_CODED 1024
+#define ANS_WORDS_OFF (ANS_STATE_OFF + 512) /* 64 A states (even groups), then 64 B states (odd groups) */
+#define ANS_MIN_CODED 2048
 
 size_t oracle_ans_max_compressed(size_t n)
 {
@@ -75,10 +75,11 @@ static void ans_normalise(const uint32_t* count, size_t n, uint32_t* freq)
   }
 }
 
-/* symbol index of (group q, lane l, row-in-group r) */
-static size_t ans_index(size_t q, unsigned l, unsigned r)
+/* Symbol index of (pair of groups q, state h: 0 = A = even group / 1 = B = odd group, lane l, byte r of the lane's
+ * dword). A row of the coder is (q, r): first the 64 A symbols, then the 64 B symbols. */
+static size_t ans_index(size_t q, unsigned h, unsigned l, unsigned r)
 {
-  return 256 * q + 4 * l + r;
+  return 256 * (2 * q + h) + 4 * l + r;
 }
 
 size_t oracle_ans_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t dst_cap)
@@ -100,39 +101,44 @@ size_t oracle_ans_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t ds
   }
   const size_t limit_words = (n + ANS_HEADER - ANS_WORDS_OFF) / 2;
   uint16_t* words = (uint16_t*)(dst + ANS_WORDS_OFF); /* dst + 784: 2-byte aligned whenever dst is */
-  uint32_t x[64];
+  uint32_t x[2][64];
   for (unsigned l = 0; l < 64; ++l) {
-    x[l] = ANS_LOW;
+    x[0][l] = x[1][l] = ANS_LOW;
   }
   size_t p = 0;
   const size_t groups = (n + 255) / 256;
-  for (size_t q = groups; q-- > 0;) {
+  const size_t pairs = (groups + 1) / 2;
+  for (size_t q = pairs; q-- > 0;) {
     for (unsigned rr = 0; rr < 4; ++rr) {
       const unsigned r = 3 - rr;
-      /* the lanes that renormalise in this row append their words in lane order */
+      /* the states that renormalise in this row append their words: A's in lane order, then B's */
       unsigned cnt = 0;
-      for (unsigned l = 0; l < 64; ++l) {
-        const size_t i = ans_index(q, l, r);
-        if (i < n && (x[l] >> (32 - ANS_PROB_BITS)) >= freq[src[i]]) {
-          ++cnt;
+      for (unsigned h = 0; h < 2; ++h) {
+        for (unsigned l = 0; l < 64; ++l) {
+          const size_t i = ans_index(q, h, l, r);
+          if (i < n && (x[h][l] >> (32 - ANS_PROB_BITS)) >= freq[src[i]]) {
+            ++cnt;
+          }
         }
       }
       if (p + cnt >= limit_words) {
         return ans_store(src, n, dst);
       }
-      for (unsigned l = 0; l < 64; ++l) {
-        const size_t i = ans_index(q, l, r);
-        if (i >= n) {
-          continue;
+      for (unsigned h = 0; h < 2; ++h) {
+        for (unsigned l = 0; l < 64; ++l) {
+          const size_t i = ans_index(q, h, l, r);
+          if (i >= n) {
+            continue;
+          }
+          const uint32_t f = freq[src[i]];
+          if ((x[h][l] >> (32 - ANS_PROB_BITS)) >= f) {
+            const uint16_t wv = (uint16_t)x[h][l];
+            memcpy((uint8_t*)words + 2 * p, &wv, 2);
+            ++p;
+            x[h][l] >>= 16;
+          }
+          x[h][l] = ((x[h][l] / f) << ANS_PROB_BITS) + (x[h][l] % f) + start[src[i]];
         }
-        const uint32_t f = freq[src[i]];
-        if ((x[l] >> (32 - ANS_PROB_BITS)) >= f) {
-          const uint16_t wv = (uint16_t)x[l];
-          memcpy((uint8_t*)words + 2 * p, &wv, 2);
-          ++p;
-          x[l] >>= 16;
-        }
-        x[l] = ((x[l] / f) << ANS_PROB_BITS) + (x[l] % f) + start[src[i]];
       }
     }
   }
@@ -143,7 +149,7 @@ size_t oracle_ans_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t ds
     const uint16_t f16 = (uint16_t)freq[s];
     memcpy(dst + ANS_FREQ_OFF + 2 * s, &f16, 2);
   }
-  memcpy(dst + ANS_STATE_OFF, x, 256);
+  memcpy(dst + ANS_STATE_OFF, x, 512);
   return ANS_WORDS_OFF + 2 * p;
 }
 
@@ -196,26 +202,29 @@ int oracle_ans_decompress(const uint8_t* src, size_t src_len, uint8_t* dst, size
       sym_of[k] = (uint8_t)s;
     }
   }
-  uint32_t x[64];
-  memcpy(x, src + ANS_STATE_OFF, 256);
+  uint32_t x[2][64];
+  memcpy(x, src + ANS_STATE_OFF, 512);
   const uint8_t* words = src + ANS_WORDS_OFF;
   size_t p = n_words;
   const size_t groups = (n + 255) / 256;
-  for (size_t q = 0; q < groups; ++q) {
+  const size_t pairs = (groups + 1) / 2;
+  for (size_t q = 0; q < pairs; ++q) {
     for (unsigned r = 0; r < 4; ++r) {
-      uint32_t nx[64];
+      uint32_t nx[2][64];
       unsigned cnt = 0;
-      for (unsigned l = 0; l < 64; ++l) {
-        const size_t i = ans_index(q, l, r);
-        if (i >= n) {
-          continue;
-        }
-        const uint32_t slot = x[l] & (ANS_SCALE - 1);
-        const uint8_t s = sym_of[slot];
-        dst[i] = s;
-        nx[l] = freq[s] * (x[l] >> ANS_PROB_BITS) + slot - start[s];
-        if (nx[l] < ANS_LOW) {
-          ++cnt;
+      for (unsigned h = 0; h < 2; ++h) {
+        for (unsigned l = 0; l < 64; ++l) {
+          const size_t i = ans_index(q, h, l, r);
+          if (i >= n) {
+            continue;
+          }
+          const uint32_t slot = x[h][l] & (ANS_SCALE - 1);
+          const uint8_t s = sym_of[slot];
+          dst[i] = s;
+          nx[h][l] = freq[s] * (x[h][l] >> ANS_PROB_BITS) + slot - start[s];
+          if (nx[h][l] < ANS_LOW) {
+            ++cnt;
+          }
         }
       }
       if (cnt > p) {
@@ -223,17 +232,19 @@ int oracle_ans_decompress(const uint8_t* src, size_t src_len, uint8_t* dst, size
       }
       p -= cnt;
       unsigned k = 0;
-      for (unsigned l = 0; l < 64; ++l) {
-        if (ans_index(q, l, r) >= n) {
-          continue;
+      for (unsigned h = 0; h < 2; ++h) {
+        for (unsigned l = 0; l < 64; ++l) {
+          if (ans_index(q, h, l, r) >= n) {
+            continue;
+          }
+          if (nx[h][l] < ANS_LOW) {
+            uint16_t wv;
+            memcpy(&wv, words + 2 * (p + k), 2);
+            nx[h][l] = (nx[h][l] << 16) | wv;
+            ++k;
+          }
+          x[h][l] = nx[h][l];
         }
-        if (nx[l] < ANS_LOW) {
-          uint16_t wv;
-          memcpy(&wv, words + 2 * (p + k), 2);
-          nx[l] = (nx[l] << 16) | wv;
-          ++k;
-        }
-        x[l] = nx[l];
       }
     }
   }
@@ -241,7 +252,7 @@ int oracle_ans_decompress(const uint8_t* src, size_t src_len, uint8_t* dst, size
     return ORACLE_ERR_INPUT;
   }
   for (unsigned l = 0; l < 64; ++l) {
-    if (x[l] != ANS_LOW) {
+    if (x[0][l] != ANS_LOW || x[1][l] != ANS_LOW) {
       return ORACLE_ERR_INPUT;
     }
   }

@@ -81,7 +81,7 @@ def test_corrupt_streams(backend, oracle):
         elif i == 1:
             b[0] ^= 0xFF
         elif i == 2:
-            b[rng.randint(784, b.size)] ^= 0x10  # a stream word
+            b[rng.randint(1040, b.size)] ^= 0x10  # a stream word
         elif i == 3:
             b[4] ^= 0x40  # uncompressed size field
         elif i == 4:
