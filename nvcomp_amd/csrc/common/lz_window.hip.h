@@ -561,18 +561,6 @@ __device__ __forceinline__ void far_load_seq(uint32_t (&buf)[8], uint32_t& l4, c
   l4 = wave::gload_u32(src + len - 4);
 }
 
-/* 1..3 byte runs (Snappy copies, short literal runs). */
-__device__ __forceinline__ void copy_tiny(uint8_t* dst, const uint8_t* src, uint32_t len)
-{
-  dst[0] = src[0];
-  if (len > 1) {
-    dst[1] = src[1];
-  }
-  if (len > 2) {
-    dst[2] = src[2];
-  }
-}
-
 /* Match copy inside the window with byte-serial semantics: d[i] = d[i - off].
  * Same pattern-doubling scheme as lz::wave_match_copy, on LDS. */
 __device__ __forceinline__ void lds_match_copy(uint8_t* d, uint32_t off, uint32_t len)
