@@ -199,13 +199,18 @@ __device__ __forceinline__ bool unpack_stream(const uint8_t* src, uint32_t avail
   }
   const uint64_t wmask = width_mask(w);
   const uint64_t vmask = bits == 64 ? ~0ull : ((1ull << bits) - 1);
-  /* 4 tiles per step: their (up to 12) loads are issued together -- one memory round trip instead of four */
-  for (uint32_t base = 0; base < count; base += 256) {
-    uint32_t w0[4], w1[4], w2[4];
+  /* several tiles per step: their loads are issued together -- one memory round trip instead of one per tile.
+   * Elements of up to 4 bytes never straddle three words, so they get 8 tiles in flight for the same registers. */
+  constexpr uint32_t kTiles = sizeof(T) <= 4 ? 8 : 4;
+  for (uint32_t base = 0; base < count; base += 64 * kTiles) {
+    uint32_t w0[kTiles], w1[kTiles], w2[sizeof(T) <= 4 ? 1 : kTiles];
 #pragma unroll
-    for (uint32_t u = 0; u < 4; ++u) {
+    for (uint32_t u = 0; u < kTiles; ++u) {
       const uint32_t i = base + 64 * u + lane;
-      w0[u] = w1[u] = w2[u] = 0;
+      w0[u] = w1[u] = 0;
+      if (sizeof(T) > 4) {
+        w2[u] = 0;
+      }
       if (bits && i < count) {
         const uint64_t bit = (uint64_t)i * bits;
         const uint32_t k = (uint32_t)(bit / 32);
@@ -214,13 +219,13 @@ __device__ __forceinline__ bool unpack_stream(const uint8_t* src, uint32_t avail
         if (sh + bits > 32) {
           w1[u] = in[3 + k + 1];
         }
-        if (sh + bits > 64) {
+        if (sizeof(T) > 4 && sh + bits > 64) {
           w2[u] = in[3 + k + 2];
         }
       }
     }
 #pragma unroll
-    for (uint32_t u = 0; u < 4; ++u) {
+    for (uint32_t u = 0; u < kTiles; ++u) {
       const uint32_t i = base + 64 * u + lane;
       if (i < count) {
         uint64_t x = 0;
@@ -230,7 +235,7 @@ __device__ __forceinline__ bool unpack_stream(const uint8_t* src, uint32_t avail
           if (sh + bits > 32) {
             x |= (uint64_t)w1[u] << (32 - sh);
           }
-          if (sh + bits > 64) {
+          if (sizeof(T) > 4 && sh + bits > 64) {
             x |= (uint64_t)w2[u] << (64 - sh);
           }
           x &= vmask;
