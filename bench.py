@@ -340,7 +340,9 @@ def run_case(args, ctx):
     }
     if rank == 0:
         traffic = None
-        tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        tpath = os.path.join(REPO, "profiles", f"pmc_traffic_{args.algo}.json")
+        if not os.path.exists(tpath):
+            tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 rec = json.load(open(tpath))
