@@ -327,6 +327,28 @@ __device__ __forceinline__ uint32_t decode_chunk(
       err |= lz::kErrInput;
       return 0;
     }
+    /* A copy that continues the copy before it (same offset, nothing in between) is the same match going on: the
+     * compressor cuts matches into 64-byte elements, so runs and periodic columns arrive as long trains of them.
+     * The first lane of a train takes the whole length, the others become empty sequences. */
+    uint64_t train = 0;
+    {
+      const uint32_t prev_off = wave::shuffle(s.match_off, (lane - 1) & 63u);
+      const uint32_t prev_len = wave::shuffle(s.match_len, (lane - 1) & 63u);
+      const bool cont = lane > 0 && lane < count && s.lit_len == 0 && s.match_len != 0 && prev_len != 0 && prev_off == s.match_off;
+      train = wave::ballot(cont);
+      if (train) {
+        const uint32_t incl = wave::scan_add_inclusive(lane < count ? s.match_len : 0u);
+        const uint64_t above = lane < 63 ? train >> (lane + 1) : 0ull;
+        const uint32_t followers = wave::ctz64(~above); /* consecutive continuing lanes right after this one */
+        const uint32_t end_incl = wave::shuffle(incl, (lane + followers) & 63u);
+        if (cont) {
+          s.match_len = 0;
+          s.match_off = 0;
+        } else if (followers) {
+          s.match_len += end_incl - incl;
+        }
+      }
+    }
     bool big;
     uint32_t take = lzw::execute_window_batch<CHECKED>(ir, ow, limit, op, count, s, err, big);
     if (CHECKED && err) {
@@ -355,7 +377,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
       ow.wbase = op & ~15u;
       ow.valid_lo = op;
       ow.flushed = op;
-      take = 1;
+      take = 1 + wave::ctz64(~(train >> 1)); /* sequence 0 and the empty sequences of its train */
     }
     seqpos = wave::shuffle(seqpos, (lane + take) & 63u);
     count -= take;
