@@ -48,7 +48,7 @@ def parse_args():
                    help="lz4 is the headline (BASELINE.json configs[1]); cascaded/bitcomp/ans are this library's own stream "
                         "formats: their inputs are made by the HIP compressor (checked against the CPU model) outside the timed region")
     p.add_argument("--opts", default="", help="cascaded: chunk_size,type,num_RLEs,num_deltas,use_bp; bitcomp: algo,type")
-    p.add_argument("--mib-per-gpu", type=int, default=1024, help="uncompressed MiB decoded per GPU per step")
+    p.add_argument("--mib-per-gpu", type=int, default=4096, help="uncompressed MiB decoded per GPU per step")
     p.add_argument("--unique-mib", type=int, default=64, help="unique MiB generated + CPU-compressed per rank")
     p.add_argument("--unique-kib", type=int, default=0, help="(tests) unique KiB per rank, overrides --unique-mib/--mib-per-gpu")
     p.add_argument("--dataset", default=None,
@@ -187,10 +187,11 @@ def setup_runtime(args):
 
         lib, dev = emu_conftest.emu_library(), emu_conftest.HostDevice()
         edist = None
-        if world > 1:  # CPU-only multi-process self-test: gloo
+        if world > 1 or os.environ.get("NVCOMP_AMD_BENCH_FORCE_DIST") == "1":  # CPU-only multi-process self-test: gloo
             import torch.distributed as edist
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
             edist.init_process_group("gloo", rank=rank, world_size=world)
         rt = EmuRuntime(edist)
     else:
@@ -198,12 +199,16 @@ def setup_runtime(args):
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
-        if world > 1:
+        # NVCOMP_AMD_BENCH_FORCE_DIST=1: bring RCCL up even for one rank, so a 1-GPU box can exercise the
+        # barrier / max-over-ranks / digest-gather calls the N>1 launch relies on (tests/test_programs.py)
+        use_dist = world > 1 or os.environ.get("NVCOMP_AMD_BENCH_FORCE_DIST") == "1"
+        if use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", rank=rank, world_size=world)
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
         lib = nvcomp_amd.load_library()  # raises when the HIP library is missing
         dev = nvcomp_amd.TorchDevice(f"cuda:{local_rank}")
-        rt = TorchRuntime(torch, dist if world > 1 else None, dev)
+        rt = TorchRuntime(torch, dist if use_dist else None, dev)
     return {"rank": rank, "world": world, "lib": lib, "dev": dev, "rt": rt}
 
 
@@ -413,7 +418,7 @@ def run_case(args, ctx):
 
 
 def finish(result, args, world, rt, data):
-    if world > 1:
+    if rt.dist is not None:
         digests = [None] * world
         rt.dist.all_gather_object(digests, shard_digest(data))
         result["config"]["shard_digests"] = digests
@@ -494,7 +499,8 @@ def run_allgather_case(args, ctx):
 
     rank, world, lib, dev, rt = ctx["rank"], ctx["world"], ctx["lib"], ctx["dev"], ctx["rt"]
     dist = rt.dist
-    assert world >= 2 and dist is not None, "--allgather needs at least 2 ranks"
+    forced = os.environ.get("NVCOMP_AMD_BENCH_FORCE_DIST") == "1"  # one rank: collectives run, nothing is remote
+    assert dist is not None and (world >= 2 or forced), "--allgather needs at least 2 ranks"
     codec = nvcomp_amd.BatchedCodec(lib, dev, "LZ4")
     unique = (args.unique_kib << 10) if args.unique_kib else (args.unique_mib << 20)
     gen = getattr(datasets, args.dataset) if hasattr(datasets, args.dataset) else datasets.CLASSES[args.dataset]
@@ -528,7 +534,8 @@ def run_allgather_case(args, ctx):
     actual = dev.upload(np.zeros(m, dtype=np.uint64).view(np.uint8))
     statuses = dev.upload(np.full(m, -1, dtype=np.int32).view(np.uint8))
     remote = [r for r in range(world) if r != rank]
-    out_ptrs = np.concatenate([ptr(out) + r * shard_bytes + np.arange(n, dtype=np.uint64) * CHUNK for r in remote])
+    out_ptrs = np.concatenate([ptr(out) + r * shard_bytes + np.arange(n, dtype=np.uint64) * CHUNK for r in remote]
+                              + [np.zeros(0, dtype=np.uint64)])
     out_batch = DeviceBatch(out, dev_u64(out_ptrs), dev_u64(np.full(m, CHUNK)), None, None, m)
     moved = [0]
 
@@ -565,7 +572,7 @@ def run_allgather_case(args, ctx):
     rt.barrier_sync()
     elapsed = rt.max_over_ranks(time.perf_counter() - t0)
     del keep
-    st = dev.download(statuses).view(np.int32)[:m]
+    st = dev.download(statuses, 4 * m).view(np.int32)
     assert (st == 0).all(), f"{int((st != 0).sum())} remote chunks failed"
     # every rank must now hold every shard: compare fingerprints with the owners'
     weights = (torch.arange(shard_bytes, device=sizes.device) % 65521).to(torch.int64)

@@ -503,6 +503,106 @@ __device__ __forceinline__ bool rle_decode(const T* A, const uint16_t* runs, uin
   return true;
 }
 
+/* Expansion of layers whose runs are all short (at most kDirectMaxRun, at most kDirectMaxBits bits each in the
+ * packed stream): the run lengths are extracted straight from the stream's words -- 4 consecutive runs per lane
+ * out of two dwords -- so neither a run pool nor the marks exist in LDS, an inner layer expands IN PLACE, and the
+ * sub-chunk decodes inside the smallest slice (8 waves per SIMD). This is the shape of smooth float columns
+ * (BASELINE.json configs[3]): a few repeated neighbours per sub-chunk, short runs of equal deltas below that. */
+constexpr uint32_t kDirectMaxBits = 6;
+constexpr uint32_t kDirectMaxRun = 64;
+
+__host__ __device__ inline bool runs_are_short(uint32_t bits, uint32_t mn_lo, uint32_t mn_hi)
+{
+  return bits <= kDirectMaxBits && mn_hi == 0 && mn_lo >= 1 && mn_lo + (1u << bits) - 1u <= kDirectMaxRun;
+}
+
+/* Runs j0..j0+3 (zero beyond c) and their values for this lane. packed: the stream's words after its header. */
+template <typename T>
+__device__ __forceinline__ void load_short_runs(const T* A, const uint32_t* packed, uint32_t bits, uint32_t mn, uint32_t c,
+                                                uint32_t j0, uint32_t (&r)[4], T (&a)[4])
+{
+  const uint32_t words = (c * bits + 31) / 32;
+  const uint32_t mask = (1u << bits) - 1u;
+  uint64_t v = 0;
+  if (bits && j0 < c) {
+    const uint32_t bit = j0 * bits;
+    const uint32_t k = bit >> 5;
+    const uint32_t lo = packed[k];
+    const uint32_t hi = k + 1 < words ? packed[k + 1] : 0u;
+    v = (((uint64_t)hi << 32) | lo) >> (bit & 31u);
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < 4; ++k) {
+    const bool live = j0 + k < c;
+    r[k] = live ? mn + ((uint32_t)(v >> (k * bits)) & mask) : 0u;
+    a[k] = live ? A[j0 + k] : (T)0;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void store_short_runs(T* out, uint32_t pos, const uint32_t (&r)[4], const T (&a)[4])
+{
+#pragma unroll
+  for (uint32_t k = 0; k < 4; ++k) {
+    for (uint32_t q = 0; q < r[k]; ++q) {
+      out[pos + q] = a[k];
+    }
+    pos += r[k];
+  }
+}
+
+/* Outermost layer: A (LDS, c values) -> out (HBM, target elements), ascending. */
+template <typename T>
+__device__ __forceinline__ bool rle_expand_direct(const T* A, const uint32_t* packed, uint32_t bits, uint32_t mn, uint32_t c,
+                                                  T* out, uint32_t target)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  uint32_t carry = 0;
+  bool bad = false;
+  for (uint32_t base = 0; base < c; base += 256) {
+    uint32_t r[4];
+    T a[4];
+    load_short_runs(A, packed, bits, mn, c, base + 4 * lane, r, a);
+    const uint32_t mine = r[0] + r[1] + r[2] + r[3];
+    const uint32_t incl = wave::scan_add_inclusive(mine);
+    const uint32_t pos = incl - mine + carry;
+    if (pos + mine > target) {
+      bad = true;
+    } else {
+      store_short_runs(out, pos, r, a);
+    }
+    carry += wave::read_lane(incl, 63);
+  }
+  return !wave::ballot(bad) && carry == target;
+}
+
+/* Inner layer: A[0..c) -> A[0..target) in place. Tiles run from the top down: tile t's output starts at the sum of
+ * all runs below it, which is at least 256 t (every run is >= 1) -- it lands on values this tile already holds in
+ * registers or that higher tiles have consumed, never on values still to be read. */
+template <typename T>
+__device__ __forceinline__ bool rle_expand_inplace(T* A, const uint32_t* packed, uint32_t bits, uint32_t mn, uint32_t c,
+                                                   uint32_t target)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  uint32_t above = 0; /* elements produced by the tiles above */
+  for (uint32_t t = (c + 255) / 256; t-- > 0;) {
+    uint32_t r[4];
+    T a[4];
+    load_short_runs(A, packed, bits, mn, c, 256 * t + 4 * lane, r, a);
+    const uint32_t mine = r[0] + r[1] + r[2] + r[3];
+    const uint32_t incl = wave::scan_add_inclusive(mine);
+    const uint32_t total = wave::read_lane(incl, 63);
+    if (above + total > target) {
+      return false;
+    }
+    wave::sync(); /* every lane holds its values before any lane overwrites them */
+    store_short_runs(A, target - above - total + (incl - mine), r, a);
+    wave::sync();
+    above += total;
+  }
+  return above == target;
+}
+
 /* ---- sub-chunk codec ------------------------------------------------------- */
 
 constexpr uint32_t kSubNeedsLds = 0xffffffffu; /* compress_sub: the streams do not fit the LDS slice it was given */
@@ -730,6 +830,7 @@ __device__ __forceinline__ uint32_t decompress_sub(
   uint32_t pool_used = 0;    /* run entries that must be unpacked */
   uint32_t inner_real = 0;   /* expanding layers below the outermost one: they expand into LDS */
   uint32_t marks_elems = 0;  /* largest expansion target */
+  bool all_short = true;     /* every expanding layer qualifies for rle_expand_direct / rle_expand_inplace */
   for (uint32_t l = 0; l < num_rles; ++l) {
     if (avail - pos < 12) {
       return kSubBad;
@@ -747,6 +848,7 @@ __device__ __forceinline__ uint32_t decompress_sub(
       return kSubBad;
     }
     const bool id = bits == 0 && mn_lo == 1 && mn_hi == 0 && cl == target;
+    all_short = all_short && (id || runs_are_short(bits, mn_lo, mn_hi));
     if (lane == 0) {
       ident[l] = id ? 1u : 0u;
       src_off[l] = pos;
@@ -763,6 +865,13 @@ __device__ __forceinline__ uint32_t decompress_sub(
   /* value buffers: the outermost expanding layer writes to HBM when it is layer 0, so a buffer holds at most
    * counts[0] elements then; without that it holds the n elements of the sub-chunk */
   const bool outer_to_hbm = num_rles != 0 && ident[0] == 0;
+  /* all runs short: one value buffer, expanded in place, no pool, no marks */
+  const bool direct = all_short && pool_used != 0;
+  if (direct) {
+    pool_used = 0;
+    marks_elems = 0;
+    inner_real = 0;
+  }
   const uint32_t top = outer_to_hbm ? counts[0] : n;
   const uint32_t val_bytes = align16(top * w);
   const uint32_t n_bufs = inner_real ? 2u : 1u;
@@ -776,7 +885,7 @@ __device__ __forceinline__ uint32_t decompress_sub(
   uint16_t* pool = (uint16_t*)(lds + meta_bytes + n_bufs * val_bytes);
   uint16_t* marks = (uint16_t*)(lds + meta_bytes + n_bufs * val_bytes + pool_bytes);
   for (uint32_t l = 0; l < num_rles; ++l) {
-    if (ident[l]) {
+    if (ident[l] || direct) {
       continue;
     }
     uint32_t used;
@@ -803,6 +912,19 @@ __device__ __forceinline__ uint32_t decompress_sub(
     if (l < num_rles && !ident[l]) {
       const uint32_t target = l == 0 ? n : counts[l - 1];
       /* layer 0 writes the sub-chunk itself */
+      if (direct) {
+        const uint32_t so = src_off[l];
+        const uint32_t bits = word_at(so);
+        const uint32_t mn = word_at(so + 4);
+        const uint32_t* packed = (const uint32_t*)(src + so + 12);
+        if (l == 0 ? !rle_expand_direct(cur, packed, bits, mn, c, (T*)dst, target)
+                   : !rle_expand_inplace(cur, packed, bits, mn, c, target)) {
+          return kSubBad;
+        }
+        in_hbm = l == 0;
+        c = target;
+        continue;
+      }
       if (!rle_decode(cur, pool + run_off[l], c, l == 0 ? (T*)dst : oth, target, marks)) {
         return kSubBad;
       }

@@ -48,7 +48,8 @@ def main():
             rows = list(csv.DictReader(open(p)))
             launches = len({r["Dispatch_Id"] for r in rows if "lz4_decompress_window_kernel" in r["Kernel_Name"]})
             pmc.update(pmc_per_launch(p, "lz4_decompress_window_kernel", max(1, launches)))
-    pmc["_note"] = ("per launch of lz4_decompress_window_kernel<checked>, 16384 chunks x 64 KiB (1 GiB out, 471 MB in); "
+    chunks = bench.get("bench_lz4", {}).get("config", {}).get("chunks_per_gpu", 0)
+    pmc["_note"] = (f"per launch of lz4_decompress_window_kernel<checked>, {chunks} chunks x 64 KiB; "
                     "separate rocprofv3 --pmc passes; FETCH_SIZE/WRITE_SIZE in KB")
     json.dump(pmc, open(os.path.join(dst, prefix + "_pmc.json"), "w"), indent=1)
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc and "bench_lz4" in bench:
@@ -58,7 +59,7 @@ def main():
         # 0.516x their true bytes (the guide's gfx950 1/2 factor); the other half of the stream is added back.
         traffic = fetch + 0.5 * comp + write
         json.dump({
-            "algo": "lz4", "dataset": "silesia_style", "chunks_per_gpu": 16384,
+            "algo": "lz4", "dataset": "silesia_style", "chunks_per_gpu": chunks,
             "hbm_bytes_per_launch": int(traffic), "fetch_bytes_counted": int(fetch), "write_bytes_counted": int(write),
             "calibration": {
                 "noise_dataset": {"input_stream_KB": 1052700, "FETCH_SIZE_KB": 543117.5, "counted_over_true": 0.516,
@@ -68,10 +69,28 @@ def main():
                                       "meaning": "-DNVCOMP_LZW_FAR_ABLATE: far-match reads folded onto L2-resident lines; what remains is the "
                                                  "stream (471 MB true, counted at 1/2) plus the pointer arrays"}},
             "note": "traffic = FETCH_SIZE as counted + the uncounted half of the compressed stream (0.5 x C) + WRITE_SIZE; separate "
-                    f"rocprofv3 --pmc passes, KB units, session {tag}. The far-match gather part of FETCH_SIZE (about 3.4 GB for ~85 M "
-                    "matches of ~9 bytes) is tallied at 64 B per request and is uncalibrated: if every request is a 128-B line fill the true "
-                    "figure is up to 8.7 GB. WRITE_SIZE matches the algorithmic 1.07 GB plus partial-line effects.",
+                    f"rocprofv3 --pmc passes, KB units, session {tag}. The far-match gather part of FETCH_SIZE (what exceeds half the "
+                    "stream; matches of ~9 bytes each) is tallied at 64 B per request and is uncalibrated: if every request is a 128-B "
+                    "line fill the true figure is up to 2.5x larger. WRITE_SIZE matches the algorithmic output bytes plus partial-line "
+                    "effects. The calibration sessions ran at 16384 chunks.",
         }, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+    # own-format decode kernels (scripts/gpu_traffic.sh legs of the same session)
+    for algo in ("bitcomp", "ans", "cascaded"):
+        f = os.path.join(src, f"traffic_{algo}_FETCH_SIZE.json")
+        w = os.path.join(src, f"traffic_{algo}_WRITE_SIZE.json")
+        b = bench.get("bench_" + algo)
+        if not (os.path.exists(f) and os.path.exists(w) and b):
+            continue
+        fetch = json.load(open(f))["KB_per_launch"] * 1024
+        write = json.load(open(w))["KB_per_launch"] * 1024
+        json.dump({
+            "algo": algo, "dataset": b["config"]["dataset"], "chunks_per_gpu": b["config"]["chunks_per_gpu"],
+            "hbm_bytes_per_launch": int(2 * fetch + write), "fetch_bytes_counted": int(fetch), "write_bytes_counted": int(write),
+            "algorithmic_bytes": b["roofline"]["algorithmic_bytes_per_launch"],
+            "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (scripts/gpu_traffic.sh, session {tag}), KB units, per "
+                    "decompress call; FETCH_SIZE doubled: these kernels read their input with wide coalesced loads, for which gfx950 "
+                    "reports 1/2 of the bytes (MI355X_MICROARCH.md 'HBM'; calibrated on the compressed size in session tr1).",
+        }, open(os.path.join(dst, f"pmc_traffic_{algo}.json"), "w"), indent=1)
     print("collected", sorted(os.listdir(dst)))
 
 

@@ -43,4 +43,5 @@ cat "$OUT/rc.txt"; tail -3 "$OUT/pytest_gpu.log"; cat "$OUT/bench_lz4.json"
 for a in cascaded bitcomp ans; do
   timeout 400 python bench.py --algo $a > "$OUT/bench_$a.json" 2> "$OUT/bench_$a.err"; echo "bench $a rc=$?" >> "$OUT/rc.txt"
 done
+bash scripts/gpu_traffic.sh "${1:-final}" > "$OUT/traffic.log" 2>&1
 tail -3 "$OUT/rc.txt"

@@ -13,7 +13,10 @@ agg = collections.defaultdict(float); n = collections.defaultdict(set)
 for r in csv.DictReader(open(sys.argv[1])):
     if "_decompress_kernel" in r["Kernel_Name"] and sys.argv[2] in r["Kernel_Name"]:
         agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]].add(r["Dispatch_Id"])
+import json, os
 for k, v in agg.items():
     print(sys.argv[2], k, "KB per launch:", round(v / len(n[k]), 1), "launches", len(n[k]))
+    json.dump({"KB_per_launch": v / len(n[k]), "launches": len(n[k])},
+              open(os.path.join(os.path.dirname(os.path.dirname(sys.argv[1])), f"traffic_{sys.argv[2]}_{k}.json"), "w"))
 PY
 done; done

@@ -61,6 +61,39 @@ def test_scheme_combinations(backend, oracle, r, d, bp):
         roundtrip(backend, oracle, chunks, (4096, typ, r, d, bp))
 
 
+@pytest.mark.parametrize("typ", [1, 3, 4, 6])
+@pytest.mark.parametrize("r,d", [(2, 1), (1, 0), (1, 1), (3, 2)])
+def test_short_run_expansion(backend, oracle, typ, r, d):
+    """Values with short runs (smooth float columns, BASELINE.json configs[3]): when every expanding layer's runs are
+    at most 64 the decoder expands them straight from the packed run streams (casc::rle_expand_direct to HBM,
+    rle_expand_inplace for inner layers); one longer run anywhere sends the sub-chunk down the pool + marks path.
+    Both sides of every boundary, every element width."""
+    w = WIDTH[typ]
+    rng = np.random.RandomState(100 * typ + 10 * r + d)
+    dt = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[w]
+
+    def column(run_lengths, n_runs):
+        runs = rng.choice(run_lengths, size=n_runs, p=None)
+        vals = (np.cumsum(rng.randint(1, 7, size=n_runs)) % (1 << (8 * w - 1) if w < 8 else 1 << 62)).astype(dt)
+        vals[1:][vals[1:] == vals[:-1]] += 1  # neighbours stay distinct: the second RLE layer finds nothing
+        return np.repeat(vals, runs).view(np.uint8)
+
+    chunks = [
+        column([1, 1, 1, 1, 1, 1, 1, 2], 3000),        # bits 1, min 1
+        column([1, 1, 1, 1, 2, 3, 4], 3000),            # bits 2
+        column([1, 1, 1, 5, 8], 2000),                  # bits 3, max run exactly 8
+        column([1, 1, 1, 1, 9], 2000),                  # bits 4
+        column([1, 2, 64], 400),                        # bits 6, max run exactly 64
+        column([1, 2, 65], 400),                        # 65 > 64: pool + marks path
+        column([2, 3], 2000),                           # min 2
+        column([1, 1, 1, 1, 1, 300], 500),              # one long run per few: general path
+        np.repeat(column([1, 2], 1500).view(dt), 2).view(np.uint8),  # every value twice: the inner layer expands too
+        datasets.float_columns(65536, typ),
+    ]
+    chunks = [c[: c.size // w * w] for c in chunks]
+    roundtrip(backend, oracle, chunks, (4096, typ, r, d, 1))
+
+
 def test_sub_chunk_sizes(backend, oracle):
     chunks = [datasets.int32_column(40000, 9), datasets.table_rows(12000, 4)]
     for sub in (256, 512, 1000, 4096, 8192, 16384):

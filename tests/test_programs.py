@@ -132,3 +132,27 @@ def test_bench_contract_on_gpu(algo):
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     base = res["cpu_baseline"]
     assert base["value"] > 0 and base["cores"] >= 1 and base["kind"] in ("reference", "port") and base["sample"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--allgather"]], ids=["sharded", "allgather"])
+def test_bench_under_launcher_with_rccl(extra):
+    """The driver's N>1 launch line, with one rank (the box has one GPU) and RCCL forced up: process-group init on
+    the device, barrier, max-over-ranks all-reduce, digest gather and (--allgather) the RCCL all-gathers all run
+    on the real backend instead of only on gloo (tests/test_multiprocess.py)."""
+    import json
+    import os
+    import sys
+
+    env = dict(os.environ, NVCOMP_AMD_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29641", "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--mib-per-gpu", "64", "--unique-mib", "8", "--no-cpu-baseline", "--no-extras"] + extra
+    r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-8000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 1 and res["steps"] == 2
+    if not extra:
+        assert res["value"] > 1.0 and len(res["config"]["shard_digests"]) == 1
