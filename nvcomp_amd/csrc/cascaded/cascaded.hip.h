@@ -112,32 +112,52 @@ __device__ __forceinline__ uint64_t scan_add64(uint64_t v)
 template <typename T>
 struct Stream
 {
+  static constexpr uint32_t kBytes = sizeof(T);
   const T* p;
   __device__ __forceinline__ uint64_t get(uint32_t i) const { return (uint64_t)p[i]; }
+  __device__ __forceinline__ uint32_t get32(uint32_t i) const { return (uint32_t)p[i]; }
 };
 
-/* min / range of a stream -> (min value as stored, bits) */
+/* min / range of a stream -> (min value as stored, bits). Elements of up to 4 bytes are ranged in 32-bit
+ * arithmetic (one DPP reduction per bound); 8-byte elements take the 64-bit path. */
 template <typename S>
 __device__ __forceinline__ void stream_range(const S& s, uint32_t count, uint32_t w, bool as_signed, uint64_t& mn_out,
                                              uint32_t& bits_out)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
-  uint64_t lo = ~0ull, hi = 0;
-  for (uint32_t i = lane; i < count; i += 64) {
-    const uint64_t k = to_key(s.get(i), w, as_signed);
-    lo = k < lo ? k : lo;
-    hi = k > hi ? k : hi;
-  }
-  lo = reduce_min64(lo);
-  hi = reduce_max64(hi);
   if (count == 0) {
     mn_out = 0;
     bits_out = 0;
     return;
   }
-  bits_out = bits_for(hi - lo);
-  /* back from key space: the minimum as a w-byte value */
-  mn_out = (as_signed ? (lo ^ 0x8000000000000000ull) : lo) & width_mask(w);
+  if constexpr (S::kBytes <= 4) {
+    const uint32_t sh = 32 - 8 * w;
+    const uint32_t flip = as_signed ? 0x80000000u : 0u;
+    uint32_t lo = ~0u, hi = 0;
+    for (uint32_t i = lane; i < count; i += 64) {
+      const uint32_t v = s.get32(i);
+      const uint32_t k = (as_signed ? (uint32_t)((int32_t)(v << sh) >> sh) : v) ^ flip;
+      lo = k < lo ? k : lo;
+      hi = k > hi ? k : hi;
+    }
+    lo = ~wave::reduce_max(~lo);
+    hi = wave::reduce_max(hi);
+    const uint32_t range = hi - lo;
+    bits_out = range ? 32u - (uint32_t)__builtin_clz(range) : 0u;
+    mn_out = (uint64_t)(lo ^ flip) & width_mask(w);
+  } else {
+    uint64_t lo = ~0ull, hi = 0;
+    for (uint32_t i = lane; i < count; i += 64) {
+      const uint64_t k = to_key(s.get(i), w, as_signed);
+      lo = k < lo ? k : lo;
+      hi = k > hi ? k : hi;
+    }
+    lo = reduce_min64(lo);
+    hi = reduce_max64(hi);
+    bits_out = bits_for(hi - lo);
+    /* back from key space: the minimum as a w-byte value */
+    mn_out = (as_signed ? (lo ^ 0x8000000000000000ull) : lo) & width_mask(w);
+  }
 }
 
 __device__ __forceinline__ uint32_t stream_bytes(uint32_t count, uint32_t bits)
@@ -145,8 +165,10 @@ __device__ __forceinline__ uint32_t stream_bytes(uint32_t count, uint32_t bits)
   return 12 + 4 * (uint32_t)(((uint64_t)count * bits + 31) / 32);
 }
 
-/* Write one packed stream at dst (global, 4-byte aligned). Every lane assembles
- * whole output words from the elements that overlap them. */
+/* Write one packed stream at dst (global, 4-byte aligned). Every lane assembles whole output words from the
+ * elements that overlap them. The first such element of word k is floor(32 k / bits): a multiply by the
+ * stream's reciprocal (exact: 32 k < 2^21, bits <= 64), not a division per word; the last one is found by
+ * walking. Elements of up to 4 bytes with bits <= 32 are assembled in 32-bit arithmetic. */
 template <typename S>
 __device__ __forceinline__ uint32_t pack_stream(uint8_t* dst, const S& s, uint32_t count, uint32_t w, uint64_t mn,
                                                 uint32_t bits)
@@ -158,18 +180,36 @@ __device__ __forceinline__ uint32_t pack_stream(uint8_t* dst, const S& s, uint32
     out[1] = (uint32_t)mn;
     out[2] = (uint32_t)(mn >> 32);
   }
-  const uint32_t words = (uint32_t)(((uint64_t)count * bits + 31) / 32);
+  const uint32_t words = (count * bits + 31) / 32; /* count <= kMaxElems: no overflow */
+  if (words == 0) {
+    return 12;
+  }
+  const uint32_t recip = bits > 1 ? (uint32_t)((0x100000000ull + bits - 1) / bits) : 0u;
+  if (S::kBytes <= 4 && bits <= 32) {
+    const uint32_t mn32 = (uint32_t)mn;
+    const uint32_t vmask = bits == 32 ? ~0u : ((1u << bits) - 1u); /* bits <= 8 w: the width mask is implied */
+    for (uint32_t k = lane; k < words; k += 64) {
+      const uint32_t bit0 = 32 * k;
+      uint32_t e = bits > 1 ? __umulhi(bit0, recip) : bit0;
+      int32_t rel = (int32_t)(e * bits) - (int32_t)bit0; /* in (-bits, 0] */
+      uint32_t word = 0;
+      for (; rel < 32 && e < count; ++e, rel += (int32_t)bits) {
+        const uint32_t x = (s.get32(e) - mn32) & vmask;
+        word |= rel >= 0 ? x << rel : x >> (-rel);
+      }
+      out[3 + k] = word;
+    }
+    return 12 + 4 * words;
+  }
   const uint64_t wmask = width_mask(w);
   const uint64_t vmask = bits == 64 ? ~0ull : ((1ull << bits) - 1);
   for (uint32_t k = lane; k < words; k += 64) {
-    const uint64_t bit0 = (uint64_t)k * 32;
-    uint32_t e = (uint32_t)(bit0 / bits);
-    uint32_t e_last = (uint32_t)((bit0 + 31) / bits);
-    e_last = e_last < count - 1 ? e_last : count - 1;
+    const uint32_t bit0 = 32 * k;
+    uint32_t e = bits > 1 ? __umulhi(bit0, recip) : bit0;
+    int32_t rel = (int32_t)(e * bits) - (int32_t)bit0;
     uint32_t word = 0;
-    for (; e <= e_last; ++e) {
+    for (; rel < 32 && e < count; ++e, rel += (int32_t)bits) {
       const uint64_t x = ((s.get(e) - mn) & wmask) & vmask;
-      const int64_t rel = (int64_t)((uint64_t)e * bits) - (int64_t)bit0;
       word |= rel >= 0 ? (uint32_t)(x << rel) : (uint32_t)(x >> (-rel));
     }
     out[3 + k] = word;
@@ -624,7 +664,11 @@ struct LayerMeta
  * intermediate streams do not fit the `budget` bytes of LDS at `lds` (nothing final has been decided then:
  * the caller repeats the whole chunk in a pass with a larger slice). With at least one RLE layer the input is
  * never staged: the first layer reads it from HBM and only its (values, runs) output lives in LDS, so a
- * compressible sub-chunk needs a fraction of the worst case. */
+ * compressible sub-chunk needs a fraction of the worst case.
+ * Every layer's run stream is packed into dst as soon as the layer has run -- the streams are laid out in layer
+ * order, so its position is known -- which leaves ONE run pool, reused by every layer: the worst case is the value
+ * buffer plus 2 bytes per element, whatever num_RLEs is. A sub-chunk that stops shrinking is stored raw; the
+ * speculative stream writes never pass the raw size, so they stay inside what the caller reserved. */
 template <typename T>
 __device__ __forceinline__ uint32_t compress_sub(
     const uint8_t* src, uint32_t bytes, uint8_t* dst, const Params& p, uint8_t* lds, uint32_t budget)
@@ -633,36 +677,29 @@ __device__ __forceinline__ uint32_t compress_sub(
   const uint32_t w = sizeof(T);
   const uint32_t n = bytes / w;
   const T* in = (const T*)src;
-  LayerMeta* meta = (LayerMeta*)lds;
-  const uint32_t meta_bytes = (uint32_t)((sizeof(LayerMeta) + 15u) & ~15u);
-  if (budget < meta_bytes + 64) {
-    return kSubNeedsLds;
-  }
   const uint32_t rl = p.num_rles;
   const uint32_t layers = rl > p.num_deltas ? rl : p.num_deltas;
-  uint32_t* counts = meta->counts;
-  uint32_t* run_off = meta->run_off;
-  uint32_t* ident = meta->ident;
-  /* One value buffer V of n elements and the run pools behind it. Layer 0 reads the input from HBM and compacts
+  /* One value buffer V of n elements and the run pool behind it. Layer 0 reads the input from HBM and compacts
    * it into V; later layers compact V in place. A layer that finds no runs is the identity: its runs are dropped
    * and, with bit-packing, its run stream is just a header (the bytes are what the general path would write).
    * kSubNeedsLds when V or the run pool does not fit `budget`. */
   const bool can_skip = p.use_bp != 0;
-  uint8_t* area = lds + meta_bytes;
-  const uint32_t area_bytes = budget - meta_bytes;
   const uint32_t v_bytes = (n * w + 15u) & ~15u;
-  if (v_bytes > area_bytes) {
+  if (v_bytes + 64 > budget) {
     return kSubNeedsLds;
   }
-  T* V = (T*)area;
-  uint16_t* pool = (uint16_t*)(area + v_bytes);
-  const uint32_t pool_cap = (area_bytes - v_bytes) / 2;
+  T* V = (T*)lds;
+  uint16_t* pool = (uint16_t*)(lds + v_bytes);
+  const uint32_t pool_cap = (budget - v_bytes) / 2;
+  const uint32_t raw_sz = 4 + ((bytes + 3u) & ~3u);
+  uint32_t* out32 = (uint32_t*)dst;
+  uint32_t pos = 4 + 4 * rl;
+  bool raw = pos >= raw_sz;
   uint32_t c = n;
-  uint32_t pool_used = 0;
   const T* cur = in; /* HBM until layer 0 (or a delta) has put the data into V */
-  for (uint32_t l = 0; l < layers; ++l) {
+  for (uint32_t l = 0; l < layers && !raw; ++l) {
     if (l < rl) {
-      const uint32_t m = rle_encode(cur, c, V, pool + pool_used, pool_cap - pool_used);
+      const uint32_t m = rle_encode(cur, c, V, pool, pool_cap);
       bool id;
       if (m == kRleOverflow) {
         /* a partial compaction may have overwritten the head of V: only an input still in HBM can be recounted */
@@ -673,17 +710,33 @@ __device__ __forceinline__ uint32_t compress_sub(
       } else {
         id = can_skip && m == c; /* no runs: V holds the values unchanged, the runs (all 1) are dropped */
         cur = V;
-        if (!id) {
-          c = m;
-          pool_used += m;
-        }
-      }
-      if (lane == 0) {
-        ident[l] = id ? 1u : 0u;
-        run_off[l] = id ? pool_used : pool_used - c;
-        counts[l] = c;
+        c = m;
       }
       wave::sync();
+      uint64_t mn;
+      uint32_t bits;
+      if (id) { /* all run lengths are 1: what stream_range finds for them, without the stream */
+        mn = c ? 1 : 0;
+        bits = 0;
+      } else if (p.use_bp) {
+        Stream<uint16_t> s{pool};
+        stream_range(s, c, 2, false, mn, bits);
+      } else {
+        mn = 0;
+        bits = 16;
+      }
+      const uint32_t sb = stream_bytes(c, bits);
+      if (pos + sb >= raw_sz) {
+        raw = true;
+        break;
+      }
+      if (lane == 0) {
+        out32[1 + l] = c;
+      }
+      Stream<uint16_t> s{pool};
+      pack_stream(dst + pos, s, c, 2, mn, bits);
+      pos += sb;
+      wave::sync(); /* the pool is free for the next layer */
     }
     if (l < p.num_deltas) {
       if (cur == in) { /* nothing has moved the data into V yet */
@@ -697,44 +750,26 @@ __device__ __forceinline__ uint32_t compress_sub(
     }
   }
   wave::sync();
-  /* sizes first: a sub-chunk that would not shrink is stored raw */
-  uint64_t* mins = meta->mins;
-  uint32_t* bitsv = meta->bits;
-  uint32_t sz = 4 + 4 * p.num_rles;
-  for (uint32_t l = 0; l < p.num_rles; ++l) {
-    if (ident[l]) { /* all run lengths are 1: what stream_range finds for them, without the stream */
-      if (lane == 0) {
-        mins[l] = counts[l] ? 1 : 0;
-        bitsv[l] = 0;
-      }
-      wave::sync();
-    } else if (p.use_bp) {
-      Stream<uint16_t> s{pool + run_off[l]};
-      stream_range(s, counts[l], 2, false, mins[l], bitsv[l]);
-    } else {
-      mins[l] = 0;
-      bitsv[l] = 16;
-    }
-    sz += stream_bytes(counts[l], bitsv[l]);
-  }
-  {
+  if (!raw) {
     const bool as_signed = p.num_deltas > 0 ? true : type_signed(p.type);
+    uint64_t mn = 0;
+    uint32_t bits = 8 * w;
+    Stream<T> s{(T*)cur};
     if (p.use_bp) {
-      Stream<T> s{(T*)cur};
-      stream_range(s, c, w, as_signed, mins[8], bitsv[8]);
-    } else {
-      mins[8] = 0;
-      bitsv[8] = 8 * w;
+      stream_range(s, c, w, as_signed, mn, bits);
     }
-    sz += stream_bytes(c, bitsv[8]);
+    const uint32_t sb = stream_bytes(c, bits);
+    if (pos + sb >= raw_sz) {
+      raw = true;
+    } else {
+      pack_stream(dst + pos, s, c, w, mn, bits);
+      pos += sb;
+    }
   }
-  const uint32_t raw_sz = 4 + ((bytes + 3u) & ~3u);
-  uint32_t* out32 = (uint32_t*)dst;
-  if (sz >= raw_sz) {
+  if (raw) { /* would not shrink: marker + the bytes, zero padded to a multiple of 4 */
     if (lane == 0) {
       out32[0] = kRawMarker;
     }
-    /* raw bytes, zero padded to a multiple of 4 */
     const uint32_t padded = raw_sz - 4;
     copy_bytes(dst + 4, src, bytes);
     if (lane < padded - bytes) {
@@ -744,18 +779,6 @@ __device__ __forceinline__ uint32_t compress_sub(
   }
   if (lane == 0) {
     out32[0] = n;
-    for (uint32_t l = 0; l < p.num_rles; ++l) {
-      out32[1 + l] = counts[l];
-    }
-  }
-  uint32_t pos = 4 + 4 * p.num_rles;
-  for (uint32_t l = 0; l < p.num_rles; ++l) {
-    Stream<uint16_t> s{pool + run_off[l]};
-    pos += pack_stream(dst + pos, s, counts[l], 2, mins[l], bitsv[l]);
-  }
-  {
-    Stream<T> s{(T*)cur};
-    pos += pack_stream(dst + pos, s, c, w, mins[8], bitsv[8]);
   }
   return pos;
 }
@@ -944,18 +967,19 @@ __device__ __forceinline__ uint32_t decompress_sub(
   return kSubOk;
 }
 
-/* Worst case of compress_sub: LayerMeta, the value buffer of n elements, num_rles run pools of n entries. */
+/* Worst case of compress_sub: the value buffer of n elements and one run pool of n entries (none without RLE). */
 __host__ __device__ inline uint32_t compress_lds_per_wave(uint32_t sub_bytes, uint32_t width, uint32_t num_rles)
 {
   const uint32_t n = sub_bytes / width;
-  return ((uint32_t)((sizeof(LayerMeta) + 15u) & ~15u)) + ((sub_bytes + 15u) & ~15u) + ((2 * num_rles * n + 15u) & ~15u);
+  return 64 + ((sub_bytes + 15u) & ~15u) + (num_rles ? ((2 * n + 15u) & ~15u) : 0u);
 }
 
-/* Worst case of decompress_sub: LayerMeta, two value buffers, the run pools, the marks of an expansion. */
+/* Worst case of decompress_sub: LayerMeta, two value buffers, num_rles run pools, the marks of an expansion. */
 __host__ __device__ inline uint32_t decompress_lds_per_wave(uint32_t sub_bytes, uint32_t width, uint32_t num_rles)
 {
   const uint32_t n = sub_bytes / width;
-  return compress_lds_per_wave(sub_bytes, width, num_rles) + ((sub_bytes + 15u) & ~15u) + (num_rles ? ((2 * n + 15u) & ~15u) : 0u);
+  return ((uint32_t)((sizeof(LayerMeta) + 15u) & ~15u)) + 2 * ((sub_bytes + 15u) & ~15u) + ((2 * num_rles * n + 15u) & ~15u)
+         + (num_rles ? ((2 * n + 15u) & ~15u) : 0u);
 }
 
 } // namespace casc
