@@ -197,28 +197,45 @@ __global__ void cascaded_decompress_kernel(
     const uint8_t* payload = src + kHeaderBytes + 4 * (size_t)num_sub;
     const uint32_t pay_len = (uint32_t)(src_len - kHeaderBytes - 4 * (size_t)num_sub);
     uint8_t* slice = lds + (size_t)wv * lds_per_wave;
-    uint32_t begin = 0;
+    /* The sub-chunk table is read 64 entries at a time (one coalesced load, then v_readlane), and the first
+     * 256 bytes of the NEXT sub-chunk -- all of its header words -- are requested before the current one is
+     * decoded: per sub-chunk one memory round trip is exposed (the packed words) instead of three. */
+    uint32_t tab = 0;
+    auto load_head = [&](uint32_t b, uint32_t e) -> uint32_t {
+      const uint32_t lim = e < pay_len ? e : pay_len;
+      return (b <= lim && 4 * lane + 4 <= lim - b) ? *(const uint32_t*)(payload + b + 4 * lane) : 0u;
+    };
+    uint32_t begin = 0, end = 0, head = 0;
     for (uint32_t s = 0; s < num_sub && !err && !deferred; ++s) {
-      const uint32_t end = wave::uniform(table[s]);
+      if ((s & 63u) == 0) {
+        tab = s + lane < num_sub ? table[s + lane] : 0u;
+        end = wave::read_lane(tab, 0);
+        head = load_head(begin, end);
+      }
       const uint32_t off = s * sub;
       const uint32_t bytes = n_bytes - off < sub ? n_bytes - off : sub;
       if (end < begin || end > pay_len || end - begin < 4) {
         err = casc::kErrInput;
         break;
       }
+      uint32_t next_end = 0, next_head = 0;
+      if (s + 1 < num_sub && ((s + 1) & 63u) != 0) {
+        next_end = wave::read_lane(tab, (s + 1) & 63u);
+        next_head = load_head(end, next_end);
+      }
       uint32_t rc;
       switch (w) {
       case 1:
-        rc = casc::decompress_sub<uint8_t>(payload + begin, end - begin, dst + off, bytes, num_rles, num_deltas, slice, lds_per_wave);
+        rc = casc::decompress_sub<uint8_t>(payload + begin, end - begin, head, dst + off, bytes, num_rles, num_deltas, slice, lds_per_wave);
         break;
       case 2:
-        rc = casc::decompress_sub<uint16_t>(payload + begin, end - begin, dst + off, bytes, num_rles, num_deltas, slice, lds_per_wave);
+        rc = casc::decompress_sub<uint16_t>(payload + begin, end - begin, head, dst + off, bytes, num_rles, num_deltas, slice, lds_per_wave);
         break;
       case 4:
-        rc = casc::decompress_sub<uint32_t>(payload + begin, end - begin, dst + off, bytes, num_rles, num_deltas, slice, lds_per_wave);
+        rc = casc::decompress_sub<uint32_t>(payload + begin, end - begin, head, dst + off, bytes, num_rles, num_deltas, slice, lds_per_wave);
         break;
       default:
-        rc = casc::decompress_sub<uint64_t>(payload + begin, end - begin, dst + off, bytes, num_rles, num_deltas, slice, lds_per_wave);
+        rc = casc::decompress_sub<uint64_t>(payload + begin, end - begin, head, dst + off, bytes, num_rles, num_deltas, slice, lds_per_wave);
         break;
       }
       if (rc == casc::kSubNeedLds) {
@@ -231,6 +248,8 @@ __global__ void cascaded_decompress_kernel(
         err = casc::kErrInput;
       }
       begin = end;
+      end = next_end;
+      head = next_head;
       wave::sync();
     }
     produced = n_bytes;

@@ -799,8 +799,8 @@ __device__ __forceinline__ uint32_t align16(uint32_t v)
  * 3.5 x the sub-chunk; the last RLE layer expands straight into `dst` (HBM). */
 template <typename T>
 __device__ __forceinline__ uint32_t decompress_sub(
-    const uint8_t* src, uint32_t avail, uint8_t* dst, uint32_t bytes, uint32_t num_rles, uint32_t num_deltas, uint8_t* lds,
-    uint32_t budget)
+    const uint8_t* src, uint32_t avail, uint32_t head, uint8_t* dst, uint32_t bytes, uint32_t num_rles, uint32_t num_deltas,
+    uint8_t* lds, uint32_t budget)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   const uint32_t w = sizeof(T);
@@ -808,9 +808,9 @@ __device__ __forceinline__ uint32_t decompress_sub(
   if (avail < 4) {
     return kSubBad;
   }
-  /* the first 256 bytes of the sub-chunk in one coalesced load: all of its header words (a compressible
-   * sub-chunk fits entirely), read back with v_readlane instead of a dependent HBM round trip each */
-  const uint32_t head = 4 * lane + 4 <= avail ? *(const uint32_t*)(src + 4 * lane) : 0u;
+  /* `head`: the first 256 bytes of the sub-chunk (lane i holds dword i, zero beyond `avail`), loaded by the caller
+   * while the previous sub-chunk was being decoded: all of the header words (a compressible sub-chunk fits
+   * entirely), read back with v_readlane instead of a dependent HBM round trip each */
   auto word_at = [&](uint32_t byte_pos) -> uint32_t {
     return byte_pos < 256 ? wave::read_lane(head, byte_pos >> 2) : wave::uniform(*(const uint32_t*)(src + byte_pos));
   };
