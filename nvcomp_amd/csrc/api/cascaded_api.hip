@@ -20,9 +20,10 @@ constexpr uint32_t kHeaderBytes = 20;
 /* Decode runs three passes with growing LDS per wave; a sub-chunk's need follows from its actual stream counts
  * (casc::decompress_sub), so compressible data is decoded by the first pass at full occupancy. */
 constexpr uint32_t kSmallBudget = 5 * 1024;       /* pass 0: 4 waves per workgroup, 8 workgroups per CU */
-constexpr uint32_t kMidBudget = 8 * 1024 + 512;   /* compress pass 1: a 4 KiB sub-chunk and two full run pools: 4 workgroups per CU */
-constexpr uint32_t kFastBudget = 16 * 1024;       /* decode pass 1: 4 waves per workgroup (two value buffers: a variant that expands in
-                                                     place at twice the occupancy measured 30 % slower, the decoder is latency-bound) */
+constexpr uint32_t kMidBudget = 8 * 1024 + 512;   /* compress: a worst case up to here (4 KiB sub-chunks of >= 2-byte elements: value buffer +
+                                                     one run pool) is the last pass itself; beyond it an intermediate pass of this size runs first */
+constexpr uint32_t kFastBudget = 16 * 1024;       /* decode pass 1: 4 waves per workgroup (two value buffers + pools + marks: sub-chunks with
+                                                     long runs; short-run ones expand in place inside pass 0, casc::rle_expand_inplace) */
 constexpr uint32_t kBigBudget = 64 * 1024;        /* last pass: one wave per workgroup; also the compressor's limit */
 
 void clear_stale_error()
