@@ -17,7 +17,7 @@ constexpr unsigned kWavesPerBlock = 4;
 constexpr uint32_t kMaxOutCap = 1u << 26;
 
 template <class T, bool DELTA>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) bitcomp_compress_kernel(
+__global__ void __launch_bounds__(64 * kWavesPerBlock, 8) bitcomp_compress_kernel(
     const void* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
     size_t batch_size,

@@ -46,7 +46,7 @@ bool opts_ok(const nvcompBatchedCascadedOpts_t& o)
          && o.chunk_size >= 256 && o.chunk_size <= 16384 && o.chunk_size % w == 0;
 }
 
-__global__ void cascaded_compress_kernel(
+__global__ void __launch_bounds__(256, 8) cascaded_compress_kernel(
     const void* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
     size_t batch_size,
@@ -130,7 +130,7 @@ __global__ void cascaded_compress_kernel(
 
 /* pass p decodes the chunks with todo == p (pass 0: all) whose streams fit its LDS budget and hands the others
  * on by setting todo = p + 1. */
-__global__ void cascaded_decompress_kernel(
+__global__ void __launch_bounds__(256, 8) cascaded_decompress_kernel(
     const void* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes,
     const size_t* out_caps,

@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lz4_decompress_size_kerne
   }
 }
 
-__global__ void __launch_bounds__(64 * kWavesPerBlock) lz4_compress_kernel(
+__global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZM_WAVES_PER_SIMD) lz4_compress_kernel(
     const void* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
     size_t batch_size,

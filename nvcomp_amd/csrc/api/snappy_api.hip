@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) snappy_decompress_size_ke
   }
 }
 
-__global__ void __launch_bounds__(64 * kWavesPerBlock) snappy_compress_kernel(
+__global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZM_WAVES_PER_SIMD) snappy_compress_kernel(
     const void* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
     size_t batch_size,

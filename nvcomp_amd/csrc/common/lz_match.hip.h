@@ -35,6 +35,9 @@ namespace lzm {
 #ifndef NVCOMP_LZM_HASH_BITS
 #define NVCOMP_LZM_HASH_BITS 12
 #endif
+#ifndef NVCOMP_LZM_WAVES_PER_SIMD
+#define NVCOMP_LZM_WAVES_PER_SIMD 5 /* what the 8 KiB hash table per wave allows (4-wave workgroups, 160 KB LDS per CU) */
+#endif
 constexpr uint32_t kHashBits = NVCOMP_LZM_HASH_BITS;
 constexpr uint32_t kHashSize = 1u << kHashBits;
 constexpr uint32_t kMinMatch = 4;

@@ -27,9 +27,11 @@
 namespace lzw {
 
 /* Tunables (overridable with -D for the A/B builds of scripts/build_variants.sh). */
-/* Defaults from the MI355X sweeps of profiles/r01_window_variants.json and
- * r01_pchase_variants.json: a small window at 6-8 waves/SIMD beats a large one -- the decoder
- * is instruction-issue bound, not LDS- or HBM-bound; 6, 7 and 8 waves/SIMD measure the same. */
+/* Defaults from the MI355X sweeps of profiles/r01_window_variants.json, r01_pchase_variants.json and
+ * r01_occupancy_variants.json: a small window at 6-7 waves/SIMD beats a large one -- the decoder is
+ * instruction-issue bound, not LDS- or HBM-bound. The LDS slice (5.5 KiB/wave) allows 7 waves/SIMD; asking the
+ * compiler for 8 makes it give up on the register budget (74 VGPRs = 6 waves), asking for 7 yields 72 VGPRs
+ * and 3 spilled dwords: +2 %. */
 #ifndef NVCOMP_LZW_OUTWIN
 #define NVCOMP_LZW_OUTWIN 2048
 #endif
@@ -43,7 +45,7 @@ namespace lzw {
 #define NVCOMP_LZW_INRING 2048
 #endif
 #ifndef NVCOMP_LZW_WAVES_PER_SIMD
-#define NVCOMP_LZW_WAVES_PER_SIMD 8
+#define NVCOMP_LZW_WAVES_PER_SIMD 7
 #endif
 
 constexpr uint32_t kOutWin = NVCOMP_LZW_OUTWIN;     /* bytes of output window per wave */
