@@ -47,7 +47,8 @@ constexpr uint32_t kMinCodedBytes = 2048; /* smaller chunks are always stored */
 constexpr uint32_t kRingWords = 512;
 constexpr uint32_t kHistCopies = 4; /* the lanes spread their LDS atomics over this many histograms */
 constexpr uint32_t kEncodeLds = 1024 * kHistCopies; /* >= the 2 KiB symbol table that replaces the histograms */
-constexpr uint32_t kDecodeLds = kProbScale * 4 + kRingWords * 2 + 528;
+constexpr uint32_t kDecodeLds = kProbScale * 4 + kRingWords * 2; /* 5 KiB: 8 workgroups of 4 waves per CU */
+static_assert(kRingWords * 2 >= 2 * 257 + 2, "the cumulative frequencies borrow the ring's space while the table is built");
 constexpr uint32_t kErrNone = 0;
 constexpr uint32_t kErrInput = 1;
 constexpr uint32_t kErrOutput = 2;
@@ -371,7 +372,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
 
   uint32_t* table = (uint32_t*)lds;
   uint16_t* ring = (uint16_t*)(lds + kProbScale * 4);
-  uint16_t* cum = (uint16_t*)(lds + kProbScale * 4 + kRingWords * 2); /* 257 entries */
+  uint16_t* cum = ring; /* 257 entries, only while the table is built: the ring is filled afterwards */
 
   /* decode table from the frequencies */
   uint32_t f[4], start[4];
@@ -406,6 +407,8 @@ __device__ __forceinline__ uint32_t decode_chunk(
     const uint32_t lo = cum[s];
     table[slot] = s | ((cum[s + 1] - lo) << 8) | ((slot - lo) << 20);
   }
+
+  wave::sync(); /* the last reads of cum[] precede the first ring words */
 
   WordRing w;
   w.words = in + kWordsOffset;
