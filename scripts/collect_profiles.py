@@ -75,21 +75,29 @@ def main():
                     "effects. The calibration sessions ran at 16384 chunks.",
         }, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
     # own-format decode kernels (scripts/gpu_traffic.sh legs of the same session)
+    # traffic.log lines: "<algo> <COUNTER> KB per launch: <x> launches <n>"; the passes ran 3 decompress calls
+    # (1 warm-up + 2 timed), Cascaded launches its kernel once per pass (3 per call)
+    logged = {}
+    tl = os.path.join(src, "traffic.log")
+    if os.path.exists(tl):
+        for line in open(tl):
+            t = line.split()
+            if len(t) == 8 and t[2:5] == ["KB", "per", "launch:"]:
+                logged[(t[0], t[1])] = float(t[5]) * int(t[7]) / 3.0
     for algo in ("bitcomp", "ans", "cascaded"):
-        f = os.path.join(src, f"traffic_{algo}_FETCH_SIZE.json")
-        w = os.path.join(src, f"traffic_{algo}_WRITE_SIZE.json")
         b = bench.get("bench_" + algo)
-        if not (os.path.exists(f) and os.path.exists(w) and b):
+        if not ((algo, "FETCH_SIZE") in logged and (algo, "WRITE_SIZE") in logged and b):
             continue
-        fetch = json.load(open(f))["KB_per_launch"] * 1024
-        write = json.load(open(w))["KB_per_launch"] * 1024
+        fetch = logged[(algo, "FETCH_SIZE")] * 1024
+        write = logged[(algo, "WRITE_SIZE")] * 1024
         json.dump({
             "algo": algo, "dataset": b["config"]["dataset"], "chunks_per_gpu": b["config"]["chunks_per_gpu"],
             "hbm_bytes_per_launch": int(2 * fetch + write), "fetch_bytes_counted": int(fetch), "write_bytes_counted": int(write),
             "algorithmic_bytes": b["roofline"]["algorithmic_bytes_per_launch"],
             "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (scripts/gpu_traffic.sh, session {tag}), KB units, per "
-                    "decompress call; FETCH_SIZE doubled: these kernels read their input with wide coalesced loads, for which gfx950 "
-                    "reports 1/2 of the bytes (MI355X_MICROARCH.md 'HBM'; calibrated on the compressed size in session tr1).",
+                    "decompress call (all passes of a call summed); FETCH_SIZE doubled: these kernels read their input with wide "
+                    "coalesced loads, for which gfx950 reports 1/2 of the bytes (MI355X_MICROARCH.md 'HBM'; calibrated on the "
+                    "compressed size in session tr1).",
         }, open(os.path.join(dst, f"pmc_traffic_{algo}.json"), "w"), indent=1)
     print("collected", sorted(os.listdir(dst)))
 
