@@ -52,8 +52,9 @@ def valid_streams(oracle, fmt, chunks):
 def test_corrupt_streams_are_contained(backend, oracle, fmt):
     rng = np.random.RandomState(["LZ4", "Snappy", "Cascaded", "Bitcomp", "ANS"].index(fmt) * 101 + 17)
     n = 96 if backend.name == "gpu" else 24
-    gens = [datasets.text, datasets.int32_column, datasets.lowcard, datasets.table_rows]
-    chunks = [gens[i % 4](int(rng.choice([600, 4096, 20000, 65536])), i) for i in range(n)]
+    # float_columns: short runs in both Cascaded layers (the decoder's rle_expand_direct / rle_expand_inplace path)
+    gens = [datasets.text, datasets.int32_column, datasets.lowcard, datasets.table_rows, datasets.float_columns]
+    chunks = [gens[i % 5](int(rng.choice([600, 4096, 20000, 65536])), i) for i in range(n)]
     good, dec, opts = valid_streams(oracle, fmt, chunks)
     bad = [damage(rng, g) for g in good]
     caps = [c.size for c in chunks]
