@@ -43,6 +43,14 @@ nvcompStatus_t nvcompBatchedANSCompressGetTempSize(
     nvcompBatchedANSOpts_t format_opts,
     size_t* temp_bytes);
 
+/* reference: CHANGELOG.md:36-41 (nvcompBatched*CompressGetTempSizeEx; never called in tree) */
+nvcompStatus_t nvcompBatchedANSCompressGetTempSizeEx(
+    size_t batch_size,
+    size_t max_uncompressed_chunk_bytes,
+    nvcompBatchedANSOpts_t format_opts,
+    size_t* temp_bytes,
+    const size_t max_total_uncompressed_bytes);
+
 nvcompStatus_t nvcompBatchedANSCompressGetMaxOutputChunkSize(
     size_t max_uncompressed_chunk_bytes,
     nvcompBatchedANSOpts_t format_opts,
@@ -64,6 +72,13 @@ nvcompStatus_t nvcompBatchedANSDecompressGetTempSize(
     size_t num_chunks,
     size_t max_uncompressed_chunk_bytes,
     size_t* temp_bytes);
+
+/* reference: CHANGELOG.md:114-117 (nvcompBatched<Format>DecompressGetTempSizeEx) */
+nvcompStatus_t nvcompBatchedANSDecompressGetTempSizeEx(
+    size_t num_chunks,
+    size_t max_uncompressed_chunk_bytes,
+    size_t* temp_bytes,
+    size_t max_total_uncompressed_bytes);
 
 /* device_actual_uncompressed_bytes and device_statuses may each be NULL. */
 nvcompStatus_t nvcompBatchedANSDecompressAsync(

@@ -40,6 +40,14 @@ nvcompStatus_t nvcompBatchedBitcompCompressGetTempSize(
     nvcompBatchedBitcompFormatOpts format_opts,
     size_t* temp_bytes);
 
+/* reference: CHANGELOG.md:36-41 (nvcompBatched*CompressGetTempSizeEx; never called in tree) */
+nvcompStatus_t nvcompBatchedBitcompCompressGetTempSizeEx(
+    size_t batch_size,
+    size_t max_uncompressed_chunk_bytes,
+    nvcompBatchedBitcompFormatOpts format_opts,
+    size_t* temp_bytes,
+    const size_t max_total_uncompressed_bytes);
+
 nvcompStatus_t nvcompBatchedBitcompCompressGetMaxOutputChunkSize(
     size_t max_uncompressed_chunk_bytes,
     nvcompBatchedBitcompFormatOpts format_opts,
@@ -61,6 +69,13 @@ nvcompStatus_t nvcompBatchedBitcompDecompressGetTempSize(
     size_t num_chunks,
     size_t max_uncompressed_chunk_bytes,
     size_t* temp_bytes);
+
+/* reference: CHANGELOG.md:114-117 (nvcompBatched<Format>DecompressGetTempSizeEx) */
+nvcompStatus_t nvcompBatchedBitcompDecompressGetTempSizeEx(
+    size_t num_chunks,
+    size_t max_uncompressed_chunk_bytes,
+    size_t* temp_bytes,
+    size_t max_total_uncompressed_bytes);
 
 /* The reference requires non-NULL actual-size and status arrays for Bitcomp and is "not
  * fully asynchronous" (README.md:14-15); this build accepts NULL for either and never

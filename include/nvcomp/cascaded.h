@@ -43,6 +43,14 @@ nvcompStatus_t nvcompBatchedCascadedCompressGetTempSize(
     nvcompBatchedCascadedOpts_t format_opts,
     size_t* temp_bytes);
 
+/* reference: CHANGELOG.md:36-41 (nvcompBatched*CompressGetTempSizeEx; never called in tree) */
+nvcompStatus_t nvcompBatchedCascadedCompressGetTempSizeEx(
+    size_t batch_size,
+    size_t max_uncompressed_chunk_bytes,
+    nvcompBatchedCascadedOpts_t format_opts,
+    size_t* temp_bytes,
+    const size_t max_total_uncompressed_bytes);
+
 nvcompStatus_t nvcompBatchedCascadedCompressGetMaxOutputChunkSize(
     size_t max_uncompressed_chunk_bytes,
     nvcompBatchedCascadedOpts_t format_opts,
@@ -64,6 +72,13 @@ nvcompStatus_t nvcompBatchedCascadedDecompressGetTempSize(
     size_t num_chunks,
     size_t max_uncompressed_chunk_bytes,
     size_t* temp_bytes);
+
+/* reference: CHANGELOG.md:114-117 (nvcompBatched<Format>DecompressGetTempSizeEx) */
+nvcompStatus_t nvcompBatchedCascadedDecompressGetTempSizeEx(
+    size_t num_chunks,
+    size_t max_uncompressed_chunk_bytes,
+    size_t* temp_bytes,
+    size_t max_total_uncompressed_bytes);
 
 /* The reference requires non-NULL actual-size and status arrays for Cascaded
  * (README.md:14); this build accepts NULL for either (superset). */

@@ -74,9 +74,9 @@ ENTRY_POINTS = (
 EXTRA_ENTRY_POINTS = {
     "LZ4": ("CompressGetTempSizeEx", "DecompressGetTempSizeEx"),
     "Snappy": ("CompressGetTempSizeEx", "DecompressGetTempSizeEx"),
-    "Cascaded": (),
-    "Bitcomp": (),
-    "ANS": (),
+    "Cascaded": ("CompressGetTempSizeEx", "DecompressGetTempSizeEx"),
+    "Bitcomp": ("CompressGetTempSizeEx", "DecompressGetTempSizeEx"),
+    "ANS": ("CompressGetTempSizeEx", "DecompressGetTempSizeEx"),
 }
 
 

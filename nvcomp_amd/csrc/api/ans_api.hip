@@ -233,4 +233,21 @@ nvcompStatus_t nvcompBatchedANSGetDecompressSizeAsync(
   return launch_status();
 }
 
+nvcompStatus_t nvcompBatchedANSCompressGetTempSizeEx(
+    size_t batch_size,
+    size_t max_uncompressed_chunk_bytes,
+    nvcompBatchedANSOpts_t format_opts,
+    size_t* temp_bytes,
+    const size_t /*max_total_uncompressed_bytes*/)
+{
+  /* the scratch does not depend on the batch's total size */
+  return nvcompBatchedANSCompressGetTempSize(batch_size, max_uncompressed_chunk_bytes, format_opts, temp_bytes);
+}
+
+nvcompStatus_t nvcompBatchedANSDecompressGetTempSizeEx(
+    size_t num_chunks, size_t max_uncompressed_chunk_bytes, size_t* temp_bytes, size_t /*max_total_uncompressed_bytes*/)
+{
+  return nvcompBatchedANSDecompressGetTempSize(num_chunks, max_uncompressed_chunk_bytes, temp_bytes);
+}
+
 } // extern "C"

@@ -291,4 +291,21 @@ nvcompStatus_t nvcompBatchedBitcompGetDecompressSizeAsync(
   return launch_status();
 }
 
+nvcompStatus_t nvcompBatchedBitcompCompressGetTempSizeEx(
+    size_t batch_size,
+    size_t max_uncompressed_chunk_bytes,
+    nvcompBatchedBitcompFormatOpts format_opts,
+    size_t* temp_bytes,
+    const size_t /*max_total_uncompressed_bytes*/)
+{
+  /* the scratch does not depend on the batch's total size */
+  return nvcompBatchedBitcompCompressGetTempSize(batch_size, max_uncompressed_chunk_bytes, format_opts, temp_bytes);
+}
+
+nvcompStatus_t nvcompBatchedBitcompDecompressGetTempSizeEx(
+    size_t num_chunks, size_t max_uncompressed_chunk_bytes, size_t* temp_bytes, size_t /*max_total_uncompressed_bytes*/)
+{
+  return nvcompBatchedBitcompDecompressGetTempSize(num_chunks, max_uncompressed_chunk_bytes, temp_bytes);
+}
+
 } // extern "C"

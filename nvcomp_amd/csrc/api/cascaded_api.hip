@@ -456,4 +456,21 @@ nvcompStatus_t nvcompBatchedCascadedGetDecompressSizeAsync(
   return launch_status();
 }
 
+nvcompStatus_t nvcompBatchedCascadedCompressGetTempSizeEx(
+    size_t batch_size,
+    size_t max_uncompressed_chunk_bytes,
+    nvcompBatchedCascadedOpts_t format_opts,
+    size_t* temp_bytes,
+    const size_t /*max_total_uncompressed_bytes*/)
+{
+  /* the scratch does not depend on the batch's total size */
+  return nvcompBatchedCascadedCompressGetTempSize(batch_size, max_uncompressed_chunk_bytes, format_opts, temp_bytes);
+}
+
+nvcompStatus_t nvcompBatchedCascadedDecompressGetTempSizeEx(
+    size_t num_chunks, size_t max_uncompressed_chunk_bytes, size_t* temp_bytes, size_t /*max_total_uncompressed_bytes*/)
+{
+  return nvcompBatchedCascadedDecompressGetTempSize(num_chunks, max_uncompressed_chunk_bytes, temp_bytes);
+}
+
 } // extern "C"
