@@ -647,15 +647,13 @@ __device__ __forceinline__ bool rle_expand_inplace(T* A, const uint32_t* packed,
 
 constexpr uint32_t kSubNeedsLds = 0xffffffffu; /* compress_sub: the streams do not fit the LDS slice it was given */
 
-/* Per-wave bookkeeping of the layer loops, kept in LDS: indexing private arrays with the
- * run-time layer number would put them in scratch memory. */
+/* Per-wave bookkeeping of the decoder's layer loops, kept in LDS: indexing private arrays with the
+ * run-time layer number would put them in scratch memory. (The compressor packs every layer as soon as it
+ * has run and keeps nothing per layer.) */
 struct LayerMeta
 {
   uint32_t counts[8];
   uint32_t run_off[8];
-  uint32_t bits[9];
-  uint32_t pad;
-  uint64_t mins[9];
   uint32_t ident[8];   /* RLE layer l found no runs: values pass through, every run length is 1 */
   uint32_t src_off[8]; /* decode: where layer l's run stream starts inside the sub-chunk */
 };
