@@ -792,9 +792,10 @@ __device__ __forceinline__ uint32_t align16(uint32_t v)
 }
 
 /* Decode one sub-chunk with the calling wave. `lds`/`budget`: this wave's LDS slice. The slice is carved from
- * the stream's ACTUAL counts (LayerMeta first, then two value buffers of counts[0] elements, the run pools and
- * the marks of the final expansion), so well-compressed data needs a few KiB where the worst case needs
- * 3.5 x the sub-chunk; the last RLE layer expands straight into `dst` (HBM). */
+ * the stream's ACTUAL counts: LayerMeta, then either ONE value buffer of counts[0] elements when every expanding
+ * layer has short runs (rle_expand_direct / rle_expand_inplace: no pool, no marks), or two value buffers, the run
+ * pools and the marks of the final expansion. Well-compressed or run-poor data needs a few KiB where the worst
+ * case needs 3.5 x the sub-chunk; the outermost RLE layer expands straight into `dst` (HBM). */
 template <typename T>
 __device__ __forceinline__ uint32_t decompress_sub(
     const uint8_t* src, uint32_t avail, uint32_t head, uint8_t* dst, uint32_t bytes, uint32_t num_rles, uint32_t num_deltas,
