@@ -120,13 +120,27 @@ static int c_snappy_enc(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size
   return *out == 0 ? 1 : 0;
 }
 
+static int c_cascaded_dec(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out)
+{
+  return oracle_cascaded_decompress(s, n, d, cap, out);
+}
+static int c_bitcomp_dec(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out)
+{
+  return oracle_bitcomp_decompress(s, n, d, cap, out);
+}
+static int c_ans_dec(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out)
+{
+  return oracle_ans_decompress(s, n, d, cap, out);
+}
+
 double oracle_batch_run(
     int codec, int threads, int repeats, size_t n_chunks,
     const uint8_t* const* in_ptrs, const size_t* in_sizes,
     uint8_t* const* out_ptrs, const size_t* out_caps, size_t* out_sizes, int* errors)
 {
-  static const batch_codec_fn table[4] = {c_lz4_dec, c_snappy_dec, c_lz4_enc, c_snappy_enc};
-  if (codec < 0 || codec > 3) {
+  static const batch_codec_fn table[7] = {c_lz4_dec, c_snappy_dec, c_lz4_enc, c_snappy_enc,
+                                          c_cascaded_dec, c_bitcomp_dec, c_ans_dec};
+  if (codec < 0 || codec > 6) {
     return -1.0;
   }
   return batch_run_generic(

@@ -49,7 +49,8 @@ size_t oracle_ans_compress(const uint8_t* src, size_t n_bytes, uint8_t* dst, siz
 int oracle_ans_decompress(const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_cap, size_t* out_len);
 
 /* Batched, threaded drivers used for the cpu_baseline timing (oracle/batch.c).
- * codec: 0 = lz4 decompress, 1 = snappy decompress, 2 = lz4 compress, 3 = snappy compress.
+ * codec: 0 = lz4 decompress, 1 = snappy decompress, 2 = lz4 compress, 3 = snappy compress,
+ * 4 / 5 / 6 = cascaded / bitcomp / ans decompress (the own-stream CPU models).
  * Returns wall seconds of the best of `repeats` runs; per-chunk result sizes in out_sizes. */
 double oracle_batch_run(
     int codec, int threads, int repeats, size_t n_chunks,

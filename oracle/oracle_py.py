@@ -23,6 +23,7 @@ _PORT = os.path.join(_HERE, "liboracle.so")
 _REF = os.path.join(_HERE, "_ref", "libcpucodecs.so")
 
 LZ4_DEC, SNAPPY_DEC, LZ4_ENC, SNAPPY_ENC, LZ4_ENC_HC = 0, 1, 2, 3, 4
+CASCADED_DEC, BITCOMP_DEC, ANS_DEC = 4, 5, 6  # oracle_batch_run only (the port library; 4 means HC in the reference shim)
 
 _u8p = C.POINTER(C.c_uint8)
 _szp = C.POINTER(C.c_size_t)
