@@ -138,6 +138,70 @@ def test_every_element_kind(backend, oracle):
     assert sizes.tolist() == [c.size for c in chunks]
 
 
+def test_copy_trains(backend, oracle):
+    """Trains of copy elements with the same offset and no literal between them -- how the format spells a match longer
+    than 64 bytes. The decoder merges a train into one match per batch (snappy_decode_window.hip.h): trains shorter and
+    longer than a batch, trains longer than the window, overlapping periods 1..7, mixed copy-1/2/4 encodings of the
+    same offset, trains cut by a literal or by a change of offset, and a train right at the start of a batch."""
+    rng = np.random.RandomState(77)
+    streams, raws = [], []
+
+    def build(program):
+        body, raw = b"", bytearray()
+        for op in program:
+            if op[0] == "lit":
+                blk = rng.randint(0, 256, size=op[1]).astype(np.uint8).tobytes()
+                body += _lit(blk)
+                raw += blk
+            else:
+                _, kind, off, ln = op
+                assert 0 < off <= len(raw)
+                if kind == 1:
+                    assert 4 <= ln <= 11 and off < 2048
+                    body += bytes([1 | ((ln - 4) << 2) | ((off >> 8) << 5), off & 255])
+                elif kind == 2:
+                    body += bytes([2 | ((ln - 1) << 2)]) + off.to_bytes(2, "little")
+                else:
+                    body += bytes([3 | ((ln - 1) << 2)]) + off.to_bytes(4, "little")
+                for _ in range(ln):
+                    raw.append(raw[-off])
+        streams.append(_varint(len(raw)) + body)
+        raws.append(bytes(raw))
+
+    # one long train per period, far longer than window + batch
+    for off in (1, 2, 3, 4, 5, 7, 64, 100):
+        build([("lit", 100)] + [("copy", 2, off, 64)] * 150)
+    # trains of random length and element sizes, same offset, separated by literals or by an offset change
+    for _ in range(6):
+        prog = [("lit", 300)]
+        produced = 300
+        for _ in range(200):
+            if produced > 60000:  # stay inside one 64 KiB chunk (2-byte offsets)
+                break
+            off = int(rng.choice([1, 3, 8, 63, 64, 65, 200, produced]))
+            off = min(off, produced)
+            for _ in range(int(rng.choice([1, 2, 3, 5, 17, 40, 70]))):
+                kind = int(rng.choice([1, 2, 3])) if off < 2048 else int(rng.choice([2, 3]))
+                ln = int(rng.randint(4, 12)) if kind == 1 else int(rng.choice([1, 2, 3, 4, 31, 32, 33, 63, 64]))
+                prog.append(("copy", kind, off, ln))
+                produced += ln
+            if rng.rand() < 0.5:
+                n = int(rng.choice([1, 2, 3, 4, 5, 60, 61]))
+                prog.append(("lit", n))
+                produced += n
+        build(prog)
+    # a train that starts as the very first element after a 1-byte literal, and 63 one-byte copies then a long one
+    build([("lit", 1)] + [("copy", 2, 1, 64)] * 40 + [("lit", 2)] + [("copy", 2, 2, 1)] * 63 + [("copy", 2, 2, 64)] * 30)
+    chunks = [np.frombuffer(r, dtype=np.uint8) for r in raws]
+    comp = [np.frombuffer(s, dtype=np.uint8) for s in streams]
+    if oracle.have_ref():
+        for s, r in zip(comp, chunks):
+            rc, out = oracle.ref_snappy_decompress(s, max(r.size, 1))
+            assert rc == 0 and np.array_equal(out, r), "hand-built stream is not legal snappy"
+    check_decode(backend, oracle, chunks, comp)
+    check_decode(backend, oracle, chunks, comp, checked=False)
+
+
 def test_corrupt_streams(backend, oracle):
     rng = np.random.RandomState(23)
     chunks = datasets.split_chunks(datasets.table_rows(24000, 4), 4000)
