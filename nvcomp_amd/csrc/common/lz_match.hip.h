@@ -39,13 +39,25 @@ namespace lzm {
 #define NVCOMP_LZM_WAVES_PER_SIMD 5 /* what the 8 KiB hash table per wave allows (4-wave workgroups, 160 KB LDS per CU) */
 #endif
 constexpr uint32_t kHashBits = NVCOMP_LZM_HASH_BITS;
+/* Entries of the per-wave table. A power of two by default; -DNVCOMP_LZM_HASH_ENTRIES=3072 (a multiple of 128) gives
+ * the 6 KiB table that fits 6 waves/SIMD (with -DNVCOMP_LZM_WAVES_PER_SIMD=6) -- an A/B build, not yet measured. */
+#ifdef NVCOMP_LZM_HASH_ENTRIES
+constexpr uint32_t kHashSize = NVCOMP_LZM_HASH_ENTRIES;
+#else
 constexpr uint32_t kHashSize = 1u << kHashBits;
+#endif
+static_assert(kHashSize % 128 == 0 && kHashSize <= 65536, "the table is cleared 64 dwords at a time");
 constexpr uint32_t kMinMatch = 4;
 constexpr uint32_t kLaneCap = 36; /* per-lane match measurement: 4 + 8 dword compares */
 
 __device__ __forceinline__ uint32_t hash4(uint32_t v)
 {
-  return (v * 2654435761u) >> (32 - kHashBits);
+  const uint32_t h = v * 2654435761u;
+  if constexpr ((kHashSize & (kHashSize - 1)) == 0) {
+    return h >> (32 - kHashBits);
+  } else {
+    return __umulhi(h, kHashSize); /* multiply-shift range reduction onto [0, kHashSize) */
+  }
 }
 
 /* Wave-cooperative extension of a match known to be at least `have` bytes long. */
