@@ -88,32 +88,55 @@ static uint64_t bc_value(const uint8_t* src, size_t i, unsigned s, int algo)
 }
 
 /* set `bits` bits of `v` at bit position `pos` of lane `lane`'s bit string inside `payload` */
+/* The lane's bit string lives in its dwords: dword d of lane l at payload + (64 d + l) * 4, little endian, bit b of
+ * the string = bit b % 32 of dword b / 32. A value of up to 64 bits touches at most three of them. */
+static uint32_t bc_dword(const uint8_t* payload, unsigned lane, uint64_t d)
+{
+  const uint8_t* p = payload + (d * 64 + lane) * 4;
+  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+static void bc_or_dword(uint8_t* payload, unsigned lane, uint64_t d, uint32_t x)
+{
+  uint8_t* p = payload + (d * 64 + lane) * 4;
+  p[0] |= (uint8_t)x;
+  p[1] |= (uint8_t)(x >> 8);
+  p[2] |= (uint8_t)(x >> 16);
+  p[3] |= (uint8_t)(x >> 24);
+}
+
 static void bc_put(uint8_t* payload, unsigned lane, uint64_t pos, uint64_t v, unsigned bits)
 {
-  for (unsigned b = 0; b < bits; ++b) {
-    if ((v >> b) & 1) {
-      const uint64_t bit = pos + b;
-      const uint64_t dword = bit / 32;
-      const unsigned in_dword = (unsigned)(bit % 32);
-      uint8_t* p = payload + (dword * 64 + lane) * 4 + in_dword / 8;
-      *p |= (uint8_t)(1u << (in_dword % 8));
-    }
+  if (bits == 0) {
+    return;
+  }
+  v &= bc_mask(bits);
+  const uint64_t d = pos / 32;
+  const unsigned sh = (unsigned)(pos % 32);
+  bc_or_dword(payload, lane, d, (uint32_t)(v << sh));
+  if (sh + bits > 32) {
+    bc_or_dword(payload, lane, d + 1, (uint32_t)(v >> (32 - sh)));
+  }
+  if (sh + bits > 64) {
+    bc_or_dword(payload, lane, d + 2, (uint32_t)(v >> (64 - sh)));
   }
 }
 
 static uint64_t bc_get(const uint8_t* payload, unsigned lane, uint64_t pos, unsigned bits)
 {
-  uint64_t v = 0;
-  for (unsigned b = 0; b < bits; ++b) {
-    const uint64_t bit = pos + b;
-    const uint64_t dword = bit / 32;
-    const unsigned in_dword = (unsigned)(bit % 32);
-    const uint8_t* p = payload + (dword * 64 + lane) * 4 + in_dword / 8;
-    if ((*p >> (in_dword % 8)) & 1) {
-      v |= 1ull << b;
-    }
+  if (bits == 0) {
+    return 0;
   }
-  return v;
+  const uint64_t d = pos / 32;
+  const unsigned sh = (unsigned)(pos % 32);
+  uint64_t v = (uint64_t)bc_dword(payload, lane, d) >> sh;
+  if (sh + bits > 32) {
+    v |= (uint64_t)bc_dword(payload, lane, d + 1) << (32 - sh);
+  }
+  if (sh + bits > 64) { /* sh > 0 here */
+    v |= (uint64_t)bc_dword(payload, lane, d + 2) << (64 - sh);
+  }
+  return v & bc_mask(bits);
 }
 
 size_t oracle_bitcomp_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t dst_cap, int algo, int elem_size)
