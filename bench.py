@@ -462,7 +462,9 @@ def own_format_cpu_baseline(oracle, algo, comp, chunks, threads):
     """The CPU model of the stream (oracle/*_ref.c: a scalar port, written for clarity) over a bounded sample, one
     chunk per task on `threads` host threads (oracle/batch.c), best of 3 runs."""
     code = {"cascaded": oracle.CASCADED_DEC, "bitcomp": oracle.BITCOMP_DEC, "ans": oracle.ANS_DEC}[algo]
-    reps = max(1, min(16, (8 * threads + len(comp) - 1) // max(1, len(comp))))  # >= 8 chunks per thread
+    # >= 64 chunks (4 MiB) per thread, at most 16 x the unique set (1 GiB by default): starting and joining 256 threads
+    # costs milliseconds, a smaller sample would time that instead of the codec
+    reps = max(1, min(16, (64 * threads + len(comp) - 1) // max(1, len(comp))))
     s_comp, s_caps = list(comp) * reps, [c.size for c in chunks] * reps
     secs, outs, errs = oracle.batch_run(code, s_comp, s_caps, threads=threads, repeats=3)
     assert errs == 0 and all(o.size == c for o, c in zip(outs, s_caps))
