@@ -48,7 +48,9 @@ def parse_args():
                    help="lz4 is the headline (BASELINE.json configs[1]); cascaded/bitcomp/ans are this library's own stream "
                         "formats: their inputs are made by the HIP compressor (checked against the CPU model) outside the timed region")
     p.add_argument("--opts", default="", help="cascaded: chunk_size,type,num_RLEs,num_deltas,use_bp; bitcomp: algo,type")
-    p.add_argument("--mib-per-gpu", type=int, default=4096, help="uncompressed MiB decoded per GPU per step")
+    p.add_argument("--mib-per-gpu", type=int, default=None,
+                   help="uncompressed MiB decoded per GPU per step (default 4096; 1024 with --allgather, whose compaction "
+                        "step builds a mask over every output slot)")
     p.add_argument("--unique-mib", type=int, default=64, help="unique MiB generated + CPU-compressed per rank")
     p.add_argument("--unique-kib", type=int, default=0, help="(tests) unique KiB per rank, overrides --unique-mib/--mib-per-gpu")
     p.add_argument("--dataset", default=None,
@@ -608,6 +610,8 @@ def run_allgather_case(args, ctx):
 
 def main():
     args = parse_args()
+    if args.mib_per_gpu is None:
+        args.mib_per_gpu = 1024 if args.allgather else 4096
     if args.dataset is None:
         # BASELINE.json configs[3]: "int32 columnar floats" -> float columns shaped like the reference's ExampleFloatData.csv
         args.dataset = "float_columns" if args.algo in ("cascaded", "bitcomp") else "silesia_style"
