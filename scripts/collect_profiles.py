@@ -84,7 +84,7 @@ def main():
             t = line.split()
             if len(t) == 8 and t[2:5] == ["KB", "per", "launch:"]:
                 logged[(t[0], t[1])] = float(t[5]) * int(t[7]) / 3.0
-    for algo in ("bitcomp", "ans", "cascaded"):
+    for algo in ("bitcomp", "ans", "cascaded", "snappy"):
         b = bench.get("bench_" + algo)
         if not ((algo, "FETCH_SIZE") in logged and (algo, "WRITE_SIZE") in logged and b):
             continue
@@ -92,7 +92,11 @@ def main():
         write = logged[(algo, "WRITE_SIZE")] * 1024
         json.dump({
             "algo": algo, "dataset": b["config"]["dataset"], "chunks_per_gpu": b["config"]["chunks_per_gpu"],
-            "hbm_bytes_per_launch": int(2 * fetch + write), "fetch_bytes_counted": int(fetch), "write_bytes_counted": int(write),
+            # own formats: every read is a wide coalesced stream read (x2); Snappy: as for LZ4, only the stream part is
+            # half-counted (add 0.5 x C back), the far-match gathers stay as counted
+            "hbm_bytes_per_launch": int(fetch + 0.5 * b["config"]["compressed_bytes_per_gpu"] + write) if algo == "snappy"
+            else int(2 * fetch + write),
+            "fetch_bytes_counted": int(fetch), "write_bytes_counted": int(write),
             "algorithmic_bytes": b["roofline"]["algorithmic_bytes_per_launch"],
             "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (scripts/gpu_traffic.sh, session {tag}), KB units, per "
                     "decompress call (all passes of a call summed); FETCH_SIZE doubled: these kernels read their input with wide "
