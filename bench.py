@@ -62,6 +62,9 @@ def parse_args():
     p.add_argument("--no-extras", action="store_true", help="skip the GPU compress leg (ratio / compress GB/s)")
     p.add_argument("--allgather", action="store_true", help="benchmark_allgather.cpp path (N >= 2)")
     p.add_argument("--no-verify", action="store_true", help="(profiling of ablated kernels only) skip output checks")
+    p.add_argument("--lz-index-min-batch", type=int, default=None,
+                   help="include/nvcomp/amd_ext.h: smallest batch that takes the two-kernel (token index) LZ decode path; "
+                        "0 = always, a huge value = never (the single-kernel chase decoder)")
     p.add_argument("--dry-run-emu", action="store_true",
                    help="CPU-only self-test of this script's plumbing against tests/emu (prints value=null)")
     return p.parse_args()
@@ -227,6 +230,8 @@ def run_case(args, ctx):
     if own_format:
         opts = tuple(int(x) for x in args.opts.split(",")) if args.opts else OWN_FORMAT_OPTS[args.algo]
     codec = nvcomp_amd.BatchedCodec(lib, dev, fmt, opts)
+    if args.lz_index_min_batch is not None:
+        lib.nvcompAmdSetLZIndexMinBatch(args.lz_index_min_batch)
     threads = len(os.sched_getaffinity(0))
 
     # ---- build the batch (untimed) ----

@@ -11,33 +11,26 @@
 
 #include "common/log.h"
 
+#include "nvcomp/amd_ext.h"
+
+#include "common/tuning.h"
+
 #include "lz4/lz4_decode.hip.h"
 #include "lz4/lz4_decode_window.hip.h"
 #include "lz4/lz4_encode.hip.h"
+#include "lz4/lz4_index.hip.h"
 
 namespace {
 
 constexpr unsigned kWavesPerBlock = 4; /* 256-thread workgroups, one chunk per wave */
 constexpr uint32_t kMaxOutCap = 1u << 26;
 
-/* Kernel variant switch for A/B measurements: NVCOMP_AMD_LZ4_DECODE =
- *   window (default) LDS-staged sequence-parallel decoder (lz4_decode_window.hip.h)
- *   direct           sequence-parallel, decoding straight to HBM (lz4_decode.hip.h)
- *   serial           one sequence per step, whole-wave copies (ablation baseline) */
-int lz4_decode_variant()
-{
-  static const int v = [] {
-    const char* e = getenv("NVCOMP_AMD_LZ4_DECODE");
-    if (e == nullptr) {
-      return 0;
-    }
-    if (e[0] == 'a') {
-      return e[1] == '1' ? 11 : 12;
-    }
-    return e[0] == 'd' ? 1 : e[0] == 's' ? 2 : 0;
-  }();
-  return v;
-}
+/* A/B and ablation kernels exist in measurement builds only (scripts/build_variants.sh passes
+ * -DNVCOMP_AMD_LZ4_VARIANT=1 direct | 2 serial | 11 / 12 chase-only / chase+parse ablations, the last two with
+ * wrong output by construction); the shipped library has exactly one decoder and no run-time switch. */
+#ifndef NVCOMP_AMD_LZ4_VARIANT
+#define NVCOMP_AMD_LZ4_VARIANT 0
+#endif
 
 template <bool CHECKED, int ABLATE = 0>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZW_WAVES_PER_SIMD) lz4_decompress_window_kernel(
@@ -47,12 +40,16 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZW_WAVES_PER_SIMD
     size_t* actual_bytes,
     size_t batch_size,
     void* const* __restrict__ out_ptrs,
-    nvcompStatus_t* statuses)
+    nvcompStatus_t* statuses,
+    const uint32_t* __restrict__ index_counts /* non-null: only the chunks the indexer left out (lzi::kNotIndexed) */)
 {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][lzw::kLdsPerWave];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
   const size_t chunk = (size_t)blockIdx.x * kWavesPerBlock + w;
   if (chunk >= batch_size) {
+    return;
+  }
+  if (index_counts != nullptr && wave::uniform(index_counts[chunk]) != lzi::kNotIndexed) {
     return;
   }
   const uint8_t* in = wave::uniform_ptr((const uint8_t*)comp_ptrs[chunk]);
@@ -75,6 +72,56 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZW_WAVES_PER_SIMD
     lzw::prof_end();
 #endif
   }
+  if (wave::lane_id() == 0) {
+    if (actual_bytes != nullptr) {
+      actual_bytes[chunk] = err ? 0 : produced;
+    }
+    if (CHECKED) {
+      statuses[chunk] = err ? nvcompErrorCannotDecompress : nvcompSuccess;
+    }
+  }
+}
+
+/* Token indexer: one LANE per chunk, 64 chunks per single-wave workgroup (common/lz_index.hip.h). */
+__global__ void __launch_bounds__(64) lz4_index_kernel(
+    const void* const* __restrict__ comp_ptrs, const size_t* __restrict__ comp_bytes, size_t batch_size, lzi::Layout lay)
+{
+  __shared__ __attribute__((aligned(16))) uint32_t lds[lzi::kLdsDwords];
+  lzi::index_chunks<lz4i::Format>(comp_ptrs, comp_bytes, batch_size, lay, lds);
+}
+
+/* The window decoder fed from the token index: no chase tables in LDS, one wave per chunk. */
+template <bool CHECKED>
+__global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZW_INDEXED_WAVES_PER_SIMD) lz4_decompress_indexed_kernel(
+    const void* const* __restrict__ comp_ptrs,
+    const size_t* __restrict__ comp_bytes,
+    const size_t* out_caps,
+    size_t* actual_bytes,
+    size_t batch_size,
+    void* const* __restrict__ out_ptrs,
+    nvcompStatus_t* statuses,
+    lzi::Layout lay)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][lzw::kLdsPerWaveIndexed];
+  const uint32_t w = wave::uniform(threadIdx.x >> 6);
+  const size_t chunk = (size_t)blockIdx.x * kWavesPerBlock + w;
+  if (chunk >= batch_size) {
+    return;
+  }
+  const uint32_t n_tok = wave::uniform(lay.counts[chunk]);
+  if (n_tok == lzi::kNotIndexed) {
+    return; /* the chase decoder takes this chunk */
+  }
+  const uint8_t* in = wave::uniform_ptr((const uint8_t*)comp_ptrs[chunk]);
+  uint8_t* out = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
+  const uint32_t in_len = (uint32_t)wave::uniform64(comp_bytes[chunk]); /* <= lzi::kMaxInput */
+  size_t cap64 = wave::uniform64(out_caps[chunk]);
+  if (cap64 > kMaxOutCap) {
+    cap64 = kMaxOutCap;
+  }
+  uint32_t err = lz::kErrNone;
+  const uint32_t produced = lz4w::decode_chunk_indexed<CHECKED>(
+      in, in_len, out, (uint32_t)cap64, lds[w], lay.table + chunk * (size_t)lay.stride, n_tok, err);
   if (wave::lane_id() == 0) {
     if (actual_bytes != nullptr) {
       actual_bytes[chunk] = err ? 0 : produced;
@@ -185,6 +232,12 @@ unsigned grid_for(size_t batch_size)
   return (unsigned)((batch_size + kWavesPerBlock - 1) / kWavesPerBlock);
 }
 
+/* worst case of the block format: one length byte per 255 literals + token + slack (== LZ4_compressBound) */
+size_t lz4_bound(size_t n)
+{
+  return n + n / 255 + 16;
+}
+
 bool lz4_type_ok(nvcompType_t t)
 {
   return (t >= NVCOMP_TYPE_CHAR && t <= NVCOMP_TYPE_UINT) || t == NVCOMP_TYPE_BITS;
@@ -195,12 +248,13 @@ bool lz4_type_ok(nvcompType_t t)
 extern "C" {
 
 nvcompStatus_t nvcompBatchedLZ4DecompressGetTempSize(
-    size_t /*num_chunks*/, size_t /*max_uncompressed_chunk_bytes*/, size_t* temp_bytes)
+    size_t num_chunks, size_t max_uncompressed_chunk_bytes, size_t* temp_bytes)
 {
   if (temp_bytes == nullptr) {
     return nvcompErrorInvalidValue;
   }
-  *temp_bytes = 0; /* the decoder keeps all state in registers */
+  /* the token index: u32 count + one u16 per possible token of every chunk (common/lz_index.hip.h) */
+  *temp_bytes = num_chunks == 0 ? 0 : lzi::temp_bytes_for(num_chunks, lz4_bound(max_uncompressed_chunk_bytes));
   return nvcompSuccess;
 }
 
@@ -216,14 +270,15 @@ nvcompStatus_t nvcompBatchedLZ4DecompressAsync(
     const size_t* device_uncompressed_bytes,
     size_t* device_actual_uncompressed_bytes,
     size_t batch_size,
-    void* const /*device_temp_ptr*/,
-    size_t /*temp_bytes*/,
+    void* const device_temp_ptr,
+    size_t temp_bytes,
     void* const* device_uncompressed_ptrs,
     nvcompStatus_t* device_statuses,
     hipStream_t stream)
 {
-  nvlog::call(3, "nvcompBatchedLZ4DecompressAsync(batch_size=%zu, statuses=%s, actual_sizes=%s, stream=%p)", batch_size,
-              device_statuses ? "yes" : "null", device_actual_uncompressed_bytes ? "yes" : "null", (void*)stream);
+  nvlog::call(3, "nvcompBatchedLZ4DecompressAsync(batch_size=%zu, statuses=%s, actual_sizes=%s, temp_bytes=%zu, stream=%p)",
+              batch_size, device_statuses ? "yes" : "null", device_actual_uncompressed_bytes ? "yes" : "null", temp_bytes,
+              (void*)stream);
   if (batch_size == 0) {
     return nvcompSuccess;
   }
@@ -235,50 +290,50 @@ nvcompStatus_t nvcompBatchedLZ4DecompressAsync(
   const dim3 grid(grid_for(batch_size));
   const dim3 block(64 * kWavesPerBlock);
   const bool checked = device_statuses != nullptr;
-  const int variant = lz4_decode_variant();
-  const bool serial = variant == 2;
-  if (variant >= 10) { /* profiling-only ablations (NVCOMP_AMD_LZ4_DECODE=a1|a2): wrong output by design */
-    if (variant == 11) {
-      hipLaunchKernelGGL((lz4_decompress_window_kernel<false, 1>), grid, block, 0, stream, device_compressed_ptrs,
-                         device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,
-                         batch_size, device_uncompressed_ptrs, device_statuses);
-    } else {
-      hipLaunchKernelGGL((lz4_decompress_window_kernel<false, 2>), grid, block, 0, stream, device_compressed_ptrs,
-                         device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,
-                         batch_size, device_uncompressed_ptrs, device_statuses);
-    }
-    return launch_status();
-  }
-  if (variant == 0) {
+#define NVCOMP_LZ4_ARGS                                                                                        \
+  device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes, \
+      batch_size, device_uncompressed_ptrs, device_statuses
+#if NVCOMP_AMD_LZ4_VARIANT == 0
+  /* Two-kernel path when the caller's temp buffer holds the token index and the batch is large enough to fill
+   * the indexer's lanes (one lane per chunk; below the threshold the chase decoder's latency is lower). */
+  const lzi::Layout lay = batch_size >= nvcomp_amd_tuning::lz_index_min_batch
+                              ? lzi::carve(device_temp_ptr, temp_bytes, batch_size)
+                              : lzi::Layout{nullptr, nullptr, 0};
+  const uint32_t* only = nullptr;
+  if (lay.stride != 0) {
+    hipLaunchKernelGGL(lz4_index_kernel, dim3((unsigned)((batch_size + 63) / 64)), dim3(64), 0, stream,
+                       device_compressed_ptrs, device_compressed_bytes, batch_size, lay);
     if (checked) {
-      hipLaunchKernelGGL((lz4_decompress_window_kernel<true>), grid, block, 0, stream, device_compressed_ptrs,
-                         device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,
-                         batch_size, device_uncompressed_ptrs, device_statuses);
+      hipLaunchKernelGGL((lz4_decompress_indexed_kernel<true>), grid, block, 0, stream, NVCOMP_LZ4_ARGS, lay);
     } else {
-      hipLaunchKernelGGL((lz4_decompress_window_kernel<false>), grid, block, 0, stream, device_compressed_ptrs,
-                         device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,
-                         batch_size, device_uncompressed_ptrs, device_statuses);
+      hipLaunchKernelGGL((lz4_decompress_indexed_kernel<false>), grid, block, 0, stream, NVCOMP_LZ4_ARGS, lay);
     }
-    return launch_status();
+    only = lay.counts; /* chunks the index leaves out (> 65535 bytes, row overflow) fall to the chase decoder */
   }
-#define NVCOMP_LZ4_LAUNCH(C, P)                                                                               \
-  hipLaunchKernelGGL((lz4_decompress_kernel<C, P>), grid, block, 0, stream, device_compressed_ptrs,           \
-                     device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,   \
-                     batch_size, device_uncompressed_ptrs, device_statuses)
   if (checked) {
-    if (serial) {
-      NVCOMP_LZ4_LAUNCH(true, false);
-    } else {
-      NVCOMP_LZ4_LAUNCH(true, true);
-    }
+    hipLaunchKernelGGL((lz4_decompress_window_kernel<true>), grid, block, 0, stream, NVCOMP_LZ4_ARGS, only);
   } else {
-    if (serial) {
-      NVCOMP_LZ4_LAUNCH(false, false);
-    } else {
-      NVCOMP_LZ4_LAUNCH(false, true);
-    }
+    hipLaunchKernelGGL((lz4_decompress_window_kernel<false>), grid, block, 0, stream, NVCOMP_LZ4_ARGS, only);
   }
-#undef NVCOMP_LZ4_LAUNCH
+#elif NVCOMP_AMD_LZ4_VARIANT == 11
+  hipLaunchKernelGGL((lz4_decompress_window_kernel<false, 1>), grid, block, 0, stream, NVCOMP_LZ4_ARGS, nullptr);
+#elif NVCOMP_AMD_LZ4_VARIANT == 12
+  hipLaunchKernelGGL((lz4_decompress_window_kernel<false, 2>), grid, block, 0, stream, NVCOMP_LZ4_ARGS, nullptr);
+#elif NVCOMP_AMD_LZ4_VARIANT == 3 /* the round-1 decoder: chase inside the decode kernel, whatever the batch size */
+  if (checked) {
+    hipLaunchKernelGGL((lz4_decompress_window_kernel<true>), grid, block, 0, stream, NVCOMP_LZ4_ARGS, nullptr);
+  } else {
+    hipLaunchKernelGGL((lz4_decompress_window_kernel<false>), grid, block, 0, stream, NVCOMP_LZ4_ARGS, nullptr);
+  }
+#else
+  if (checked) {
+    hipLaunchKernelGGL((lz4_decompress_kernel<true, NVCOMP_AMD_LZ4_VARIANT == 1>), grid, block, 0, stream, NVCOMP_LZ4_ARGS);
+  } else {
+    hipLaunchKernelGGL((lz4_decompress_kernel<false, NVCOMP_AMD_LZ4_VARIANT == 1>), grid, block, 0, stream, NVCOMP_LZ4_ARGS);
+  }
+#endif
+#undef NVCOMP_LZ4_ARGS
+  (void)temp_bytes;
   return launch_status();
 }
 
@@ -333,8 +388,7 @@ nvcompStatus_t nvcompBatchedLZ4CompressGetMaxOutputChunkSize(
   if (max_uncompressed_chunk_bytes > nvcompLZ4CompressionMaxAllowedChunkSize) {
     return nvcompErrorChunkSizeTooLarge;
   }
-  /* worst case of the block format: one length byte per 255 literals + token + slack */
-  *max_compressed_bytes = max_uncompressed_chunk_bytes + max_uncompressed_chunk_bytes / 255 + 16;
+  *max_compressed_bytes = lz4_bound(max_uncompressed_chunk_bytes);
   return nvcompSuccess;
 }
 

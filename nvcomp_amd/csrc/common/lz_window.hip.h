@@ -70,6 +70,11 @@ constexpr uint32_t kChaseWin = 256;                 /* stream positions one chas
 constexpr uint32_t kChaseLevels = 6;                /* jump tables for 1, 2, 4, 8, 16, 32 tokens ahead */
 constexpr uint32_t kChaseLds = NVCOMP_LZW_PCHASE ? kChaseLevels * kChaseWin : 0;
 constexpr uint32_t kLdsPerWave = kOutLds + kInLds + kChaseLds;
+/* the decoder fed from the token index (common/lz_index.hip.h) builds no jump tables: 4 144 B per wave = 8 waves/SIMD */
+constexpr uint32_t kLdsPerWaveIndexed = kOutLds + kInLds;
+#ifndef NVCOMP_LZW_INDEXED_WAVES_PER_SIMD
+#define NVCOMP_LZW_INDEXED_WAVES_PER_SIMD 8
+#endif
 
 constexpr uint32_t kLitShort = 32;   /* lane-parallel literal runs: up to 8 dwords */
 constexpr uint32_t kMatchShort = 32; /* lane-parallel matches:      up to 8 dwords */

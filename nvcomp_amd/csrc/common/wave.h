@@ -43,6 +43,16 @@ __device__ __forceinline__ u32x4 gload_u32x4_aligned(const uint8_t* p)
 {
   return *(const WAVE_GLOBAL u32x4*)p;
 }
+__device__ __forceinline__ u32x4 gload_u32x4(const uint8_t* p) /* any alignment (global_load_dwordx4) */
+{
+  const WAVE_GLOBAL PackedU32x4* q = (const WAVE_GLOBAL PackedU32x4*)p;
+  u32x4 r = {q->v[0], q->v[1], q->v[2], q->v[3]};
+  return r;
+}
+__device__ __forceinline__ uint32_t gload_u16(const uint16_t* p)
+{
+  return *(const WAVE_GLOBAL uint16_t*)p;
+}
 __device__ __forceinline__ void gstore_u8(uint8_t* p, uint32_t v)
 {
   *(WAVE_GLOBAL uint8_t*)p = (uint8_t)v;

@@ -84,7 +84,20 @@ def gpu():
 
 @pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
 def backend(request):
-    return request.getfixturevalue(request.param)
+    """Every test through this fixture runs the LZ decoders on their two-kernel path (token index + indexed
+    decoder: the library takes it for large batches; include/nvcomp/amd_ext.h moves the threshold). Tests of the
+    LZ decoders additionally ask for `lz_path` to see the single-kernel chase decoder too."""
+    b = request.getfixturevalue(request.param)
+    b.lib.nvcompAmdSetLZIndexMinBatch(1)
+    return b
+
+
+@pytest.fixture(params=["indexed", "chase"])
+def lz_path(request, backend):
+    """Both decode paths of nvcompBatched{LZ4,Snappy}DecompressAsync, whatever the batch size."""
+    backend.lib.nvcompAmdSetLZIndexMinBatch(1 if request.param == "indexed" else 1 << 60)
+    yield request.param
+    backend.lib.nvcompAmdSetLZIndexMinBatch(1)
 
 
 @pytest.fixture(scope="session")

@@ -49,7 +49,7 @@ def valid_streams(oracle, fmt, chunks):
 
 
 @pytest.mark.parametrize("fmt", ["LZ4", "Snappy", "Cascaded", "Bitcomp", "ANS"])
-def test_corrupt_streams_are_contained(backend, oracle, fmt):
+def test_corrupt_streams_are_contained(backend, lz_path, oracle, fmt):
     rng = np.random.RandomState(["LZ4", "Snappy", "Cascaded", "Bitcomp", "ANS"].index(fmt) * 101 + 17)
     n = 96 if backend.name == "gpu" else 24
     # float_columns: short runs in both Cascaded layers (the decoder's rle_expand_direct / rle_expand_inplace path)

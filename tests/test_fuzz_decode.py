@@ -35,7 +35,7 @@ def synth(rng, size):
 
 @pytest.mark.parametrize("fmt", ["LZ4", "Snappy"])
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_fuzz_structures(backend, oracle, fmt, seed):
+def test_fuzz_structures(backend, lz_path, oracle, fmt, seed):
     rng = np.random.RandomState(seed * 7919 + (0 if fmt == "LZ4" else 1))
     n_chunks = 24 if backend.name == "gpu" else 5
     sizes = [int(rng.choice([100, 1000, 5000, 20000, 65536, 70001, 150000])) for _ in range(n_chunks)]

@@ -12,7 +12,7 @@ MANIFEST = json.load(open(os.path.join(GOLDEN, "manifest.json")))
 
 
 @pytest.mark.parametrize("kind,fmt", [("lz4_default", "LZ4"), ("lz4_hc12", "LZ4"), ("snappy", "Snappy")])
-def test_decode_golden(backend, kind, fmt):
+def test_decode_golden(backend, lz_path, kind, fmt):
     comp, recs = [], []
     for entry in MANIFEST["files"].values():
         for rec in entry["chunks"]:

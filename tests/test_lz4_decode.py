@@ -35,14 +35,14 @@ def check_roundtrip(backend, oracle, chunks, comp, **kw):
 
 
 @pytest.mark.parametrize("name", ["text", "table", "float_csv", "float32", "int32", "lowcard", "zeros", "noise"])
-def test_classes_small(backend, oracle, name):
+def test_classes_small(backend, lz_path, oracle, name):
     size = 3 * 65536 + 1234 if backend.name == "gpu" else 65536 + 777
     data = datasets.CLASSES[name](size, 1)
     chunks = datasets.split_chunks(data)
     check_roundtrip(backend, oracle, chunks, cpu_compress(oracle, chunks))
 
 
-def test_hc_compressed_input(backend, oracle):
+def test_hc_compressed_input(backend, lz_path, oracle):
     if not oracle.have_ref():
         pytest.skip("liblz4 not available")
     data = datasets.table_rows(2 * 65536, 3)
@@ -51,13 +51,13 @@ def test_hc_compressed_input(backend, oracle):
 
 
 @pytest.mark.parametrize("checked,want_actual", [(True, True), (False, True), (True, False), (False, False)])
-def test_nullable_outputs(backend, oracle, checked, want_actual):
+def test_nullable_outputs(backend, lz_path, oracle, checked, want_actual):
     data = datasets.text(40000, 5)
     chunks = datasets.split_chunks(data, 16384)
     check_roundtrip(backend, oracle, chunks, cpu_compress(oracle, chunks), checked=checked, want_actual=want_actual)
 
 
-def test_ragged_and_tiny_chunks(backend, oracle):
+def test_ragged_and_tiny_chunks(backend, lz_path, oracle):
     rng = np.random.RandomState(7)
     sizes = [0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 31, 63, 64, 65, 255, 256, 257, 1000, 4095, 4097]
     base = datasets.text(8192, 9)
@@ -71,7 +71,7 @@ def test_ragged_and_tiny_chunks(backend, oracle):
     check_roundtrip(backend, oracle, chunks2, comp2)
 
 
-def test_unaligned_everything(backend, oracle):
+def test_unaligned_everything(backend, lz_path, oracle):
     data = datasets.table_rows(30000, 11)
     chunks = datasets.split_chunks(data, 5000)
     comp = cpu_compress(oracle, chunks)
@@ -79,7 +79,7 @@ def test_unaligned_everything(backend, oracle):
         check_roundtrip(backend, oracle, chunks, comp, base_misalign=mis)
 
 
-def test_long_matches_and_overlaps(backend, oracle):
+def test_long_matches_and_overlaps(backend, lz_path, oracle):
     # periods 1..70 and a few long ones exercise the pattern-doubling match copy
     parts = []
     rng = np.random.RandomState(13)
@@ -93,7 +93,7 @@ def test_long_matches_and_overlaps(backend, oracle):
     check_roundtrip(backend, oracle, chunks, cpu_compress(oracle, chunks))
 
 
-def test_corrupt_streams_do_not_escape(backend, oracle):
+def test_corrupt_streams_do_not_escape(backend, lz_path, oracle):
     """Invalid input -> status != success and size 0 (CHANGELOG.md:160-164); never a write
     outside the output slot (canaries) and, where the oracle accepts, identical bytes."""
     rng = np.random.RandomState(17)

@@ -31,13 +31,13 @@ def check_decode(backend, oracle, chunks, comp, **kw):
 
 
 @pytest.mark.parametrize("name", ["text", "table", "float_csv", "float32", "int32", "lowcard", "zeros", "noise"])
-def test_decode_classes(backend, oracle, name):
+def test_decode_classes(backend, lz_path, oracle, name):
     size = 3 * 65536 + 4321 if backend.name == "gpu" else 65536 + 321
     chunks = datasets.split_chunks(datasets.CLASSES[name](size, 2))
     check_decode(backend, oracle, chunks, cpu_compress(oracle, chunks))
 
 
-def test_reference_synth_workload(backend, oracle):
+def test_reference_synth_workload(backend, lz_path, oracle):
     """benchmark_snappy_synth: 64 KiB chunks of uniform bytes in [0,3], the same device array
     passed as capacity and as actual-size output (benchmarks/benchmark_snappy_synth.cpp:244-245)."""
     n = 8 if backend.name == "gpu" else 2
@@ -75,7 +75,7 @@ def _varint(v):
     return out + bytes([v])
 
 
-def test_every_element_kind(backend, oracle):
+def test_every_element_kind(backend, lz_path, oracle):
     """Hand-built legal streams: copy-1, copy-2, copy-4, 1..4-byte literal lengths,
     overlapping copies with offsets 1, 2, 3, copies of length 1..3 (copy-2 form)."""
     rng = np.random.RandomState(5)
@@ -138,7 +138,7 @@ def test_every_element_kind(backend, oracle):
     assert sizes.tolist() == [c.size for c in chunks]
 
 
-def test_copy_trains(backend, oracle):
+def test_copy_trains(backend, lz_path, oracle):
     """Trains of copy elements with the same offset and no literal between them -- how the format spells a match longer
     than 64 bytes. The decoder merges a train into one match per batch (snappy_decode_window.hip.h): trains shorter and
     longer than a batch, trains longer than the window, overlapping periods 1..7, mixed copy-1/2/4 encodings of the
@@ -202,7 +202,7 @@ def test_copy_trains(backend, oracle):
     check_decode(backend, oracle, chunks, comp, checked=False)
 
 
-def test_corrupt_streams(backend, oracle):
+def test_corrupt_streams(backend, lz_path, oracle):
     rng = np.random.RandomState(23)
     chunks = datasets.split_chunks(datasets.table_rows(24000, 4), 4000)
     comp = cpu_compress(oracle, chunks)
@@ -250,7 +250,7 @@ def test_compress_decodes_on_cpu(backend, oracle, name):
     assert ours <= cpu * 1.35 + 64, (ours, cpu)
 
 
-def test_roundtrip_ragged(backend, oracle):
+def test_roundtrip_ragged(backend, lz_path, oracle):
     rng = np.random.RandomState(9)
     base = datasets.text(9000, 3)
     sizes = [0, 1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 127, 128, 1000, 8000]
