@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZW_WAVES_PER_SIMD
     nvcompStatus_t* statuses,
     const uint32_t* __restrict__ index_counts /* non-null: only the chunks the indexer left out (lzi::kNotIndexed) */)
 {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][lzw::kLdsPerWave];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][lzg::kLdsPerWave];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
   const size_t chunk = (size_t)blockIdx.x * kWavesPerBlock + w;
   if (chunk >= batch_size) {
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZW_INDEXED_WAVES_
     nvcompStatus_t* statuses,
     lzi::Layout lay)
 {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][lzw::kLdsPerWaveIndexed];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][lzg::kLdsPerWaveIndexed];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
   const size_t chunk = (size_t)blockIdx.x * kWavesPerBlock + w;
   if (chunk >= batch_size) {

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZW_WAVES_PER_SIMD
     void* const* __restrict__ out_ptrs,
     nvcompStatus_t* statuses)
 {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][lzw::kLdsPerWave];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][lzg::kLdsPerWave];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
   const size_t chunk = (size_t)blockIdx.x * kWavesPerBlock + w;
   if (chunk >= batch_size) {

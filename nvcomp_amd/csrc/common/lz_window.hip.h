@@ -45,7 +45,7 @@ namespace lzw {
 #define NVCOMP_LZW_INRING 2048
 #endif
 #ifndef NVCOMP_LZW_WAVES_PER_SIMD
-#define NVCOMP_LZW_WAVES_PER_SIMD 7
+#define NVCOMP_LZW_WAVES_PER_SIMD 4
 #endif
 
 constexpr uint32_t kOutWin = NVCOMP_LZW_OUTWIN;     /* bytes of output window per wave */
@@ -73,7 +73,7 @@ constexpr uint32_t kLdsPerWave = kOutLds + kInLds + kChaseLds;
 /* the decoder fed from the token index (common/lz_index.hip.h) builds no jump tables: 4 144 B per wave = 8 waves/SIMD */
 constexpr uint32_t kLdsPerWaveIndexed = kOutLds + kInLds;
 #ifndef NVCOMP_LZW_INDEXED_WAVES_PER_SIMD
-#define NVCOMP_LZW_INDEXED_WAVES_PER_SIMD 8
+#define NVCOMP_LZW_INDEXED_WAVES_PER_SIMD 4
 #endif
 
 constexpr uint32_t kLitShort = 32;   /* lane-parallel literal runs: up to 8 dwords */
@@ -356,6 +356,7 @@ struct OutWindow
   uint32_t wbase;    /* output position of window index `align` (multiple of 16) */
   uint32_t valid_lo; /* positions >= valid_lo (and < op) are present in the window */
   uint32_t flushed;  /* positions < flushed are in HBM; valid_lo <= flushed <= op, op - flushed < 16 between batches */
+  uint8_t* scratch;  /* LDS, lzg::kScratch bytes: the gather executor's staging area and tables (common/lz_gather.hip.h) */
 };
 
 __device__ __forceinline__ void out_init(OutWindow& w, uint8_t* out, uint8_t* lds)
@@ -366,6 +367,7 @@ __device__ __forceinline__ void out_init(OutWindow& w, uint8_t* out, uint8_t* ld
   w.wbase = 0;
   w.valid_lo = 0;
   w.flushed = 0;
+  w.scratch = nullptr;
 }
 
 __device__ __forceinline__ uint8_t* out_at(const OutWindow& w, uint32_t pos)

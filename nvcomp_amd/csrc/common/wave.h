@@ -209,6 +209,12 @@ __device__ __forceinline__ void sync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+/* LDS word |= bits, no return value (ds_or_b32): lanes of one instruction may hit the same word. */
+__device__ __forceinline__ void lds_or(uint32_t* p, uint32_t bits)
+{
+  __hip_atomic_fetch_or(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 /* Trailing-zero / popcount helpers on ballots. */
 __device__ __forceinline__ uint32_t ctz64(uint64_t m)
 {

@@ -12,7 +12,7 @@
  */
 #pragma once
 
-#include "common/lz_window.hip.h"
+#include "common/lz_gather.hip.h"
 
 namespace lz4w {
 
@@ -257,6 +257,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
   lzw::OutWindow ow;
   lzw::in_init(ir, in, in_len, lds + lzw::kOutLds);
   lzw::out_init(ow, out, lds);
+  lzg::attach_scratch(ow, lds + lzw::kOutLds + lzw::kInLds + lzw::kChaseLds);
 #if NVCOMP_LZW_PCHASE
   lzw::Chase c;
   lzw::chase_init(c, ir.vbeg, lds + lzw::kOutLds + lzw::kInLds);
@@ -303,7 +304,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
       return 0;
     }
     bool big;
-    uint32_t take = lzw::execute_window_batch<CHECKED>(ir, ow, out_cap, op, count, s, err, big);
+    uint32_t take = lzg::execute_batch<CHECKED>(ir, ow, out_cap, op, count, s, err, big);
     if (CHECKED && err) {
       return 0;
     }
@@ -328,9 +329,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
         lz::wave_match_copy(out + op + llen, moff, mlen);
       }
       op += llen + mlen;
-      ow.wbase = op & ~15u;
-      ow.valid_lo = op;
-      ow.flushed = op;
+      lzg::restart_window(ow, op);
       take = 1;
     }
     /* drop the executed sequences, keep the rest for the next round */
@@ -363,6 +362,7 @@ __device__ __forceinline__ uint32_t decode_chunk_indexed(
   lzw::OutWindow ow;
   lzw::in_init(ir, in, in_len, lds + lzw::kOutLds);
   lzw::out_init(ow, out, lds);
+  lzg::attach_scratch(ow, lds + lzw::kOutLds + lzw::kInLds);
   uint32_t op = 0;
   uint32_t done = 0;  /* sequences executed */
   uint32_t wbase = 0; /* token index of tw0 lane 0 */
@@ -386,7 +386,7 @@ __device__ __forceinline__ uint32_t decode_chunk_indexed(
       return 0;
     }
     bool big;
-    uint32_t take = lzw::execute_window_batch<CHECKED>(ir, ow, out_cap, op, count, s, err, big);
+    uint32_t take = lzg::execute_batch<CHECKED>(ir, ow, out_cap, op, count, s, err, big);
     if (CHECKED && err) {
       return 0;
     }
@@ -411,9 +411,7 @@ __device__ __forceinline__ uint32_t decode_chunk_indexed(
         lz::wave_match_copy(out + op + llen, moff, mlen);
       }
       op += llen + mlen;
-      ow.wbase = op & ~15u;
-      ow.valid_lo = op;
-      ow.flushed = op;
+      lzg::restart_window(ow, op);
       take = 1;
     }
     done += take;

@@ -8,18 +8,7 @@
  */
 #pragma once
 
-/* Snappy's own window tunables (MI355X sweep, profiles/r01_occupancy_variants.json): its elements are half as long as
- * LZ4's sequences, so a batch of 64 fills a smaller window; 1472 bytes leave 5 104 B of LDS per wave = 8 waves/SIMD,
- * which this decoder (unlike LZ4's, which loses more to the spills of a 64-VGPR budget) turns into +4.5 %. */
-#ifndef NVCOMP_LZW_OUTWIN
-#define NVCOMP_LZW_OUTWIN 1472
-#define NVCOMP_LZW_BATCHMAX 736
-#define NVCOMP_LZW_KEEP 544
-#endif
-#ifndef NVCOMP_LZW_WAVES_PER_SIMD
-#define NVCOMP_LZW_WAVES_PER_SIMD 8
-#endif
-#include "common/lz_window.hip.h"
+#include "common/lz_gather.hip.h"
 
 namespace snappyw {
 
@@ -284,6 +273,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
   lzw::OutWindow ow;
   lzw::in_init(ir, in, in_len, lds + lzw::kOutLds);
   lzw::out_init(ow, out, lds);
+  lzg::attach_scratch(ow, lds + lzw::kOutLds + lzw::kInLds + lzw::kChaseLds);
   lzw::in_ensure(ir, ir.vbeg, ir.vbeg + lzw::kInBlock);
   /* varint32 preamble */
   uint32_t q = ir.vbeg;
@@ -361,7 +351,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
       }
     }
     bool big;
-    uint32_t take = lzw::execute_window_batch<CHECKED>(ir, ow, limit, op, count, s, err, big);
+    uint32_t take = lzg::execute_batch<CHECKED>(ir, ow, limit, op, count, s, err, big);
     if (CHECKED && err) {
       return 0;
     }
@@ -385,9 +375,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
         lz::wave_match_copy(out + op + llen, moff, mlen);
       }
       op += llen + mlen;
-      ow.wbase = op & ~15u;
-      ow.valid_lo = op;
-      ow.flushed = op;
+      lzg::restart_window(ow, op);
       take = 1 + wave::ctz64(~(train >> 1)); /* sequence 0 and the empty sequences of its train */
     }
     seqpos = wave::shuffle(seqpos, (lane + take) & 63u);

@@ -171,6 +171,8 @@ inline uint32_t reduce_add(uint32_t v)
 
 inline void sync() { emu::wave_rendezvous(kSync, 0, 0); }
 
+inline void lds_or(uint32_t* p, uint32_t bits) { *p |= bits; }
+
 inline uint32_t ctz64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
 inline uint32_t popc64(uint64_t m) { return (uint32_t)__builtin_popcountll(m); }
 inline uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t shift)
