@@ -13,13 +13,14 @@
 extern "C" {
 #endif
 
-/* nvcompBatched{LZ4,Snappy}DecompressAsync run as two kernels -- a token indexer with one
- * LANE per chunk, then the decoder proper fed from that index (held in the caller's temp
- * buffer) -- when the batch has at least this many chunks; smaller batches, which cannot
- * fill the indexer's lanes, use the single-kernel decoder that chases tokens itself.
- * Default: NVCOMP_AMD_LZ_INDEX_MIN_BATCH_DEFAULT. Returns the previous value. Process-wide;
- * not synchronised with concurrent *Async calls. */
-#define NVCOMP_AMD_LZ_INDEX_MIN_BATCH_DEFAULT 8192
+/* nvcompBatchedLZ4DecompressAsync can run as two kernels -- a token indexer with one LANE per chunk, then the
+ * decoder proper fed from that index (held in the caller's temp buffer) -- when the batch has at least this many
+ * chunks. Measured on MI355X (65 536 x 64 KiB, profiles/r02_decode_alternatives.json) the indexer's serial walk costs more
+ * than the in-kernel token chase it replaces (322 vs 452 GB/s), so the path is OFF by default (threshold = SIZE_MAX)
+ * and nvcompBatchedLZ4DecompressGetTempSize asks for the index space only for batches at or above the threshold:
+ * set the threshold BEFORE the size query. Returns the previous value. Process-wide; not synchronised with
+ * concurrent *Async calls. */
+#define NVCOMP_AMD_LZ_INDEX_MIN_BATCH_DEFAULT ((size_t)-1)
 size_t nvcompAmdSetLZIndexMinBatch(size_t min_batch);
 
 #ifdef __cplusplus

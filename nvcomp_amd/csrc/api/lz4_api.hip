@@ -23,6 +23,12 @@
 namespace {
 
 constexpr unsigned kWavesPerBlock = 4; /* 256-thread workgroups, one chunk per wave */
+/* The decoders' workgroup size is a tuning parameter of its own: a workgroup's LDS is released when its LAST wave ends, and
+ * chunks of a mixed batch take very different times. */
+#ifndef NVCOMP_LZ_DEC_WAVES_PER_BLOCK
+#define NVCOMP_LZ_DEC_WAVES_PER_BLOCK 4
+#endif
+constexpr unsigned kDecWaves = NVCOMP_LZ_DEC_WAVES_PER_BLOCK;
 constexpr uint32_t kMaxOutCap = 1u << 26;
 
 /* A/B and ablation kernels exist in measurement builds only (scripts/build_variants.sh passes
@@ -33,7 +39,7 @@ constexpr uint32_t kMaxOutCap = 1u << 26;
 #endif
 
 template <bool CHECKED, int ABLATE = 0>
-__global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZW_WAVES_PER_SIMD) lz4_decompress_window_kernel(
+__global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_WAVES_PER_SIMD) lz4_decompress_window_kernel(
     const void* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes,
     const size_t* out_caps,
@@ -43,9 +49,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZW_WAVES_PER_SIMD
     nvcompStatus_t* statuses,
     const uint32_t* __restrict__ index_counts /* non-null: only the chunks the indexer left out (lzi::kNotIndexed) */)
 {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][lzg::kLdsPerWave];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kDecWaves][lzg::kLdsPerWave];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
-  const size_t chunk = (size_t)blockIdx.x * kWavesPerBlock + w;
+  const size_t chunk = (size_t)blockIdx.x * kDecWaves + w;
   if (chunk >= batch_size) {
     return;
   }
@@ -92,7 +98,7 @@ __global__ void __launch_bounds__(64) lz4_index_kernel(
 
 /* The window decoder fed from the token index: no chase tables in LDS, one wave per chunk. */
 template <bool CHECKED>
-__global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZW_INDEXED_WAVES_PER_SIMD) lz4_decompress_indexed_kernel(
+__global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_INDEXED_WAVES_PER_SIMD) lz4_decompress_indexed_kernel(
     const void* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes,
     const size_t* out_caps,
@@ -102,9 +108,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZW_INDEXED_WAVES_
     nvcompStatus_t* statuses,
     lzi::Layout lay)
 {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][lzg::kLdsPerWaveIndexed];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kDecWaves][lzg::kLdsPerWaveIndexed];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
-  const size_t chunk = (size_t)blockIdx.x * kWavesPerBlock + w;
+  const size_t chunk = (size_t)blockIdx.x * kDecWaves + w;
   if (chunk >= batch_size) {
     return;
   }
@@ -133,7 +139,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZW_INDEXED_WAVES_
 }
 
 template <bool CHECKED, bool LANE_PARALLEL>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) lz4_decompress_kernel(
+__global__ void __launch_bounds__(64 * kDecWaves) lz4_decompress_kernel(
     const void* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes,
     const size_t* out_caps,
@@ -142,7 +148,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lz4_decompress_kernel(
     void* const* __restrict__ out_ptrs,
     nvcompStatus_t* statuses)
 {
-  const size_t chunk = (size_t)blockIdx.x * kWavesPerBlock + wave::uniform(threadIdx.x >> 6);
+  const size_t chunk = (size_t)blockIdx.x * kDecWaves + wave::uniform(threadIdx.x >> 6);
   if (chunk >= batch_size) {
     return;
   }
@@ -253,8 +259,11 @@ nvcompStatus_t nvcompBatchedLZ4DecompressGetTempSize(
   if (temp_bytes == nullptr) {
     return nvcompErrorInvalidValue;
   }
-  /* the token index: u32 count + one u16 per possible token of every chunk (common/lz_index.hip.h) */
-  *temp_bytes = num_chunks == 0 ? 0 : lzi::temp_bytes_for(num_chunks, lz4_bound(max_uncompressed_chunk_bytes));
+  /* only the opt-in two-kernel path (include/nvcomp/amd_ext.h) wants scratch: the token index, u32 count + one u16 per
+   * possible token of every chunk (common/lz_index.hip.h) */
+  *temp_bytes = num_chunks == 0 || num_chunks < nvcomp_amd_tuning::lz_index_min_batch
+                    ? 0
+                    : lzi::temp_bytes_for(num_chunks, lz4_bound(max_uncompressed_chunk_bytes));
   return nvcompSuccess;
 }
 
@@ -287,8 +296,8 @@ nvcompStatus_t nvcompBatchedLZ4DecompressAsync(
     return nvcompErrorInvalidValue;
   }
   clear_stale_error();
-  const dim3 grid(grid_for(batch_size));
-  const dim3 block(64 * kWavesPerBlock);
+  const dim3 grid((unsigned)((batch_size + kDecWaves - 1) / kDecWaves));
+  const dim3 block(64 * kDecWaves);
   const bool checked = device_statuses != nullptr;
 #define NVCOMP_LZ4_ARGS                                                                                        \
   device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes, \

@@ -18,26 +18,27 @@
 namespace {
 
 constexpr unsigned kWavesPerBlock = 4; /* 256-thread workgroups, one chunk per wave */
+/* The decoders' workgroup size is a tuning parameter of its own: a workgroup's LDS is released when its LAST wave ends, and
+ * chunks of a mixed batch take very different times. */
+#ifndef NVCOMP_LZ_DEC_WAVES_PER_BLOCK
+#define NVCOMP_LZ_DEC_WAVES_PER_BLOCK 4
+#endif
+constexpr unsigned kDecWaves = NVCOMP_LZ_DEC_WAVES_PER_BLOCK;
 constexpr uint32_t kMaxOutCap = 1u << 26;
 
-/* Kernel variant switch for A/B measurements: NVCOMP_AMD_SNAPPY_DECODE =
- *   window (default) LDS-staged sequence-parallel decoder (snappy_decode_window.hip.h)
- *   direct           sequence-parallel, decoding straight to HBM (snappy_decode.hip.h)
- *   serial           one sequence per step, whole-wave copies (ablation baseline) */
-int snappy_decode_variant()
+/* A/B kernels exist in measurement builds only (scripts/build_variants.sh passes -DNVCOMP_AMD_SNAPPY_VARIANT=1 direct:
+ * sequence-parallel straight to HBM (snappy_decode.hip.h) | 2 serial: one sequence per step, the ablation baseline);
+ * the shipped library has exactly one decoder and no run-time switch. */
+#ifndef NVCOMP_AMD_SNAPPY_VARIANT
+#define NVCOMP_AMD_SNAPPY_VARIANT 0
+#endif
+constexpr int snappy_decode_variant()
 {
-  static const int v = [] {
-    const char* e = getenv("NVCOMP_AMD_SNAPPY_DECODE");
-    if (e == nullptr) {
-      return 0;
-    }
-    return e[0] == 'd' ? 1 : e[0] == 's' ? 2 : 0;
-  }();
-  return v;
+  return NVCOMP_AMD_SNAPPY_VARIANT;
 }
 
 template <bool CHECKED>
-__global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZW_WAVES_PER_SIMD) snappy_decompress_window_kernel(
+__global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_WAVES_PER_SIMD) snappy_decompress_window_kernel(
     const void* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes,
     const size_t* out_caps,
@@ -46,9 +47,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZW_WAVES_PER_SIMD
     void* const* __restrict__ out_ptrs,
     nvcompStatus_t* statuses)
 {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][lzg::kLdsPerWave];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kDecWaves][lzg::kLdsPerWave];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
-  const size_t chunk = (size_t)blockIdx.x * kWavesPerBlock + w;
+  const size_t chunk = (size_t)blockIdx.x * kDecWaves + w;
   if (chunk >= batch_size) {
     return;
   }
@@ -77,7 +78,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZW_WAVES_PER_SIMD
 }
 
 template <bool CHECKED, bool LANE_PARALLEL>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) snappy_decompress_kernel(
+__global__ void __launch_bounds__(64 * kDecWaves) snappy_decompress_kernel(
     const void* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes,
     const size_t* out_caps,
@@ -86,7 +87,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) snappy_decompress_kernel(
     void* const* __restrict__ out_ptrs,
     nvcompStatus_t* statuses)
 {
-  const size_t chunk = (size_t)blockIdx.x * kWavesPerBlock + wave::uniform(threadIdx.x >> 6);
+  const size_t chunk = (size_t)blockIdx.x * kDecWaves + wave::uniform(threadIdx.x >> 6);
   if (chunk >= batch_size) {
     return;
   }
@@ -223,8 +224,8 @@ nvcompStatus_t nvcompBatchedSnappyDecompressAsync(
     return nvcompErrorInvalidValue;
   }
   clear_stale_error();
-  const dim3 grid(grid_for(batch_size));
-  const dim3 block(64 * kWavesPerBlock);
+  const dim3 grid((unsigned)((batch_size + kDecWaves - 1) / kDecWaves));
+  const dim3 block(64 * kDecWaves);
   const bool checked = device_statuses != nullptr;
   const int variant = snappy_decode_variant();
   const bool serial = variant == 2;

@@ -46,7 +46,7 @@ constexpr uint32_t kMapBytes = 64 * 4;
 constexpr uint32_t kDeltaBytes = ((kMaxRank + 3) & ~3u) * 4;
 constexpr uint32_t kScratch = kStageBytes + kMapBytes + kDeltaBytes;
 
-static_assert(lzw::kBatchMax == kCap, "the window is sized for batches of kCap bytes");
+static_assert(!NVCOMP_LZ_GATHER || lzw::kBatchMax == kCap, "the window is sized for batches of kCap bytes");
 
 struct Scratch
 {
@@ -165,12 +165,6 @@ __device__ __forceinline__ uint32_t execute_gather_batch(
       return 0;
     }
   }
-#ifdef LZG_TRACE
-  if (op >= LZG_TRACE_LO && op <= LZG_TRACE_HI) {
-    fprintf(stderr, "lane %2u op %u take %u total %u head %u lit %u@%u match %u off %u dst %u src %u near %d inhbm %d serial %d vlo %u fl %u wbase %u\n",
-            lane, op, take, total, head, lit_len, s.lit_src, match_len, s.match_off, match_dst, match_src, (int)near, (int)in_hbm, (int)serial, ow.valid_lo, ow.flushed, ow.wbase);
-  }
-#endif
   LZ_STAT("batches", 1);
   LZ_STAT("seqs", take);
   LZ_STAT("bytes", total);
@@ -354,12 +348,6 @@ __device__ __forceinline__ uint32_t execute_gather_batch(
   op += total;
   return take;
 }
-
-/* Compile-time choice of the executor (the A/B builds of scripts/build_variants.sh): 1 = gather (default), 0 = the
- * lane-per-sequence copies of round 1. Both produce the same bytes. */
-#ifndef NVCOMP_LZ_GATHER
-#define NVCOMP_LZ_GATHER 1
-#endif
 
 constexpr uint32_t kLdsPerWave = lzw::kLdsPerWave + (NVCOMP_LZ_GATHER ? kScratch : 0);
 constexpr uint32_t kLdsPerWaveIndexed = lzw::kLdsPerWaveIndexed + (NVCOMP_LZ_GATHER ? kScratch : 0);

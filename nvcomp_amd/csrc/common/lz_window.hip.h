@@ -26,6 +26,13 @@
 
 namespace lzw {
 
+/* Which batch executor the decoders use (A/B builds of scripts/build_variants.sh): 0 = execute_window_batch below, the
+ * lane-per-sequence copies (default: 455 GB/s on the headline); 1 = the byte-gather executor of common/lz_gather.hip.h
+ * (331 GB/s: more vector instructions per batch and 4-5 waves/SIMD). Both produce the same bytes. */
+#ifndef NVCOMP_LZ_GATHER
+#define NVCOMP_LZ_GATHER 0
+#endif
+
 /* Tunables (overridable with -D for the A/B builds of scripts/build_variants.sh). */
 /* Defaults from the MI355X sweeps of profiles/r01_window_variants.json, r01_pchase_variants.json and
  * r01_occupancy_variants.json: a small window at 6-7 waves/SIMD beats a large one -- the decoder is
@@ -45,7 +52,7 @@ namespace lzw {
 #define NVCOMP_LZW_INRING 2048
 #endif
 #ifndef NVCOMP_LZW_WAVES_PER_SIMD
-#define NVCOMP_LZW_WAVES_PER_SIMD 4
+#define NVCOMP_LZW_WAVES_PER_SIMD 7
 #endif
 
 constexpr uint32_t kOutWin = NVCOMP_LZW_OUTWIN;     /* bytes of output window per wave */
@@ -73,7 +80,7 @@ constexpr uint32_t kLdsPerWave = kOutLds + kInLds + kChaseLds;
 /* the decoder fed from the token index (common/lz_index.hip.h) builds no jump tables: 4 144 B per wave = 8 waves/SIMD */
 constexpr uint32_t kLdsPerWaveIndexed = kOutLds + kInLds;
 #ifndef NVCOMP_LZW_INDEXED_WAVES_PER_SIMD
-#define NVCOMP_LZW_INDEXED_WAVES_PER_SIMD 4
+#define NVCOMP_LZW_INDEXED_WAVES_PER_SIMD 8
 #endif
 
 constexpr uint32_t kLitShort = 32;   /* lane-parallel literal runs: up to 8 dwords */

@@ -8,6 +8,18 @@
  */
 #pragma once
 
+/* Snappy's own window tunables for the lane-per-sequence executor (MI355X sweep, profiles/r01_occupancy_variants.json):
+ * its elements are half as long as LZ4's sequences, so a batch of 64 fills a smaller window; 1472 bytes leave 5 104 B of
+ * LDS per wave = 8 waves/SIMD, which this decoder (unlike LZ4's, which loses more to the spills of a 64-VGPR budget) turns
+ * into +4.5 %. */
+#if !defined(NVCOMP_LZW_OUTWIN) && !(defined(NVCOMP_LZ_GATHER) && NVCOMP_LZ_GATHER)
+#define NVCOMP_LZW_OUTWIN 1472
+#define NVCOMP_LZW_BATCHMAX 736
+#define NVCOMP_LZW_KEEP 544
+#endif
+#if !defined(NVCOMP_LZW_WAVES_PER_SIMD) && !(defined(NVCOMP_LZ_GATHER) && NVCOMP_LZ_GATHER)
+#define NVCOMP_LZW_WAVES_PER_SIMD 8
+#endif
 #include "common/lz_gather.hip.h"
 
 namespace snappyw {

@@ -9,8 +9,6 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log
 timeout 1500 python -m pytest tests -m gpu -q --timeout 600 > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$OUT/rc.txt"
 timeout 400 python bench.py > "$OUT/bench_lz4.json" 2> "$OUT/bench_lz4.err"; echo "bench lz4 rc=$?" >> "$OUT/rc.txt"
 timeout 300 python bench.py --unchecked --no-cpu-baseline --no-extras > "$OUT/bench_lz4_unchecked.json" 2> "$OUT/bench_lz4_unchecked.err"
-NVCOMP_AMD_LZ4_DECODE=direct timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/bench_lz4_direct.json" 2> "$OUT/bench_lz4_direct.err"
-NVCOMP_AMD_LZ4_DECODE=serial timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/bench_lz4_serial.json" 2> "$OUT/bench_lz4_serial.err"
 timeout 400 python bench.py --algo snappy > "$OUT/bench_snappy.json" 2> "$OUT/bench_snappy.err"; echo "bench snappy rc=$?" >> "$OUT/rc.txt"
 timeout 600 python scripts/bench_sweep.py --out "$OUT/sweep.jsonl" --mib 512 --unique-mib 32 --steps 5 > "$OUT/sweep.log" 2>&1; echo "sweep rc=$?" >> "$OUT/rc.txt"
 for ds in int32 float_columns float32 lowcard noise; do

@@ -9,9 +9,10 @@ mkdir -p "$OUT"
 if [ "${2:-}" != "notest" ]; then
   timeout 900 python -m pytest tests/test_lz4_decode.py tests/test_golden_decode.py tests/test_snappy.py tests/test_fuzz_decode.py tests/test_fuzz_corrupt.py -m gpu -q --timeout 600 -x > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -3 "$OUT/pytest.log"
 fi
-B="python bench.py --no-cpu-baseline --no-extras --lz-index-min-batch 1000000000"
-for algo in lz4 snappy; do
-  for mib in 4096 1024 256; do
+REPO=$PWD
+B="python $REPO/bench.py --no-cpu-baseline --no-extras --lz-index-min-batch 1000000000"
+for algo in ${ALGOS:-lz4 snappy}; do
+  for mib in ${MIBS:-4096 1024 256}; do
     timeout 300 $B --algo $algo --steps 10 --warmup 2 --mib-per-gpu $mib > "$OUT/${algo}_${mib}.json" 2> "$OUT/${algo}_${mib}.err"
     python -c "
 import json; r=json.load(open('$OUT/${algo}_${mib}.json')); print('$algo mib $mib', r['value'], 'GB/s', r['roofline']['kernel_ms'], 'ms', r['roofline']['frac'])"

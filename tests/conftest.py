@@ -60,6 +60,21 @@ def emu_library():
     return _emu_lib
 
 
+_emu_gather_lib = None
+
+
+def emu_gather_library():
+    """The same emulation build with the LZ decoders' alternative (byte-gather) batch executor compiled in."""
+    global _emu_gather_lib
+    if _emu_gather_lib is None:
+        from nvcomp_amd import _lib
+
+        emu_dir = os.path.join(REPO, "tests", "emu")
+        subprocess.run(["make", "-C", emu_dir, "-j8", "gather"], check=True, stdout=subprocess.DEVNULL)
+        _emu_gather_lib = _lib.declare(C.CDLL(os.path.join(emu_dir, "libnvcomp_emu_gather.so")))
+    return _emu_gather_lib
+
+
 class Backend:
     def __init__(self, name, lib, dev):
         self.name, self.lib, self.dev = name, lib, dev
@@ -73,6 +88,11 @@ class Backend:
 @pytest.fixture(scope="session")
 def emu():
     return Backend("emu", emu_library(), HostDevice())
+
+
+@pytest.fixture(scope="session")
+def emu_gather():
+    return Backend("emu", emu_gather_library(), HostDevice())
 
 
 @pytest.fixture(scope="session")

@@ -89,3 +89,21 @@ def test_call_logging_env(tmp_path):
     subprocess.run([sys.executable, "-c", code], check=True, env=env)
     text = log.read_text()
     assert "nvcompBatchedLZ4CompressAsync(batch_size=1" in text and "nvcompBatchedLZ4DecompressAsync(batch_size=1" in text
+
+
+def test_no_runtime_kernel_switches():
+    """The shipped library decides nothing from the environment except logging (a drop-in must not have
+    a change-my-decoder variable); A/B kernels are -D builds of scripts/build_variants.sh."""
+    import glob
+
+    offenders = []
+    for path in glob.glob(os.path.join(REPO, "nvcomp_amd", "csrc", "**", "*.h*"), recursive=True):
+        if path.endswith(os.path.join("common", "log.h")):
+            continue
+        if "getenv" in open(path).read():
+            offenders.append(os.path.relpath(path, REPO))
+    assert not offenders, offenders
+    # and the old variable names do nothing: the binary does not even contain them
+    blob = open(os.path.join(REPO, "nvcomp_amd", "lib", "libnvcomp.so"), "rb").read() if os.path.exists(
+        os.path.join(REPO, "nvcomp_amd", "lib", "libnvcomp.so")) else b""
+    assert b"NVCOMP_AMD_LZ4_DECODE" not in blob and b"NVCOMP_AMD_SNAPPY_DECODE" not in blob
