@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZM_WAVES_PER_SIMD
     void* const* __restrict__ out_ptrs,
     size_t* out_bytes)
 {
-  __shared__ uint16_t tables[kWavesPerBlock][lzm::kHashSize];
+  __shared__ uint16_t tables[kWavesPerBlock][lzm::kTableU16];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
   const size_t chunk = (size_t)blockIdx.x * kWavesPerBlock + w;
   if (chunk >= batch_size) {
@@ -436,6 +436,23 @@ nvcompStatus_t nvcompBatchedLZ4CompressAsync(
 }
 
 } // extern "C"
+
+#ifdef NVCOMP_LZM_PROF
+/* Profiling builds only: read (and clear) the per-phase cycle sums of the LZ4 compressor. */
+extern "C" int nvcompAmdCompProfRead(unsigned long long* host_slots, int n)
+{
+  unsigned long long v[lzm::kProfSlots] = {};
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(lzm::g_prof), sizeof(v)) != hipSuccess) {
+    return -1;
+  }
+  for (int i = 0; i < n && i < (int)lzm::kProfSlots; ++i) {
+    host_slots[i] = v[i];
+  }
+  unsigned long long z[lzm::kProfSlots] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(lzm::g_prof), z, sizeof(z));
+  return (int)lzm::kProfSlots;
+}
+#endif
 
 #ifdef NVCOMP_LZW_PROF
 /* Profiling builds only: read (and clear) the per-phase cycle sums of the window decoder. */

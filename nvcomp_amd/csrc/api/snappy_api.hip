@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZM_WAVES_PER_SIMD
     void* const* __restrict__ out_ptrs,
     size_t* out_bytes)
 {
-  __shared__ uint16_t tables[kWavesPerBlock][lzm::kHashSize];
+  __shared__ uint16_t tables[kWavesPerBlock][lzm::kTableU16];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
   const size_t chunk = (size_t)blockIdx.x * kWavesPerBlock + w;
   if (chunk >= batch_size) {

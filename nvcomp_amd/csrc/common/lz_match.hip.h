@@ -35,6 +35,12 @@ namespace lzm {
 #ifndef NVCOMP_LZM_HASH_BITS
 #define NVCOMP_LZM_HASH_BITS 12
 #endif
+/* One-byte tags beside the positions (A/B build): a probe would look at the candidate's bytes in memory only when eight
+ * more hash bits agree. Measured (profiles/r02_lz_compress.json): no gain -- the compressor is bound by the LENGTH of its
+ * dependent chain per window, not by the candidate fetches -- and the extra 4 KiB of LDS per wave cost occupancy. Off. */
+#ifndef NVCOMP_LZM_TAGS
+#define NVCOMP_LZM_TAGS 0
+#endif
 #ifndef NVCOMP_LZM_WAVES_PER_SIMD
 #define NVCOMP_LZM_WAVES_PER_SIMD 5 /* what the 8 KiB hash table per wave allows (4-wave workgroups, 160 KB LDS per CU) */
 #endif
@@ -47,8 +53,52 @@ constexpr uint32_t kHashSize = NVCOMP_LZM_HASH_ENTRIES;
 constexpr uint32_t kHashSize = 1u << kHashBits;
 #endif
 static_assert(kHashSize % 128 == 0 && kHashSize <= 65536, "the table is cleared 64 dwords at a time");
+/* The table a wave owns, in uint16 units: kHashSize positions (mod 65536), followed by kHashSize one-byte tags in the
+ * NVCOMP_LZM_TAGS build. */
+constexpr uint32_t kTableU16 = kHashSize + (NVCOMP_LZM_TAGS ? kHashSize / 2 : 0);
 constexpr uint32_t kMinMatch = 4;
-constexpr uint32_t kLaneCap = 36; /* per-lane match measurement: 4 + 8 dword compares */
+constexpr uint32_t kLaneCap = 32; /* per-lane match measurement: the word + 28 bytes, compared in registers */
+constexpr uint32_t kDenseHits = 32; /* hit lanes in a window from which its first match is probed cooperatively */
+constexpr uint32_t kBackMax = 8;    /* bytes a lane's match may grow backwards over its literal run */
+
+/* ---- phase clock (profiling builds only: -DNVCOMP_LZM_PROF, scripts/build_variants.sh) ---- */
+#ifdef NVCOMP_LZM_PROF
+constexpr uint32_t kProfSlots = 12;
+__device__ unsigned long long g_prof[kProfSlots];
+struct ProfClock
+{
+  unsigned long long acc[kProfSlots];
+  unsigned long long last;
+  __device__ __forceinline__ void begin()
+  {
+    for (uint32_t i = 0; i < kProfSlots; ++i) {
+      acc[i] = 0;
+    }
+    last = __builtin_readcyclecounter();
+  }
+  __device__ __forceinline__ void mark(uint32_t slot)
+  {
+    const unsigned long long t = __builtin_readcyclecounter();
+    acc[slot] += t - last;
+    last = t;
+  }
+  __device__ __forceinline__ void end()
+  {
+    if (wave::lane_id() == 0) {
+      for (uint32_t i = 0; i < kProfSlots; ++i) {
+        atomicAdd(&g_prof[i], acc[i]);
+      }
+    }
+  }
+};
+#define LZM_PROF_DECL lzm::ProfClock prof_clock; prof_clock.begin()
+#define LZM_T(slot) prof_clock.mark(slot)
+#define LZM_PROF_END prof_clock.end()
+#else
+#define LZM_PROF_DECL ((void)0)
+#define LZM_T(slot) ((void)0)
+#define LZM_PROF_END ((void)0)
+#endif
 
 __device__ __forceinline__ uint32_t hash4(uint32_t v)
 {
@@ -57,6 +107,17 @@ __device__ __forceinline__ uint32_t hash4(uint32_t v)
     return h >> (32 - kHashBits);
   } else {
     return __umulhi(h, kHashSize); /* multiply-shift range reduction onto [0, kHashSize) */
+  }
+}
+
+/* Eight hash bits that do not take part in the index. */
+__device__ __forceinline__ uint32_t tag4(uint32_t v)
+{
+  const uint32_t h = v * 2654435761u;
+  if constexpr ((kHashSize & (kHashSize - 1)) == 0) {
+    return (h >> (24 - kHashBits)) & 0xffu;
+  } else {
+    return (h >> 6) & 0xffu;
   }
 }
 
@@ -77,117 +138,290 @@ __device__ __forceinline__ uint32_t extend_match(
   }
 }
 
+/* The stream around a position, in registers: bytes [pos - 8, pos) and [pos, pos + 32). */
+struct Around
+{
+  uint32_t pre[2];
+  uint32_t fwd[8];
+};
+
+/* Both loads are unaligned 16-byte lane loads of consecutive addresses one byte apart: a wave touches two or three
+ * cache lines. `with_pre` = pos >= 8. The caller guarantees pos + 32 <= the end of the chunk. */
+__device__ __forceinline__ void load_around(Around& r, const uint8_t* __restrict__ src, uint32_t pos, bool with_pre)
+{
+  const wave::u32x4 a = wave::gload_u32x4(src + pos);
+  const wave::u32x4 b = wave::gload_u32x4(src + pos + 16);
+  r.fwd[0] = a.x, r.fwd[1] = a.y, r.fwd[2] = a.z, r.fwd[3] = a.w;
+  r.fwd[4] = b.x, r.fwd[5] = b.y, r.fwd[6] = b.z, r.fwd[7] = b.w;
+  r.pre[0] = 0, r.pre[1] = 0;
+  if (with_pre) {
+    r.pre[0] = wave::gload_u32(src + pos - 8);
+    r.pre[1] = wave::gload_u32(src + pos - 4);
+  }
+}
+
+/* What one lane knows about its position after the probe. */
+struct Probe
+{
+  uint32_t word; /* the 4 bytes at the position */
+  uint32_t cand; /* candidate position (valid when found) */
+  uint32_t mlen; /* match length, capped at kLaneCap (0 when not found) */
+  uint32_t back; /* equal bytes right before position and candidate, at most kBackMax */
+  bool found;
+};
+
+/* Candidate from the hash table entry `low` (position mod 65536): the nearest position below pos with these low
+ * bits; `ok` = it exists and is within the formats' 65535-byte reach. */
+__device__ __forceinline__ uint32_t table_candidate(uint32_t pos, uint32_t low, bool& ok)
+{
+  uint32_t cand = (pos & ~0xffffu) | low;
+  if (cand >= pos) {
+    cand -= 0x10000u;
+  }
+  ok = cand < pos && pos - cand <= 65535u; /* cand wraps to a huge value when there is none */
+  return cand;
+}
+
+/* A repeat of the word at distance 1, 2, 4 or 8 inside the window (runs, typed columns): found by comparing with
+ * the neighbouring lanes' words, no memory access. Returns the distance or 0. */
+__device__ __forceinline__ uint32_t neighbour_repeat(uint32_t word, bool eligible)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  uint32_t dist = 0;
+  for (uint32_t d = 1; d <= 8; d *= 2) {
+    const uint32_t other = wave::shuffle(word, (lane - d) & 63u);
+    if (eligible && dist == 0 && lane >= d && other == word) {
+      dist = d;
+    }
+  }
+  return dist;
+}
+
+/*
+ * Probe of a window whose 64 positions can all read 32 bytes ahead (every window but the last one or two of a
+ * chunk). The compressor is bound by dependent memory round trips, so a step has exactly two:
+ * the position side (`me`, loaded one step AHEAD by the caller) and ONE round of candidate-side loads -- word,
+ * the 28 bytes behind it and the 8 bytes before it together -- after which the match length up to kLaneCap and
+ * the backward growth are plain register compares. A neighbour repeat is preferred to the table's candidate: it
+ * is known to match without looking.
+ */
+__device__ __forceinline__ Probe probe_fast(
+    const uint8_t* __restrict__ src, const uint16_t* table, const Around& me, uint32_t pos, bool eligible, uint32_t match_end)
+{
+  Probe p;
+  p.word = me.fwd[0];
+  p.mlen = 0;
+  p.back = 0;
+  bool ok;
+  {
+    const uint32_t slot = hash4(p.word);
+    p.cand = table_candidate(pos, table[slot], ok);
+#if NVCOMP_LZM_TAGS
+    ok = ok && ((const uint8_t*)(table + kHashSize))[slot] == tag4(p.word);
+#endif
+  }
+  const uint32_t near = neighbour_repeat(p.word, eligible);
+  if (near) {
+    p.cand = pos - near;
+    ok = true;
+  }
+  ok = ok && eligible;
+  Around c;
+#pragma unroll
+  for (uint32_t i = 0; i < 8; ++i) {
+    c.fwd[i] = ~me.fwd[i]; /* lanes without a candidate compare unequal */
+  }
+  c.pre[0] = 0, c.pre[1] = 0;
+  if (ok) {
+    load_around(c, src, p.cand, p.cand >= kBackMax);
+  }
+  uint32_t x[8];
+#pragma unroll
+  for (uint32_t i = 0; i < 8; ++i) {
+    x[i] = me.fwd[i] ^ c.fwd[i];
+  }
+  p.found = ok && x[0] == 0;
+  /* first differing byte among bytes 4..31 */
+  uint32_t idx = 8, xv = 0;
+#pragma unroll
+  for (uint32_t i = 7; i >= 1; --i) {
+    idx = x[i] ? i : idx;
+    xv = x[i] ? x[i] : xv;
+  }
+  uint32_t mlen = 4 * idx + (xv ? (uint32_t)__builtin_ctz(xv) >> 3 : 0u);
+  const uint32_t room = match_end - pos; /* >= 4 for an eligible position */
+  mlen = mlen < room ? mlen : room;
+  p.mlen = p.found ? mlen : 0;
+  if (p.found && p.cand >= kBackMax) { /* pos > cand >= 8: both sides hold their 8 bytes */
+    const uint64_t xb = ((uint64_t)(me.pre[1] ^ c.pre[1]) << 32) | (me.pre[0] ^ c.pre[0]);
+    p.back = xb ? (uint32_t)__builtin_clzll(xb) >> 3 : kBackMax;
+  }
+  return p;
+}
+
+/* The same probe with nothing assumed about how far a position may read: the last windows of a chunk. */
+__device__ __forceinline__ Probe probe_safe(
+    const uint8_t* __restrict__ src, const uint16_t* table, uint32_t pos, bool eligible, uint32_t match_end)
+{
+  Probe p;
+  p.word = 0;
+  p.cand = 0;
+  p.mlen = 0;
+  p.back = 0;
+  p.found = false;
+  bool ok = false;
+  if (eligible) {
+    p.word = lz::ld_u32(src + pos);
+    const uint32_t slot = hash4(p.word);
+    p.cand = table_candidate(pos, table[slot], ok);
+#if NVCOMP_LZM_TAGS
+    ok = ok && ((const uint8_t*)(table + kHashSize))[slot] == tag4(p.word);
+#endif
+  }
+  const uint32_t near = neighbour_repeat(p.word, eligible);
+  if (near) {
+    p.cand = pos - near;
+    p.found = true;
+  } else if (ok) {
+    p.found = lz::ld_u32(src + p.cand) == p.word;
+  }
+  if (p.found) {
+    const uint32_t room = match_end - pos;
+    const uint32_t cap = room < kLaneCap ? room : kLaneCap;
+    uint32_t mlen = kMinMatch;
+    bool open = true;
+    while (open && mlen + 4 <= cap) {
+      const uint32_t x = lz::ld_u32(src + pos + mlen) ^ lz::ld_u32(src + p.cand + mlen);
+      if (x != 0) {
+        mlen += (uint32_t)__builtin_ctz(x) >> 3;
+        open = false;
+      } else {
+        mlen += 4;
+      }
+    }
+    while (open && mlen < cap && src[pos + mlen] == src[p.cand + mlen]) { /* at most 3 tail bytes */
+      ++mlen;
+    }
+    p.mlen = mlen;
+    while (p.back < kBackMax && p.back < p.cand && src[pos - 1 - p.back] == src[p.cand - 1 - p.back]) {
+      ++p.back;
+    }
+  }
+  return p;
+}
+
 template <class Emitter>
 __device__ __forceinline__ uint32_t encode_chunk(
     const uint8_t* __restrict__ src, uint32_t n, uint8_t* dst, uint16_t* table, uint32_t last_start,
     uint32_t match_end, bool any_match)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
-  for (uint32_t i = lane; i < kHashSize / 2; i += 64) {
+  for (uint32_t i = lane; i < kTableU16 / 2; i += 64) {
     ((uint32_t*)table)[i] = 0;
   }
   wave::sync();
 
   uint32_t op = 0;
   uint32_t anchor = 0;
+  LZM_PROF_DECL;
   if (any_match) {
     uint32_t ip = 0;
+    uint32_t skip = 0;        /* leading positions of the window that the previous step's last match already covers */
+    Around ahead;             /* position side of window `ahead_ip`, requested one step early */
+    uint32_t ahead_ip = ~0u;
+#pragma unroll
+    for (uint32_t i = 0; i < 8; ++i) {
+      ahead.fwd[i] = 0;
+    }
+    ahead.pre[0] = 0, ahead.pre[1] = 0;
     while (ip <= last_start) {
       const uint32_t pos = ip + lane;
       const bool eligible = pos <= last_start;
-      uint32_t word = 0, cand = 0;
-      bool found = false;
+      const bool fast = ip + 63 + 32 <= n; /* wave-uniform: every lane may read its 32 bytes */
+      LZM_T(0); /* loop top */
+      Probe pr;
+      Around me; /* fast windows: the bytes around this lane's position stay in registers until its literals are written */
+      me.pre[0] = 0, me.pre[1] = 0;
+      if (fast) {
+        if (ahead_ip == ip) {
+          me = ahead;
+        } else {
+          load_around(me, src, pos, pos >= kBackMax);
+        }
+        if (ip + 64 + 63 + 32 <= n) { /* the next window's position side travels while this one is worked on */
+          ahead_ip = ip + 64;
+          load_around(ahead, src, pos + 64, true);
+        }
+        pr = probe_fast(src, table, me, pos, eligible, match_end);
+      } else {
+        pr = probe_safe(src, table, pos, eligible, match_end);
+      }
+      const uint32_t word = pr.word;
+      const uint32_t cand = pr.cand;
+      uint32_t mlen = pr.mlen;
+      LZM_T(1); /* probe: position side, table, candidate loads, compares */
+      /* this window's positions go into the table now: the next probe (whose loads may already be under way)
+       * sees them, and nothing below reads the table */
+      wave::sync();
       if (eligible) {
-        word = lz::ld_u32(src + pos);
-        const uint32_t low = table[hash4(word)];
-        cand = (pos & ~0xffffu) | low; /* nearest position below pos whose low 16 bits are `low` */
-        if (cand >= pos) {
-          cand -= 0x10000u;
-        }
+        const uint32_t slot = hash4(word);
+        table[slot] = (uint16_t)pos;
+#if NVCOMP_LZM_TAGS
+        ((uint8_t*)(table + kHashSize))[slot] = (uint8_t)tag4(word);
+#endif
       }
-      if (eligible && cand < pos && pos - cand <= 65535u) { /* cand wraps to a huge value when there is none */
-        found = lz::ld_u32(src + cand) == word;
-      }
-      for (uint32_t d = 1; d <= 8; d *= 2) {
-        const uint32_t other = wave::shuffle(word, (lane - d) & 63u);
-        if (eligible && !found && lane >= d && other == word) {
-          found = true;
-          cand = pos - d;
-        }
-      }
-      const uint64_t hits = wave::ballot(found);
+      wave::sync();
+      const uint64_t hits = wave::ballot(pr.found && lane >= skip);
+      LZM_T(2); /* table insert */
       if (hits == 0) {
-        /* no match in this window: its 64 positions become literals; remember them */
-        if (eligible) {
-          table[hash4(word)] = (uint16_t)pos;
-        }
-        wave::sync();
+        /* no match starts in this window: its positions become literals */
+        skip = skip > 64 ? skip - 64 : 0;
         ip += 64;
         continue;
       }
 
-      /* ---- long first match (runs, periodic columns): one cooperative probe decides ---- */
-      {
+      /* ---- long first match (runs, periodic columns): one cooperative probe decides. Only windows where most
+       * positions hit are worth the extra memory round trip (on text a window has 10-20 hits and the per-lane
+       * measurement finds the rare long match anyway) ---- */
+      if (wave::popc64(hits) >= kDenseHits) {
         const uint32_t f0 = wave::ctz64(hits);
-        const uint32_t mpos = ip + f0;
-        const uint32_t mcand = wave::read_lane(cand, f0);
+        uint32_t mpos = ip + f0;
+        uint32_t mcand = wave::read_lane(cand, f0);
         const uint32_t p = mpos + kMinMatch + lane;
         const bool same = p < match_end && src[p] == src[mcand + kMinMatch + lane];
         const uint64_t diff = ~wave::ballot(same);
-        const uint32_t len0 = diff ? kMinMatch + wave::ctz64(diff) : extend_match(src, mpos, mcand, kMinMatch + 64, match_end);
+        uint32_t len0 = diff ? kMinMatch + wave::ctz64(diff) : extend_match(src, mpos, mcand, kMinMatch + 64, match_end);
         if (len0 >= kLaneCap) {
+          /* grow it backwards over the pending literals (what the CPU compressors call catching up): lane l
+           * compares the l-th byte before the match with the l-th byte before its source */
+          {
+            const uint32_t room = mpos - anchor < mcand ? mpos - anchor : mcand;
+            const bool eq = lane < room && src[mpos - 1 - lane] == src[mcand - 1 - lane];
+            const uint64_t ne = ~wave::ballot(eq);
+            const uint32_t back = ne ? wave::ctz64(ne) : 64u;
+            mpos -= back;
+            mcand -= back;
+            len0 += back;
+          }
           op += Emitter::match(dst + op, src + anchor, mpos - anchor, mpos - mcand, len0);
           const uint32_t next = mpos + len0;
-          if (eligible && pos < next) {
-            table[hash4(word)] = (uint16_t)pos;
-          }
-          wave::sync();
           anchor = next;
-          ip = next;
+          /* whole windows inside the match are skipped (their positions stay out of the table, as in the CPU
+           * compressors); the window the match ends in is probed from its beginning, the positions the match covers
+           * cannot start another */
+          const uint32_t jump = (next - ip) & ~63u; /* 0: it ends inside this window, which is looked at again */
+          ip += jump;
+          skip = next - ip;
           continue;
         }
       }
 
-      /* ---- every hit lane measures its own match (16-byte compares, capped): the candidate side of these
-       * loads is scattered, one L1 tag lookup per lane and load, so fewer and wider loads is what counts ---- */
-      uint32_t mlen = 0;
-      if (found) {
-        const uint32_t room = match_end - pos; /* >= 4 for an eligible position */
-        uint32_t cap = room < kLaneCap ? room : kLaneCap;
-        mlen = kMinMatch;
-        while (mlen + 16 <= cap) {
-          const wave::u32x4 a = lz::ld_u32x4(src + pos + mlen);
-          const wave::u32x4 b = lz::ld_u32x4(src + cand + mlen);
-          const uint32_t x0 = a.x ^ b.x, x1 = a.y ^ b.y, x2 = a.z ^ b.z, x3 = a.w ^ b.w;
-          if ((x0 | x1 | x2 | x3) != 0) {
-            const uint32_t first = x0 ? 0u : x1 ? 1u : x2 ? 2u : 3u;
-            const uint32_t x = x0 ? x0 : x1 ? x1 : x2 ? x2 : x3;
-            mlen += 4 * first + ((uint32_t)__builtin_ctz(x) >> 3);
-            cap = 0; /* stop */
-            break;
-          }
-          mlen += 16;
-        }
-        while (mlen + 4 <= cap) {
-          const uint32_t x = lz::ld_u32(src + pos + mlen) ^ lz::ld_u32(src + cand + mlen);
-          if (x != 0) {
-            mlen += (uint32_t)__builtin_ctz(x) >> 3;
-            cap = 0;
-            break;
-          }
-          mlen += 4;
-        }
-        while (mlen < cap && src[pos + mlen] == src[cand + mlen]) { /* at most 3 tail bytes */
-          ++mlen;
-        }
-      }
-
+      LZM_T(3); /* dense-window check */
       /* ---- greedy selection in position order (scalar walk over the hit mask) ---- */
       uint32_t prev_end = 0;  /* per selected lane: where its literal run starts */
       uint64_t selected = 0;
       uint32_t cur = 0;       /* window-relative position the next match may start at */
       uint32_t lit_from = anchor;
-      uint32_t last = 64;     /* lane of the selected match that hit the cap, if any */
       uint64_t rest = hits;
       while (rest) {
         const uint32_t f = wave::ctz64(rest);
@@ -203,39 +437,71 @@ __device__ __forceinline__ uint32_t encode_chunk(
         lit_from = ip + cur;
         rest = cur < 64 ? (hits & (~0ull << cur)) : 0ull;
       }
-      (void)last;
-      const uint32_t next_ip = cur > 64 ? ip + cur : ip + 64;
 
+      LZM_T(4); /* selection */
       /* ---- emit the selected sequences ---- */
       const bool sel = (selected >> lane) & 1;
-      const uint32_t lit_len = sel ? pos - prev_end : 0;
-      const uint32_t my_len = sel ? mlen : 0;
+      uint32_t lit_len = sel ? pos - prev_end : 0;
+      uint32_t my_len = sel ? mlen : 0;
+      /* every selected match grows backwards over its own literal run (never into the previous match) */
+      {
+        const uint32_t back = pr.back < lit_len ? pr.back : lit_len;
+        lit_len -= sel ? back : 0u;
+        my_len += sel ? back : 0u;
+      }
       const uint32_t offset = pos - cand;
       const uint32_t size = sel ? Emitter::seq_size(lit_len, my_len, offset) : 0;
       const uint32_t incl = wave::scan_add_inclusive(size);
       const uint32_t total = wave::read_lane(incl, 63);
       uint8_t* my_dst = dst + op + incl - size;
       const bool small = sel && Emitter::is_small(lit_len, my_len);
+      LZM_T(5); /* sizes + scan */
       if (small) {
         Emitter::emit_small_header(my_dst, lit_len, offset, my_len);
       }
-      /* literal runs of the small sequences: 4-byte steps, offsets clamped to len-4 */
+      LZM_T(6); /* headers */
+      /* literal runs of the small sequences. Up to 8 bytes (nearly all of them on text) are the bytes right before
+       * the lane's position, which a fast window holds in registers: no load at all. Longer runs are read back,
+       * four dwords in flight per round (a load-store pair per step costs a memory round trip per step). */
       {
-        const uint8_t* ls = src + prev_end;
+        const uint32_t run = sel ? pos - prev_end : 0; /* before the match grew backwards: the run ends at pos */
         uint8_t* ld = my_dst + Emitter::lit_offset(lit_len);
-        const bool lit4 = small && lit_len >= 4;
-        uint32_t steps = 0;
-        if (wave::ballot(lit4)) {
-          steps = wave::reduce_max(lit4 ? (lit_len + 3) / 4 : 0u);
-        }
-        if (lit4) {
-          const uint32_t lastoff = lit_len - 4;
-          for (uint32_t i = 0; i < steps; ++i) {
-            const uint32_t o = 4 * i < lastoff ? 4 * i : lastoff;
-            lz::st_u32(ld + o, lz::ld_u32(ls + o));
+        const bool from_regs = small && fast && run <= 8 && pos >= kBackMax;
+        if (from_regs && lit_len != 0) {
+          const uint64_t before = (((uint64_t)me.pre[1] << 32) | me.pre[0]) >> (8 * (8 - run));
+          if (lit_len >= 4) {
+            lz::st_u32(ld, (uint32_t)before);
+            lz::st_u32(ld + lit_len - 4, (uint32_t)(before >> (8 * (lit_len - 4))));
+          } else {
+            ld[0] = (uint8_t)before;
+            if (lit_len > 1) {
+              ld[1] = (uint8_t)(before >> 8);
+            }
+            if (lit_len > 2) {
+              ld[2] = (uint8_t)(before >> 16);
+            }
           }
         }
-        if (small && lit_len != 0 && lit_len < 4) {
+        const bool from_mem = small && !from_regs && lit_len != 0;
+        const uint8_t* ls = src + prev_end;
+        const bool lit4 = from_mem && lit_len >= 4;
+        for (uint32_t base = 0; wave::ballot(lit4 && lit_len > base) != 0; base += 16) {
+          if (lit4 && lit_len > base) {
+            const uint32_t lastoff = lit_len - 4;
+            uint32_t v[4];
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+              const uint32_t o = base + 4 * i < lastoff ? base + 4 * i : lastoff;
+              v[i] = wave::gload_u32(ls + o);
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+              const uint32_t o = base + 4 * i < lastoff ? base + 4 * i : lastoff;
+              lz::st_u32(ld + o, v[i]);
+            }
+          }
+        }
+        if (from_mem && lit_len < 4) {
           ld[0] = ls[0];
           if (lit_len > 1) {
             ld[1] = ls[1];
@@ -245,6 +511,7 @@ __device__ __forceinline__ uint32_t encode_chunk(
           }
         }
       }
+      LZM_T(7); /* literals */
       /* the few sequences a single lane cannot write: long literal run (first of the step,
        * after match-less windows) or long match (last of the step) */
       uint64_t big = wave::ballot(sel && !small);
@@ -253,22 +520,26 @@ __device__ __forceinline__ uint32_t encode_chunk(
         big &= big - 1;
         const uint32_t jdst = op + wave::read_lane(incl - size, j);
         const uint32_t jlit = wave::read_lane(prev_end, j);
-        const uint32_t jpos = ip + j;
-        Emitter::match(dst + jdst, src + jlit, jpos - jlit, wave::read_lane(offset, j), wave::read_lane(my_len, j));
+        Emitter::match(dst + jdst, src + jlit, wave::read_lane(lit_len, j), wave::read_lane(offset, j), wave::read_lane(my_len, j));
       }
       op += total;
-
-      /* insert only the positions this step consumes; the rest of the window is probed again
-       * by the next step and must still see its older candidates */
-      if (eligible && pos < next_ip) {
-        table[hash4(word)] = (uint16_t)pos;
-      }
-      wave::sync();
+      LZM_T(8); /* cooperative sequences */
       anchor = lit_from;
-      ip = next_ip;
+      /* the next window starts 64 positions on whatever the last match covers of it (so that the data requested
+       * ahead is the data needed); whole windows inside a long match are skipped */
+      if (cur >= 128) {
+        const uint32_t jump = cur & ~63u;
+        ip += jump;
+        skip = cur - jump;
+      } else {
+        ip += 64;
+        skip = cur > 64 ? cur - 64 : 0;
+      }
     }
   }
   op += Emitter::tail(dst + op, src + anchor, n - anchor);
+  LZM_T(9);
+  LZM_PROF_END;
   return op;
 }
 

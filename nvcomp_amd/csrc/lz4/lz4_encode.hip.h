@@ -109,7 +109,7 @@ struct Emitter
 };
 
 /* Compress src[0,n) into dst (capacity >= n + n/255 + 16) with the calling
- * wave; `table` is this wave's lzm::kHashSize x uint16 LDS hash table. Returns
+ * wave; `table` is this wave's LDS hash table, lzm::kTableU16 x uint16. Returns
  * the compressed size. */
 __device__ __forceinline__ uint32_t encode_chunk(
     const uint8_t* __restrict__ src, uint32_t n, uint8_t* dst, uint16_t* table)

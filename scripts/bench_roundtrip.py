@@ -64,6 +64,16 @@ def main():
         return e0.elapsed_time(e1) / a.iters * 1e-3
 
     t_c = timed(lambda: codec.compress_async(src, dst, a.chunk, ctemp, ctb))
+    if hasattr(lib, "nvcompAmdCompProfRead"):  # phase clocks of a -DNVCOMP_LZM_PROF build (scripts/build_variants.sh)
+        import ctypes
+
+        slots = (ctypes.c_ulonglong * 12)()
+        if lib.nvcompAmdCompProfRead(slots, 12) > 0:
+            tot = float(sum(slots)) or 1.0
+            names = ["loop_top", "probe", "insert", "dense_check", "selection", "sizes_scan", "headers", "literals",
+                     "cooperative", "tail", "-", "-"]
+            print(json.dumps({"phase_share": {k: round(v / tot, 4) for k, v in zip(names, slots)}, "cycles_total": tot}),
+                  file=sys.stderr, flush=True)
     csz = dev.download(dst.sizes).view(np.uint64)[:n]
     comp = DeviceBatch(dst.slab, dst.ptrs, dst.sizes, None, csz, n)
     out = empty_batch(dev, [a.chunk] * n, stride=a.chunk)
