@@ -49,13 +49,23 @@ class HostDevice:
 _emu_lib = None
 
 
+def _make_emu(*targets):
+    """Build the emulation library; serialised across pytest-xdist workers (they all start by asking for it)."""
+    import fcntl
+
+    emu_dir = os.path.join(REPO, "tests", "emu")
+    with open(os.path.join(emu_dir, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.run(["make", "-C", emu_dir, "-j8", *targets], check=True, stdout=subprocess.DEVNULL)
+    return emu_dir
+
+
 def emu_library():
     global _emu_lib
     if _emu_lib is None:
         from nvcomp_amd import _lib
 
-        emu_dir = os.path.join(REPO, "tests", "emu")
-        subprocess.run(["make", "-C", emu_dir, "-j8"], check=True, stdout=subprocess.DEVNULL)
+        emu_dir = _make_emu()
         _emu_lib = _lib.declare(C.CDLL(os.path.join(emu_dir, "libnvcomp_emu.so")))
     return _emu_lib
 
@@ -69,8 +79,7 @@ def emu_gather_library():
     if _emu_gather_lib is None:
         from nvcomp_amd import _lib
 
-        emu_dir = os.path.join(REPO, "tests", "emu")
-        subprocess.run(["make", "-C", emu_dir, "-j8", "gather"], check=True, stdout=subprocess.DEVNULL)
+        emu_dir = _make_emu("gather")
         _emu_gather_lib = _lib.declare(C.CDLL(os.path.join(emu_dir, "libnvcomp_emu_gather.so")))
     return _emu_gather_lib
 
