@@ -181,10 +181,11 @@ class BatchedCodec:
                                                   d.stream())
 
     # -- convenience round trips on host chunk lists (tests) --
-    def compress(self, chunks: Sequence[np.ndarray], in_align: int = 8) -> List[np.ndarray]:
+    def compress(self, chunks: Sequence[np.ndarray], in_align: int = 8, max_chunk: Optional[int] = None) -> List[np.ndarray]:
         d = self.dev
         n = len(chunks)
-        max_chunk = max([c.size for c in chunks] + [1])
+        if max_chunk is None:  # tests may declare less than the largest chunk: such a chunk must come back with size 0
+            max_chunk = max([c.size for c in chunks] + [1])
         src = make_batch(d, chunks, align=in_align)
         max_out = self.max_compressed_size(max_chunk)
         dst = empty_batch(d, [max_out] * n, stride=max_out)

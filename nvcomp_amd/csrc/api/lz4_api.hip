@@ -198,9 +198,13 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lz4_decompress_size_kerne
   }
 }
 
+/* STRIDE: the element size the caller declared (nvcompBatchedLZ4Opts_t.data_type): matches are searched at element
+ * boundaries only, a step covers 64 elements (common/lz_match.hip.h). */
+template <uint32_t STRIDE>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZM_WAVES_PER_SIMD) lz4_compress_kernel(
     const void* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
+    size_t max_chunk_bytes,
     size_t batch_size,
     void* const* __restrict__ out_ptrs,
     size_t* out_bytes)
@@ -213,8 +217,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZM_WAVES_PER_SIMD
   }
   const uint8_t* src = wave::uniform_ptr((const uint8_t*)in_ptrs[chunk]);
   uint8_t* dst = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
-  const uint32_t n = (uint32_t)wave::uniform64(in_bytes[chunk]);
-  const uint32_t produced = lz4::encode_chunk(src, n, dst, tables[w]);
+  const size_t n64 = wave::uniform64(in_bytes[chunk]);
+  /* a chunk larger than the caller declared would overrun the output slot sized from GetMaxOutputChunkSize: it is
+   * not compressed, its size reads 0 */
+  const uint32_t produced = n64 > max_chunk_bytes ? 0u : lz4::encode_chunk<STRIDE>(src, (uint32_t)n64, dst, tables[w]);
   if (wave::lane_id() == 0) {
     out_bytes[chunk] = produced;
   }
@@ -429,9 +435,18 @@ nvcompStatus_t nvcompBatchedLZ4CompressAsync(
     return nvcompErrorInvalidValue;
   }
   clear_stale_error();
-  hipLaunchKernelGGL(lz4_compress_kernel, dim3(grid_for(batch_size)), dim3(64 * kWavesPerBlock), 0, stream,
-                     device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
-                     device_compressed_bytes);
+#define NVCOMP_LZ4_COMPRESS(STRIDE)                                                                                  \
+  hipLaunchKernelGGL((lz4_compress_kernel<STRIDE>), dim3(grid_for(batch_size)), dim3(64 * kWavesPerBlock), 0, stream,   \
+                     device_uncompressed_ptrs, device_uncompressed_bytes, max_uncompressed_chunk_bytes, batch_size,     \
+                     device_compressed_ptrs, device_compressed_bytes)
+  switch (format_opts.data_type) {
+  case NVCOMP_TYPE_SHORT:
+  case NVCOMP_TYPE_USHORT: NVCOMP_LZ4_COMPRESS(2); break;
+  case NVCOMP_TYPE_INT:
+  case NVCOMP_TYPE_UINT: NVCOMP_LZ4_COMPRESS(4); break;
+  default: NVCOMP_LZ4_COMPRESS(1); break;
+  }
+#undef NVCOMP_LZ4_COMPRESS
   return launch_status();
 }
 

@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) snappy_decompress_size_ke
 __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZM_WAVES_PER_SIMD) snappy_compress_kernel(
     const void* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
+    size_t max_chunk_bytes,
     size_t batch_size,
     void* const* __restrict__ out_ptrs,
     size_t* out_bytes)
@@ -152,8 +153,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZM_WAVES_PER_SIMD
   }
   const uint8_t* src = wave::uniform_ptr((const uint8_t*)in_ptrs[chunk]);
   uint8_t* dst = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
-  const uint32_t n = (uint32_t)wave::uniform64(in_bytes[chunk]);
-  const uint32_t produced = snappy::encode_chunk(src, n, dst, tables[w]);
+  const size_t n64 = wave::uniform64(in_bytes[chunk]);
+  /* a chunk larger than the caller declared would overrun the output slot sized from GetMaxOutputChunkSize: it is
+   * not compressed, its size reads 0 */
+  const uint32_t produced = n64 > max_chunk_bytes ? 0u : snappy::encode_chunk(src, (uint32_t)n64, dst, tables[w]);
   if (wave::lane_id() == 0) {
     out_bytes[chunk] = produced;
   }
@@ -347,8 +350,8 @@ nvcompStatus_t nvcompBatchedSnappyCompressAsync(
   }
   clear_stale_error();
   hipLaunchKernelGGL(snappy_compress_kernel, dim3(grid_for(batch_size)), dim3(64 * kWavesPerBlock), 0, stream,
-                     device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
-                     device_compressed_bytes);
+                     device_uncompressed_ptrs, device_uncompressed_bytes, max_uncompressed_chunk_bytes, batch_size,
+                     device_compressed_ptrs, device_compressed_bytes);
   return launch_status();
 }
 

@@ -184,14 +184,14 @@ __device__ __forceinline__ uint32_t table_candidate(uint32_t pos, uint32_t low, 
 
 /* A repeat of the word at distance 1, 2, 4 or 8 inside the window (runs, typed columns): found by comparing with
  * the neighbouring lanes' words, no memory access. Returns the distance or 0. */
-__device__ __forceinline__ uint32_t neighbour_repeat(uint32_t word, bool eligible)
+__device__ __forceinline__ uint32_t neighbour_repeat(uint32_t word, bool eligible, uint32_t stride)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   uint32_t dist = 0;
   for (uint32_t d = 1; d <= 8; d *= 2) {
     const uint32_t other = wave::shuffle(word, (lane - d) & 63u);
     if (eligible && dist == 0 && lane >= d && other == word) {
-      dist = d;
+      dist = d * stride;
     }
   }
   return dist;
@@ -206,7 +206,8 @@ __device__ __forceinline__ uint32_t neighbour_repeat(uint32_t word, bool eligibl
  * is known to match without looking.
  */
 __device__ __forceinline__ Probe probe_fast(
-    const uint8_t* __restrict__ src, const uint16_t* table, const Around& me, uint32_t pos, bool eligible, uint32_t match_end)
+    const uint8_t* __restrict__ src, const uint16_t* table, const Around& me, uint32_t pos, bool eligible, uint32_t match_end,
+    uint32_t stride)
 {
   Probe p;
   p.word = me.fwd[0];
@@ -220,7 +221,7 @@ __device__ __forceinline__ Probe probe_fast(
     ok = ok && ((const uint8_t*)(table + kHashSize))[slot] == tag4(p.word);
 #endif
   }
-  const uint32_t near = neighbour_repeat(p.word, eligible);
+  const uint32_t near = neighbour_repeat(p.word, eligible, stride);
   if (near) {
     p.cand = pos - near;
     ok = true;
@@ -261,7 +262,7 @@ __device__ __forceinline__ Probe probe_fast(
 
 /* The same probe with nothing assumed about how far a position may read: the last windows of a chunk. */
 __device__ __forceinline__ Probe probe_safe(
-    const uint8_t* __restrict__ src, const uint16_t* table, uint32_t pos, bool eligible, uint32_t match_end)
+    const uint8_t* __restrict__ src, const uint16_t* table, uint32_t pos, bool eligible, uint32_t match_end, uint32_t stride)
 {
   Probe p;
   p.word = 0;
@@ -278,7 +279,7 @@ __device__ __forceinline__ Probe probe_safe(
     ok = ok && ((const uint8_t*)(table + kHashSize))[slot] == tag4(p.word);
 #endif
   }
-  const uint32_t near = neighbour_repeat(p.word, eligible);
+  const uint32_t near = neighbour_repeat(p.word, eligible, stride);
   if (near) {
     p.cand = pos - near;
     p.found = true;
@@ -310,7 +311,14 @@ __device__ __forceinline__ Probe probe_safe(
   return p;
 }
 
-template <class Emitter>
+/*
+ * STRIDE = bytes between the positions two neighbouring lanes look at: 1 for untyped data; 2, 4 or 8 when the caller
+ * declared the chunk an array of 2-, 4- or 8-byte elements (nvcompBatchedLZ4Opts_t.data_type, reference
+ * CHANGELOG.md:168-169 "an optimization to the LZ4 compressor based on specification of input data as char, short, or
+ * int"): matches then start at element boundaries only and lie a whole number of elements back, a window covers
+ * 64 x STRIDE bytes per step, and the neighbour compares look 1, 2, 4 and 8 ELEMENTS back.
+ */
+template <class Emitter, uint32_t STRIDE = 1>
 __device__ __forceinline__ uint32_t encode_chunk(
     const uint8_t* __restrict__ src, uint32_t n, uint8_t* dst, uint16_t* table, uint32_t last_start,
     uint32_t match_end, bool any_match)
@@ -326,7 +334,8 @@ __device__ __forceinline__ uint32_t encode_chunk(
   LZM_PROF_DECL;
   if (any_match) {
     uint32_t ip = 0;
-    uint32_t skip = 0;        /* leading positions of the window that the previous step's last match already covers */
+    constexpr uint32_t kWin = 64 * STRIDE; /* bytes a window covers */
+    uint32_t skip = 0;        /* leading BYTES of the window that the previous step's last match already covers */
     Around ahead;             /* position side of window `ahead_ip`, requested one step early */
     uint32_t ahead_ip = ~0u;
 #pragma unroll
@@ -335,9 +344,9 @@ __device__ __forceinline__ uint32_t encode_chunk(
     }
     ahead.pre[0] = 0, ahead.pre[1] = 0;
     while (ip <= last_start) {
-      const uint32_t pos = ip + lane;
+      const uint32_t pos = ip + lane * STRIDE;
       const bool eligible = pos <= last_start;
-      const bool fast = ip + 63 + 32 <= n; /* wave-uniform: every lane may read its 32 bytes */
+      const bool fast = ip + 63 * STRIDE + 32 <= n; /* wave-uniform: every lane may read its 32 bytes */
       LZM_T(0); /* loop top */
       Probe pr;
       Around me; /* fast windows: the bytes around this lane's position stay in registers until its literals are written */
@@ -348,13 +357,13 @@ __device__ __forceinline__ uint32_t encode_chunk(
         } else {
           load_around(me, src, pos, pos >= kBackMax);
         }
-        if (ip + 64 + 63 + 32 <= n) { /* the next window's position side travels while this one is worked on */
-          ahead_ip = ip + 64;
-          load_around(ahead, src, pos + 64, true);
+        if (ip + kWin + 63 * STRIDE + 32 <= n) { /* the next window's position side travels while this one is worked on */
+          ahead_ip = ip + kWin;
+          load_around(ahead, src, pos + kWin, true);
         }
-        pr = probe_fast(src, table, me, pos, eligible, match_end);
+        pr = probe_fast(src, table, me, pos, eligible, match_end, STRIDE);
       } else {
-        pr = probe_safe(src, table, pos, eligible, match_end);
+        pr = probe_safe(src, table, pos, eligible, match_end, STRIDE);
       }
       const uint32_t word = pr.word;
       const uint32_t cand = pr.cand;
@@ -371,12 +380,12 @@ __device__ __forceinline__ uint32_t encode_chunk(
 #endif
       }
       wave::sync();
-      const uint64_t hits = wave::ballot(pr.found && lane >= skip);
+      const uint64_t hits = wave::ballot(pr.found && lane * STRIDE >= skip);
       LZM_T(2); /* table insert */
       if (hits == 0) {
         /* no match starts in this window: its positions become literals */
-        skip = skip > 64 ? skip - 64 : 0;
-        ip += 64;
+        skip = skip > kWin ? skip - kWin : 0;
+        ip += kWin;
         continue;
       }
 
@@ -385,7 +394,7 @@ __device__ __forceinline__ uint32_t encode_chunk(
        * measurement finds the rare long match anyway) ---- */
       if (wave::popc64(hits) >= kDenseHits) {
         const uint32_t f0 = wave::ctz64(hits);
-        uint32_t mpos = ip + f0;
+        uint32_t mpos = ip + f0 * STRIDE;
         uint32_t mcand = wave::read_lane(cand, f0);
         const uint32_t p = mpos + kMinMatch + lane;
         const bool same = p < match_end && src[p] == src[mcand + kMinMatch + lane];
@@ -409,7 +418,7 @@ __device__ __forceinline__ uint32_t encode_chunk(
           /* whole windows inside the match are skipped (their positions stay out of the table, as in the CPU
            * compressors); the window the match ends in is probed from its beginning, the positions the match covers
            * cannot start another */
-          const uint32_t jump = (next - ip) & ~63u; /* 0: it ends inside this window, which is looked at again */
+          const uint32_t jump = (next - ip) / kWin * kWin; /* 0: it ends inside this window, which is looked at again */
           ip += jump;
           skip = next - ip;
           continue;
@@ -420,7 +429,7 @@ __device__ __forceinline__ uint32_t encode_chunk(
       /* ---- greedy selection in position order (scalar walk over the hit mask) ---- */
       uint32_t prev_end = 0;  /* per selected lane: where its literal run starts */
       uint64_t selected = 0;
-      uint32_t cur = 0;       /* window-relative position the next match may start at */
+      uint32_t cur = 0;       /* window-relative BYTE position the next match may start at */
       uint32_t lit_from = anchor;
       uint64_t rest = hits;
       while (rest) {
@@ -428,14 +437,17 @@ __device__ __forceinline__ uint32_t encode_chunk(
         const uint32_t flen = wave::read_lane(mlen, f);
         prev_end = wave::write_lane(prev_end, lit_from, f);
         selected |= 1ull << f;
-        cur = f + flen;
+        cur = f * STRIDE + flen;
         if (flen >= kLaneCap) { /* the capped match may be much longer: measure it with the whole wave */
-          const uint32_t full = extend_match(src, ip + f, wave::read_lane(cand, f), kLaneCap, match_end);
+          const uint32_t full = extend_match(src, ip + f * STRIDE, wave::read_lane(cand, f), kLaneCap, match_end);
           mlen = wave::write_lane(mlen, full, f);
-          cur = f + full;
+          cur = f * STRIDE + full;
         }
         lit_from = ip + cur;
-        rest = cur < 64 ? (hits & (~0ull << cur)) : 0ull;
+        {
+          const uint32_t next_lane = (cur + STRIDE - 1) / STRIDE; /* first lane at or behind the match's end */
+          rest = next_lane < 64 ? (hits & (~0ull << next_lane)) : 0ull;
+        }
       }
 
       LZM_T(4); /* selection */
@@ -527,13 +539,13 @@ __device__ __forceinline__ uint32_t encode_chunk(
       anchor = lit_from;
       /* the next window starts 64 positions on whatever the last match covers of it (so that the data requested
        * ahead is the data needed); whole windows inside a long match are skipped */
-      if (cur >= 128) {
-        const uint32_t jump = cur & ~63u;
+      if (cur >= 2 * kWin) {
+        const uint32_t jump = cur / kWin * kWin;
         ip += jump;
         skip = cur - jump;
       } else {
-        ip += 64;
-        skip = cur > 64 ? cur - 64 : 0;
+        ip += kWin;
+        skip = cur > kWin ? cur - kWin : 0;
       }
     }
   }

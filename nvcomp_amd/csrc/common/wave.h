@@ -110,7 +110,7 @@ __device__ __forceinline__ uint32_t write_lane(uint32_t vec, uint32_t val, uint3
  * around LDS-DMA / s_movrel / message instructions, none of which this library emits. */
 __device__ __forceinline__ uint32_t write_lane_scalar(uint32_t vec, uint32_t val, uint32_t lane)
 {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(val), "s"(lane));
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(val), "s"(lane) : "m0");
   return vec;
 }
 
@@ -138,7 +138,7 @@ __device__ __forceinline__ void chain_walk(uint32_t step, uint32_t limit, uint32
       "s_mov_b32 %[k], m0"
       : [rec] "+v"(rec), [r] "+s"(r), [k] "+s"(k), [d] "=&s"(d)
       : [step] "v"(step), [limit] "s"(limit)
-      : "scc");
+      : "scc", "m0");
 }
 
 /* Per-lane gather: lane i receives v of lane src_lane(i) (ds_bpermute_b32). */

@@ -206,7 +206,15 @@ __device__ __forceinline__ uint32_t decode_chunk(
       return 0;
     }
     if (SIZE_ONLY) {
-      op += wave::reduce_add(s.lit_len + s.match_len);
+      /* a hostile stream may claim lengths whose 32-bit sum wraps to a small bogus size: the batch is summed in two
+       * 16-bit halves (64 x 65535 fits) and the total checked against the largest chunk any decoder here accepts */
+      const uint32_t len = s.lit_len + s.match_len; /* each part is at most 2^30 */
+      const uint64_t batch = (uint64_t)wave::reduce_add(len & 0xffffu) + ((uint64_t)wave::reduce_add(len >> 16) << 16);
+      if (batch + op > (1u << 26)) {
+        err |= lz::kErrOutput;
+        return 0;
+      }
+      op += (uint32_t)batch;
     } else {
       op += lz::execute_batch<CHECKED, LANE_PARALLEL>(in, in_len, out, out_cap, op, count, s, err);
       if (CHECKED && err) {

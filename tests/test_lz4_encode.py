@@ -61,3 +61,37 @@ def test_opts_validation(backend):
     assert lib.nvcompBatchedLZ4CompressGetMaxOutputChunkSize(65536, LZ4Opts(7), C.byref(out)) == NvcompStatus.ErrorInvalidValue
     assert lib.nvcompBatchedLZ4CompressGetMaxOutputChunkSize(65536, LZ4Opts(0xFF), C.byref(out)) == NvcompStatus.Success
     assert lib.nvcompBatchedLZ4CompressGetTempSize(10, 1 << 25, LZ4Opts(0), C.byref(out)) == NvcompStatus.ErrorChunkSizeTooLarge
+
+
+@pytest.mark.parametrize("data_type,width", [(2, 2), (3, 2), (4, 4), (5, 4)])
+def test_data_type_option_is_honoured(backend, oracle, data_type, width):
+    """nvcompBatchedLZ4Opts_t.data_type (benchmarks/benchmark_lz4_chunked.cu:32,43,76-84; CHANGELOG.md:168-169): with a
+    2- or 4-byte element type matches are searched at element boundaries only. Every block still decodes with
+    LZ4_decompress_safe, whatever the chunk length (a ragged tail is literals), and on the int32 column (liblz4
+    ratio 37.5) the typed search loses nothing."""
+    chunks = datasets.split_chunks(datasets.int32_column(2 * 65536, 5)) + [datasets.text(30000, 2),
+                                                                          datasets.float32_column(65536, 1),
+                                                                          datasets.int32_column(4 * 1000 + 3, 9)]
+    typed = backend.codec("LZ4", (data_type,)).compress(chunks)
+    decode_all(oracle, typed, chunks)
+    untyped = backend.codec("LZ4").compress(chunks)
+    col = slice(0, 2)  # the two whole int32-column chunks
+    r_typed = sum(c.size for c in chunks[col]) / sum(c.size for c in typed[col])
+    r_untyped = sum(c.size for c in chunks[col]) / sum(c.size for c in untyped[col])
+    cpu = sum(c.size for c in chunks[col]) / sum(oracle.lz4_compress(c).size for c in chunks[col])
+    assert r_untyped >= 33 and r_untyped >= 0.9 * cpu, (r_untyped, cpu)
+    if width == 4:
+        assert r_typed >= 0.9 * r_untyped, (r_typed, r_untyped)
+
+
+def test_oversized_chunk_is_not_compressed(backend):
+    """A chunk larger than max_uncompressed_chunk_bytes would overrun the slot sized from GetMaxOutputChunkSize: its
+    compressed size reads 0 and nothing is written."""
+    from nvcomp_amd.batched import BatchedCodec
+
+    chunks = [datasets.text(3000, 1), datasets.text(9000, 2), datasets.text(2000, 3)]
+    codec = backend.codec("LZ4")
+    comp = codec.compress(chunks, max_chunk=4096) if "max_chunk" in BatchedCodec.compress.__code__.co_varnames else None
+    if comp is None:
+        pytest.skip("harness cannot declare a smaller max chunk")
+    assert comp[1].size == 0 and comp[0].size > 0 and comp[2].size > 0

@@ -40,6 +40,18 @@ def test_low_level_example_on_emulator(tmp_path):
     assert "round-tripped in place" in run([str(exe)])
 
 
+def test_crc_is_the_standard_crc32_on_emulator(tmp_path):
+    """The managers' per-chunk checksums equal zlib.crc32 (reference examples/standard_crc_checksum.cpp:94-107 compares
+    with boost::crc_32_type): the example reads crc_uncomp[] / crc_comp[] out of the container and recomputes both."""
+    import conftest
+
+    conftest.emu_library()
+    exe = tmp_path / "crc_emu"
+    run(["g++", "-O1", "-std=c++17", "-Itests/emu", "-Iinclude", "-Iexamples", "examples/standard_crc_checksum.cpp",
+         "-o", str(exe), "-Ltests/emu", "-lnvcomp_emu", "-lz", f"-Wl,-rpath,{REPO}/tests/emu"])
+    assert "equals zlib's crc32()" in run([str(exe)])
+
+
 @pytest.fixture(scope="module")
 def built_programs():
     run(["make", "-C", "benchmarks", "-j8"])
@@ -61,6 +73,7 @@ def sample_files(tmp_path_factory):
 def test_examples_on_gpu(built_programs, sample_files):
     assert "all scenarios passed" in run(["examples/bin/high_level_quickstart_example"])
     assert "round-tripped in place" in run(["examples/bin/low_level_quickstart_example"])
+    assert "equals zlib's crc32()" in run(["examples/bin/standard_crc_checksum"])
     if os.path.exists(os.path.join(REPO, "examples/bin/lz4_cpu_compression")):
         out = run(["examples/bin/lz4_cpu_compression", "-f", sample_files["table.txt"], sample_files["floats.csv"]])
         assert "decompression validated" in out
