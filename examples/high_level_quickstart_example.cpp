@@ -137,6 +137,65 @@ void multi_buffer_streamed(const uint8_t* d_in, const std::vector<uint8_t>& host
 
 } // namespace
 
+/* A manager decompresses what a manager of another chunk size wrote (the header carries the chunk size), refuses a
+ * buffer whose header does not add up, and a CascadedManager refuses a buffer that is not a whole number of elements
+ * instead of dropping its tail. */
+void header_is_authoritative(const uint8_t* d_in, const std::vector<uint8_t>& host)
+{
+  hipStream_t stream;
+  HIP_CHECK(hipStreamCreate(&stream));
+  {
+    nvcompBatchedLZ4Opts_t opts{NVCOMP_TYPE_CHAR};
+    LZ4Manager writer{1 << 15, opts, stream, 0, NoComputeNoVerify};
+    CompressionConfig cc = writer.configure_compression(host.size());
+    DeviceBuf comp(cc.max_compressed_buffer_size);
+    writer.compress(d_in, comp.p, cc);
+    LZ4Manager reader{1 << 16, opts, stream, 0, NoComputeNoVerify};
+    DecompressionConfig dc = reader.configure_decompression(comp.p);
+    if (dc.chunk_size != (1u << 15) || dc.num_chunks != cc.num_chunks) {
+      throw std::runtime_error("header: the reader did not take the writer's chunk size");
+    }
+    DeviceBuf out(dc.decomp_data_size + 4096);
+    HIP_CHECK(hipMemset(out.p + dc.decomp_data_size, 0xa5, 4096));
+    reader.decompress(out.p, comp.p, dc);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (*dc.get_status() != nvcompSuccess) {
+      throw std::runtime_error("header: status " + std::to_string((int)*dc.get_status()));
+    }
+    expect_equal(out.p, host, "header");
+    std::vector<uint8_t> fence(4096);
+    HIP_CHECK(hipMemcpy(fence.data(), out.p + dc.decomp_data_size, 4096, hipMemcpyDeviceToHost));
+    for (uint8_t b : fence) {
+      if (b != 0xa5) {
+        throw std::runtime_error("header: wrote past the output buffer");
+      }
+    }
+    /* a header that claims more chunks than its size allows is rejected before any kernel runs */
+    uint32_t bogus = (uint32_t)cc.num_chunks + 7;
+    HIP_CHECK(hipMemcpy(comp.p + 20, &bogus, 4, hipMemcpyHostToDevice)); /* Header::num_chunks */
+    bool threw = false;
+    try {
+      (void)reader.configure_decompression(comp.p);
+    } catch (const std::exception&) {
+      threw = true;
+    }
+    if (!threw) {
+      throw std::runtime_error("header: an inconsistent header was accepted");
+    }
+    threw = false;
+    try {
+      CascadedManager casc{1 << 16, nvcompBatchedCascadedDefaultOpts, stream, 0, NoComputeNoVerify};
+      (void)casc.configure_compression(1000003); /* int elements: not a multiple of 4 */
+    } catch (const std::invalid_argument&) {
+      threw = true;
+    }
+    if (!threw) {
+      throw std::runtime_error("header: CascadedManager accepted a ragged buffer");
+    }
+  }
+  HIP_CHECK(hipStreamDestroy(stream));
+}
+
 int main()
 {
   try {
@@ -154,6 +213,7 @@ int main()
     with_manager_factory(d_in.p, data, ComputeAndNoVerify, NoComputeAndVerifyIfPresent);
     with_manager_factory(d_in.p, data, NoComputeNoVerify, ComputeAndVerifyIfPresent);
     single_manager_with_checksums(d_in.p, data);
+    header_is_authoritative(d_in.p, data);
     multi_buffer_streamed<LZ4Manager>(d_in.p, data, nvcompBatchedLZ4Opts_t{NVCOMP_TYPE_CHAR}, 1 << 16);
     multi_buffer_streamed<SnappyManager>(d_in.p, data, nvcompBatchedSnappyDefaultOpts, 1 << 15);
     multi_buffer_streamed<CascadedManager>(d_in.p, data, nvcompBatchedCascadedDefaultOpts, 1 << 16);

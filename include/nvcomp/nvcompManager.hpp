@@ -58,6 +58,9 @@ struct DecompressionConfig
 {
   size_t decomp_data_size = 0;
   uint32_t num_chunks = 0;
+  /* uncompressed chunk size the buffer was written with (from its header, or the compressing manager's); a manager
+   * decompresses buffers of any chunk size of its format */
+  size_t chunk_size = 0;
   /* nvcompSuccess / nvcompErrorBadChecksum / nvcompErrorCannotDecompress; valid after the stream is synchronised */
   nvcompStatus_t* get_status() const;
   std::shared_ptr<detail::StatusWord> status;

@@ -127,14 +127,26 @@ __global__ void __launch_bounds__(256) layout_kernel(
     const size_t* comp_sizes, size_t n, uint8_t* comp_buffer, Header header, size_t tables, nvcompStatus_t* status)
 {
   __shared__ uint64_t partial[256];
+  __shared__ uint32_t refused;
+  if (threadIdx.x == 0) {
+    refused = 0;
+  }
+  __syncthreads();
   uint64_t* sizes_out = (uint64_t*)(comp_buffer + sizeof(Header));
   uint64_t* offsets = sizes_out + n;
   const size_t per = (n + 255) / 256;
   const size_t lo = (size_t)threadIdx.x * per;
   const size_t hi = lo + per < n ? lo + per : n;
   uint64_t sum = 0;
+  bool zero = false;
   for (size_t i = lo; i < hi; ++i) {
     sum += (comp_sizes[i] + 7) & ~(uint64_t)7;
+    /* every codec writes at least a header for a chunk it accepted (even an empty one, unless the whole buffer is
+     * empty): size 0 means it refused the chunk (e.g. Cascaded: not a whole number of elements) */
+    zero = zero || (comp_sizes[i] == 0 && header.uncompressed_size != 0);
+  }
+  if (zero) {
+    atomicOr(&refused, 1u);
   }
   partial[threadIdx.x] = sum;
   __syncthreads();
@@ -149,7 +161,7 @@ __global__ void __launch_bounds__(256) layout_kernel(
     header.compressed_size = sizeof(Header) + tables + run;
     *(Header*)comp_buffer = header;
     if (status != nullptr) {
-      *status = nvcompSuccess;
+      *status = refused ? nvcompErrorInvalidValue : nvcompSuccess;
     }
   }
   __syncthreads();
@@ -189,8 +201,10 @@ __global__ void setup_decompress_kernel(
     const uint64_t* offsets = sizes + n;
     comp_ptrs[i] = comp_buffer + sizeof(Header) + tables + offsets[i];
     comp_sizes[i] = sizes[i];
-    out_ptrs[i] = decomp + i * chunk;
-    out_caps[i] = total - i * chunk < chunk ? total - i * chunk : chunk;
+    /* never past the end of the buffer, whatever the configuration claims */
+    const size_t lo = i * chunk < total ? i * chunk : total;
+    out_ptrs[i] = decomp + lo;
+    out_caps[i] = total - lo < chunk ? total - lo : chunk;
   }
 }
 
@@ -407,6 +421,16 @@ BatchedManager::~BatchedManager() = default;
 
 CompressionConfig BatchedManager::configure_compression(const size_t decomp_buffer_size)
 {
+  if (impl_->format == kCascaded) {
+    /* the codec works on whole elements (nvcompBatchedCascadedOpts_t.type): a ragged buffer would lose its last
+     * chunk at compress time */
+    nvcompBatchedCascadedOpts_t o;
+    memcpy(&o, impl_->opts, sizeof(o));
+    const size_t w = o.type <= NVCOMP_TYPE_UCHAR ? 1 : o.type <= NVCOMP_TYPE_USHORT ? 2 : o.type <= NVCOMP_TYPE_UINT ? 4 : 8;
+    if (decomp_buffer_size % w != 0 || impl_->chunk % w != 0) {
+      throw std::invalid_argument("nvcomp: CascadedManager: buffer and chunk sizes must be multiples of the element size");
+    }
+  }
   CompressionConfig c;
   c.uncompressed_buffer_size = decomp_buffer_size;
   c.num_chunks = (decomp_buffer_size + impl_->chunk - 1) / impl_->chunk;
@@ -479,9 +503,19 @@ DecompressionConfig BatchedManager::configure_decompression(const uint8_t* comp_
   if (impl_->policy == ComputeAndVerify && !(h.flags & kFlagChecksums)) {
     throw std::runtime_error("nvcomp: ComputeAndVerify requested but the buffer holds no checksums");
   }
+  /* the header decides where every chunk goes: a chunk size or count that does not fit the declared size (a buffer
+   * written with other options, or a corrupted header) must not reach the kernels */
+  if (h.chunk_size == 0 || h.chunk_size > (1u << 24)
+      || (uint64_t)h.num_chunks != (h.uncompressed_size + h.chunk_size - 1) / h.chunk_size) {
+    throw std::runtime_error("nvcomp: inconsistent container header (chunk size / chunk count / uncompressed size)");
+  }
+  if (memcmp(h.opts, impl_->opts, sizeof(h.opts)) != 0) {
+    throw std::runtime_error("nvcomp: compressed buffer was written with different format options");
+  }
   DecompressionConfig d;
   d.decomp_data_size = h.uncompressed_size;
   d.num_chunks = h.num_chunks;
+  d.chunk_size = h.chunk_size;
   d.status = std::make_shared<detail::StatusWord>();
   return d;
 }
@@ -491,6 +525,7 @@ DecompressionConfig BatchedManager::configure_decompression(const CompressionCon
   DecompressionConfig d;
   d.decomp_data_size = comp_config.uncompressed_buffer_size;
   d.num_chunks = (uint32_t)comp_config.num_chunks;
+  d.chunk_size = impl_->chunk;
   d.status = std::make_shared<detail::StatusWord>();
   return d;
 }
@@ -519,7 +554,8 @@ void BatchedManager::decompress(uint8_t* decomp_buffer, const uint8_t* comp_buff
   const size_t tables = table_bytes(n);
   const unsigned blocks = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(setup_decompress_kernel, dim3(blocks), dim3(256), 0, m.stream, comp_buffer, tables, n,
-                     cfg.decomp_data_size, m.chunk, decomp_buffer, comp_ptrs, comp_sizes, out_ptrs, out_caps);
+                     cfg.decomp_data_size, cfg.chunk_size ? cfg.chunk_size : m.chunk, decomp_buffer, comp_ptrs, comp_sizes,
+                     out_ptrs, out_caps);
   const bool verify = m.verify_checksums(); /* the kernels skip the check when the buffer has no checksums */
   const uint32_t* crc_u = (const uint32_t*)(comp_buffer + sizeof(Header) + 8 * n + 8 * (n + 1));
   const uint32_t* crc_c = crc_u + n;
