@@ -159,6 +159,20 @@ def float_columns(size: int, seed: int = 0) -> np.ndarray:
     return out.view(np.uint8)[:size].copy()
 
 
+def example_float_columns(size: int, seed: int = 0) -> np.ndarray:
+    """The REAL BASELINE.json configs[3] input: the three columns of the reference's benchmarks/ExampleFloatData.csv
+    after text_to_binary.py (float32, 4001 values each; fixtures tests/golden/ExampleFloatData_col*_float.bin, made by
+    the reference's own script: scripts/make_golden_columns.py), repeated column after column to `size` bytes the way
+    the harness's `-x` duplication multiplies a file. `seed` rotates the starting column."""
+    import os
+
+    gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    cols = [np.fromfile(os.path.join(gold, f"ExampleFloatData_col{c}_float.bin"), dtype=np.uint8) for c in range(3)]
+    cols = cols[seed % 3:] + cols[:seed % 3]
+    unit = np.concatenate(cols)
+    return np.tile(unit, size // unit.size + 1)[:size].copy()
+
+
 def int32_column(size: int, seed: int = 0) -> np.ndarray:
     """Sorted keys with runs (low-cardinality dimension column), int32."""
     rng = np.random.RandomState(seed + 505)
@@ -168,6 +182,7 @@ def int32_column(size: int, seed: int = 0) -> np.ndarray:
 
 
 CLASSES: Dict[str, Callable[[int, int], np.ndarray]] = {
+    "example_float_columns": example_float_columns,
     "text": text,
     "table": table_rows,
     "float_csv": float_csv,

@@ -107,3 +107,20 @@ def test_no_runtime_kernel_switches():
     blob = open(os.path.join(REPO, "nvcomp_amd", "lib", "libnvcomp.so"), "rb").read() if os.path.exists(
         os.path.join(REPO, "nvcomp_amd", "lib", "libnvcomp.so")) else b""
     assert b"NVCOMP_AMD_LZ4_DECODE" not in blob and b"NVCOMP_AMD_SNAPPY_DECODE" not in blob
+
+
+def test_cmake_package_exports_nvcomp_target(tmp_path):
+    """find_package(nvcomp 3.0.3 REQUIRED) + nvcomp::nvcomp, as the reference's callers write it
+    (CMakeLists.txt:18, cmake/nvcomp-config.cmake.in:25-26, benchmarks/CMakeLists.txt:28): a consumer configures, builds
+    and runs (host-only entry points)."""
+    import shutil
+    import subprocess
+
+    if shutil.which("cmake") is None or not os.path.exists(os.path.join(REPO, "nvcomp_amd", "lib", "libnvcomp.so")):
+        pytest.skip("cmake or the built library is missing")
+    build = tmp_path / "b"
+    subprocess.run(["cmake", "-S", os.path.join(REPO, "tests", "cmake_consumer"), "-B", str(build),
+                    f"-Dnvcomp_DIR={REPO}/cmake", "-DCMAKE_BUILD_TYPE=Release"], check=True, capture_output=True)
+    subprocess.run(["cmake", "--build", str(build)], check=True, capture_output=True)
+    out = subprocess.run([str(build / "consumer")], check=True, capture_output=True, text=True).stdout
+    assert "LZ4 bound for 64 KiB = 65809" in out
