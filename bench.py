@@ -122,6 +122,18 @@ class TorchRuntime:
     def as_tensor(self, buf):
         return buf
 
+    def side_streams(self, k):
+        return [self.torch.cuda.Stream(device=self.dev.device) for _ in range(k)]
+
+    def on_stream(self, s):
+        return self.torch.cuda.stream(s)
+
+    def join_streams(self, streams):
+        """The current stream continues after everything queued on `streams`."""
+        cur = self.torch.cuda.current_stream(self.dev.device)
+        for s in streams:
+            cur.wait_stream(s)
+
     def shutdown(self):
         if self.dist is not None:
             self.dist.destroy_process_group()
@@ -166,6 +178,17 @@ class EmuRuntime:
         import torch
 
         return torch.from_numpy(buf)
+
+    def side_streams(self, k):
+        return [None] * k
+
+    def on_stream(self, s):
+        import contextlib
+
+        return contextlib.nullcontext()
+
+    def join_streams(self, streams):
+        pass
 
     def shutdown(self):
         if self.dist is not None:
@@ -571,56 +594,75 @@ def run_allgather_case(args, ctx):
     dst = DeviceBatch(slots, dev_u64(ptr(slots) + np.arange(n, dtype=np.uint64) * max_out), sizes, None, raw_sizes, n)
     ctb = codec.compress_temp_size(n, CHUNK)
     ctemp = dev.empty(ctb) if ctb else None
-    dtb = codec.decompress_temp_size(n * (world - 1), CHUNK)
-    dtemp = dev.empty(dtb) if dtb else None
+    dtb = codec.decompress_temp_size(n, CHUNK)
     out = rt.as_tensor(dev.empty(shard_bytes * world))
+    remote = [r for r in range(world) if r != rank]
+    m = n * len(remote)
+    # Every buffer of a step exists before the timed loop: the packed payload of this rank and one
+    # receive buffer per peer at the worst-case size (288 GB of HBM: 8 ranks x 4 GiB shards need 7 x 4.02 GiB), the
+    # gathered sizes and the pointer arrays derived from them.
+    cap_bytes = n * max_out
+    packed = rt.as_tensor(dev.empty(cap_bytes))
+    my_offsets = rt.as_tensor(dev.upload(np.zeros(n + 1, dtype=np.int64).view(np.uint8))).view(torch.int64)
+    recv = {r: rt.as_tensor(dev.empty(cap_bytes)) for r in remote}
     all_sizes_flat = torch.zeros(world * n, dtype=torch.int64, device=sizes.device)
     all_sizes = all_sizes_flat.view(world, n)
-    col = torch.arange(max_out, device=sizes.device)[None, :]
-    m = n * (world - 1)
-    actual = dev.upload(np.zeros(m, dtype=np.uint64).view(np.uint8))
-    statuses = dev.upload(np.full(m, -1, dtype=np.int32).view(np.uint8))
-    remote = [r for r in range(world) if r != rank]
-    out_ptrs = np.concatenate([ptr(out) + r * shard_bytes + np.arange(n, dtype=np.uint64) * CHUNK for r in remote]
-                              + [np.zeros(0, dtype=np.uint64)])
-    out_batch = DeviceBatch(out, dev_u64(out_ptrs), dev_u64(np.full(m, CHUNK)), None, None, m)
+    offs_all = torch.zeros(world, n, dtype=torch.int64, device=sizes.device)
+    ptrs_all = torch.zeros(world, n, dtype=torch.int64, device=sizes.device)
+    totals = torch.zeros(world, dtype=torch.int64, device=sizes.device)
+    actual = rt.as_tensor(dev.upload(np.zeros(max(m, 1), dtype=np.uint64).view(np.uint8))).view(torch.int64)
+    statuses = rt.as_tensor(dev.upload(np.full(max(m, 1), -1, dtype=np.int32).view(np.uint8))).view(torch.int32)
+    dtemps = {r: (dev.empty(dtb) if dtb else None) for r in remote}
+    out_batches = {}
+    for r in remote:
+        optrs = ptr(out) + r * shard_bytes + np.arange(n, dtype=np.uint64) * CHUNK
+        out_batches[r] = DeviceBatch(out, dev_u64(optrs), dev_u64(np.full(n, CHUNK)), None, None, n)
+    side = rt.side_streams(len(remote))
     moved = [0]
 
     def step():
         rc = codec.compress_async(src, dst, CHUNK, ctemp, ctb)
         assert rc == 0, rc
-        # compaction of the padded slots: rows truncated to their compressed size, concatenated
-        compact = slots.view(n, max_out)[col < sizes[:, None]]
-        dist.all_gather_into_tensor(all_sizes_flat, sizes)
-        totals = all_sizes.sum(dim=1)
-        cap = int(totals.max().item())  # host sync, like the reference's sync_all_streams before the copies
-        moved[0] = int(totals.sum().item())
-        mine = torch.zeros(cap, dtype=torch.uint8, device=sizes.device)
-        mine[: compact.numel()] = compact
-        gathered = torch.empty(world * cap, dtype=torch.uint8, device=sizes.device)
-        dist.all_gather_into_tensor(gathered, mine)
-        offs = torch.cumsum(all_sizes, dim=1) - all_sizes
-        base = torch.tensor([ptr(gathered) + r * cap for r in range(world)], dtype=torch.int64, device=sizes.device)
-        comp_ptrs = (offs + base[:, None])[remote].reshape(-1).contiguous()
-        comp_sizes = all_sizes[remote].reshape(-1).contiguous()
-        batch = DeviceBatch(gathered, comp_ptrs, comp_sizes, None, None, m)
-        rc = codec.decompress_async(batch, out_batch, actual, statuses, dtemp, dtb)
+        # the chunks leave their worst-case slots for one contiguous payload: device-side prefix sum + one wave per chunk
+        rc = lib.nvcompAmdBatchedPackAsync(dev.ptr(dst.ptrs), dev.ptr(sizes), n, dev.ptr(packed), cap_bytes,
+                                           dev.ptr(my_offsets), dev.stream())
         assert rc == 0, rc
-        out[rank * shard_bytes: (rank + 1) * shard_bytes] = raw  # own shard: plain copy (benchmark_allgather.cpp:386-393)
-        return gathered  # keep alive until the stream has consumed it
+        dist.all_gather_into_tensor(all_sizes_flat, sizes)
+        torch.sum(all_sizes, dim=1, out=totals)
+        host_totals = totals.tolist()  # THE host sync of a step: the sizes, like the reference's sync_all_streams (:370)
+        moved[0] = int(sum(host_totals))
+        torch.cumsum(all_sizes, dim=1, out=offs_all)
+        offs_all.sub_(all_sizes)
+        # the payloads travel rank by rank (the actual compressed bytes, not the bound the reference ships) ...
+        works = {}
+        for r in range(world):
+            buf = packed if r == rank else recv[r]
+            works[r] = dist.broadcast(buf[: host_totals[r]], src=r, async_op=True)
+        # ... and every peer's shard is decoded on its own stream as soon as IT has landed, while the next ones are
+        # still on the wire (the reference waits for all of them, benchmark_allgather.cpp:370)
+        for j, r in enumerate(remote):
+            with rt.on_stream(side[j]):
+                works[r].wait()
+                torch.add(offs_all[r], ptr(recv[r]), out=ptrs_all[r])
+                batch = DeviceBatch(recv[r], ptrs_all[r], all_sizes[r], None, None, n)
+                rc = codec.decompress_async(batch, out_batches[r], actual[j * n: (j + 1) * n], statuses[j * n: (j + 1) * n],
+                                            dtemps[r], dtb)
+                assert rc == 0, rc
+        works[rank].wait()
+        out[rank * shard_bytes: (rank + 1) * shard_bytes].copy_(raw)  # own shard: plain copy (benchmark_allgather.cpp:386-393)
+        rt.join_streams(side)
 
-    keep = None
     for _ in range(args.warmup):
-        keep = step()
+        step()
     rt.barrier_sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        keep = step()
+        step()
     rt.barrier_sync()
     elapsed = rt.max_over_ranks(time.perf_counter() - t0)
-    del keep
-    st = dev.download(statuses, 4 * m).view(np.int32)
-    assert (st == 0).all(), f"{int((st != 0).sum())} remote chunks failed"
+    if m:
+        st = statuses[:m].cpu().numpy()
+        assert (st == 0).all(), f"{int((st != 0).sum())} remote chunks failed"
     # every rank must now hold every shard: compare fingerprints with the owners'
     weights = (torch.arange(shard_bytes, device=sizes.device) % 65521).to(torch.int64)
     prints = torch.stack([(out[r * shard_bytes: (r + 1) * shard_bytes].to(torch.int64) * weights).sum() for r in range(world)])
@@ -659,7 +701,7 @@ def run_allgather_case(args, ctx):
 def main():
     args = parse_args()
     if args.mib_per_gpu is None:
-        args.mib_per_gpu = 1024 if args.allgather else 4096
+        args.mib_per_gpu = 4096
     if args.dataset is None:
         # BASELINE.json configs[3]: "int32 columnar floats" -> float columns shaped like the reference's ExampleFloatData.csv
         # BASELINE.json configs[3]: the reference's own ExampleFloatData.csv columns after text_to_binary.py

@@ -9,6 +9,10 @@
 
 #include <stddef.h>
 
+#include <hip/hip_runtime_api.h>
+
+#include "nvcomp/shared_types.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -22,6 +26,22 @@ extern "C" {
  * concurrent *Async calls. */
 #define NVCOMP_AMD_LZ_INDEX_MIN_BATCH_DEFAULT ((size_t)-1)
 size_t nvcompAmdSetLZIndexMinBatch(size_t min_batch);
+
+/* Pack the chunks of a batch (e.g. what nvcompBatched<Fmt>CompressAsync left in its worst-case-sized slots) into one
+ * contiguous buffer, in batch order and without gaps: device_offsets[i] = sum of device_chunk_bytes[0..i),
+ * device_offsets[batch_size] = the packed size; chunk i is copied to device_packed + device_offsets[i]. Everything
+ * happens on `stream`: a device-side prefix sum, then one wavefront per chunk. A chunk that would end behind
+ * `packed_capacity` is left out (size the buffer as batch_size x the compressor's declared bound). This is the step
+ * between "compress" and "send" of the reference's all-gather benchmark (benchmarks/benchmark_allgather.cpp:322-361
+ * moves the whole slots instead); bench.py --allgather is built on it. */
+nvcompStatus_t nvcompAmdBatchedPackAsync(
+    const void* const* device_chunk_ptrs,
+    const size_t* device_chunk_bytes,
+    size_t batch_size,
+    void* device_packed,
+    size_t packed_capacity,
+    size_t* device_offsets,
+    hipStream_t stream);
 
 #ifdef __cplusplus
 }

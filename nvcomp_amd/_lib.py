@@ -106,6 +106,8 @@ def declare(lib: C.CDLL, formats=FORMATS) -> C.CDLL:
         if "CompressGetTempSizeEx" in EXTRA_ENTRY_POINTS[fmt]:
             getattr(lib, pre + "CompressGetTempSizeEx").argtypes = [sz, sz, opts, szp, sz]
             getattr(lib, pre + "DecompressGetTempSizeEx").argtypes = [sz, sz, szp, sz]
+    if hasattr(lib, "nvcompAmdBatchedPackAsync"):  # include/nvcomp/amd_ext.h
+        lib.nvcompAmdBatchedPackAsync.argtypes = [vp, vp, sz, vp, sz, vp, vp]
     if hasattr(lib, "nvcompAmdSetLZIndexMinBatch"):  # include/nvcomp/amd_ext.h
         lib.nvcompAmdSetLZIndexMinBatch.argtypes = [sz]
         lib.nvcompAmdSetLZIndexMinBatch.restype = sz

@@ -36,3 +36,20 @@ def test_allgather_two_ranks():
     assert res["n_gpus"] == 2 and "all-gather" in res["metric"]
     assert res["config"]["compressed_bytes_moved_per_step"] > 0
     assert res["config"]["ratio"] > 1.0
+
+
+def test_allgather_step_is_library_code():
+    """The timed step of --allgather allocates nothing and compacts with the library (it used to be
+    boolean-mask indexing, torch.zeros/empty per step and two host syncs)."""
+    import inspect
+    import re
+
+    sys.path.insert(0, REPO)
+    import bench
+
+    src = inspect.getsource(bench.run_allgather_case)
+    step = src[src.index("    def step():"): src.index("    for _ in range(args.warmup):")]
+    for banned in ("torch.zeros", "torch.empty", "dev.empty", "dev.upload", ".item()", "col <"):
+        assert banned not in step, banned
+    assert "nvcompAmdBatchedPackAsync" in step and "broadcast" in step and "on_stream" in step
+    assert len(re.findall(r"\.tolist\(\)|\.cpu\(\)", step)) == 1, "exactly one host sync: the sizes"
