@@ -415,12 +415,10 @@ __device__ __forceinline__ uint32_t encode_chunk(
           op += Emitter::match(dst + op, src + anchor, mpos - anchor, mpos - mcand, len0);
           const uint32_t next = mpos + len0;
           anchor = next;
-          /* whole windows inside the match are skipped (their positions stay out of the table, as in the CPU
-           * compressors); the window the match ends in is probed from its beginning, the positions the match covers
-           * cannot start another */
-          const uint32_t jump = (next - ip) / kWin * kWin; /* 0: it ends inside this window, which is looked at again */
-          ip += jump;
-          skip = next - ip;
+          /* the next window starts right behind the match (at the next element boundary): every one of its 64
+           * positions is searched; the position side requested ahead is not the data it needs and is loaded again */
+          ip = (next + STRIDE - 1) / STRIDE * STRIDE;
+          skip = 0;
           continue;
         }
       }
@@ -539,10 +537,9 @@ __device__ __forceinline__ uint32_t encode_chunk(
       anchor = lit_from;
       /* the next window starts 64 positions on whatever the last match covers of it (so that the data requested
        * ahead is the data needed); whole windows inside a long match are skipped */
-      if (cur >= 2 * kWin) {
-        const uint32_t jump = cur / kWin * kWin;
-        ip += jump;
-        skip = cur - jump;
+      if (cur >= 2 * kWin) { /* a long match measured by the whole wave: go on right behind it */
+        ip = (ip + cur + STRIDE - 1) / STRIDE * STRIDE;
+        skip = 0;
       } else {
         ip += kWin;
         skip = cur > kWin ? cur - kWin : 0;

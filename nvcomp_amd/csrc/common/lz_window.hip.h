@@ -577,30 +577,92 @@ __device__ __forceinline__ void far_load_seq(uint32_t (&buf)[8], uint32_t& l4, c
   l4 = wave::gload_u32(src + len - 4);
 }
 
+/* Periodic fill: d[i] = d[i - off] for i in [0, len) with off < 256, i.e. the `off` bytes before d repeated. The
+ * pattern is read ONCE -- lane l keeps its bytes 4l .. 4l+3 -- and every output dword is assembled from four
+ * cross-lane fetches (ds_bpermute) at byte index (position mod off); the dwords go out with ALIGNED stores, 256 bytes
+ * per step, a few head / tail bytes around them. No step reads what an earlier step wrote: no round trips through
+ * LDS, and when off divides 256 (1, 2, 4, 8, ... : runs and typed columns) the dword of a lane never changes, a step is
+ * one store. The pattern-doubling copy this replaces for short periods moved 4 .. 64 bytes per dependent round trip. */
+__device__ __forceinline__ void lds_periodic_fill(uint8_t* d, uint32_t off, uint32_t len)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  /* the pattern, a dword per lane (bytes at or behind `off` are never selected) */
+  uint32_t pat = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 4; ++k) {
+    const uint32_t j = 4 * lane + k;
+    if (j < off) {
+      pat |= (uint32_t)d[(int32_t)j - (int32_t)off] << (8 * k);
+    }
+  }
+  const uint32_t head = (4u - ((uint32_t)(uintptr_t)d & 3u)) & 3u; /* bytes up to the first aligned dword */
+  const uint32_t h = head < len ? head : len;
+  const uint32_t magic = off == 1 ? 0u : 0xffffffffu / off + 1; /* x / off == umulhi(x, magic) for x, off < 2^16 (off 1: x mod 1 = 0 below) */
+  if (lane < h) {
+    const uint32_t sidx = off == 1 ? 0u : lane - __umulhi(lane, magic) * off;
+    d[lane] = (uint8_t)(wave::shuffle(pat, sidx >> 2) >> (8 * (sidx & 3u)));
+  } else if (h != 0) {
+    (void)wave::shuffle(pat, 0); /* the cross-lane fetch is executed by the whole wave */
+  }
+  const uint32_t body = (len - h) >> 2; /* aligned dwords */
+  const uint32_t step = off == 1 ? 0u : 256u - __umulhi(256u, magic) * off; /* 256 mod off: how far the phase moves per 256-byte step */
+  uint32_t r = h + 4 * lane;
+  r = off == 1 ? 0u : r - __umulhi(r, magic) * off;
+  uint32_t word = 0;
+  bool fresh = true;
+  for (uint32_t base = 0; base < body; base += 64) {
+    if (fresh) {
+      uint32_t sidx = r;
+      word = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t b = (wave::shuffle(pat, sidx >> 2) >> (8 * (sidx & 3u))) & 0xffu;
+        word |= b << (8 * k);
+        sidx = sidx + 1 == off ? 0 : sidx + 1;
+      }
+      fresh = step != 0;
+      r += step;
+      r = r >= off ? r - off : r;
+    }
+    if (base + lane < body) {
+      *(uint32_t*)(d + h + 4 * (base + lane)) = word;
+    }
+  }
+  const uint32_t tail_at = h + 4 * body;
+  const uint32_t tail = len - tail_at; /* 0 .. 3 */
+  {
+    const uint32_t i = tail_at + lane;
+    const uint32_t sidx = off == 1 ? 0u : i - __umulhi(i, magic) * off;
+    const uint32_t b = wave::shuffle(pat, (lane < tail ? sidx : 0u) >> 2) >> (8 * (sidx & 3u));
+    if (lane < tail) {
+      d[i] = (uint8_t)b;
+    }
+  }
+  wave::sync();
+}
+
 /* Match copy inside the window with byte-serial semantics: d[i] = d[i - off].
- * Same pattern-doubling scheme as lz::wave_match_copy, on LDS. */
+ * Periods below 256 are a periodic fill; longer ones move 256 bytes per step (a step never reads what it writes). */
 __device__ __forceinline__ void lds_match_copy(uint8_t* d, uint32_t off, uint32_t len)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
+  if (off < 256) {
+    lds_periodic_fill(d, off, len);
+    return;
+  }
   uint32_t done = 0;
-  uint32_t E = off;
   while (done < len) {
-    while (E < 256 && 2 * E <= done + off) {
-      E *= 2;
-    }
     const uint32_t rem = len - done;
-    if (E >= 256 && rem >= 256) {
+    if (rem >= 256) {
       uint8_t* t = d + done + lane * 4;
-      lz::st_u32(t, ld32(t - E));
+      lz::st_u32(t, ld32(t - off));
       done += 256;
     } else {
-      uint32_t n = E < 64 ? E : 64;
-      n = n < rem ? n : rem;
-      if (lane < n) {
-        uint8_t* t = d + done + lane;
-        *t = *(t - E);
+      for (uint32_t i = lane; i < rem; i += 64) {
+        uint8_t* t = d + done + i;
+        *t = *(t - off);
       }
-      done += n;
+      done = len;
     }
     wave::sync();
   }

@@ -269,39 +269,54 @@ __device__ __forceinline__ uint32_t decode_chunk(
   uint32_t op = 0;
   uint32_t seqpos = 0;
   uint32_t count = 0; /* sequences recorded in seqpos lanes [0, count) and not yet executed */
+  /* Parsed sequences stay in registers until they are executed. A batch ends at 1 KiB of output, so on data with long
+   * matches (runs, sorted key columns: 200-400 bytes per sequence) a round executes only a handful of the 64 sequences
+   * a chase delivers: re-chasing and re-parsing the rest every round was 5 000 cycles per SEQUENCE on the reference's
+   * own published shape (profiles/r02_mortgage_like.json). Now the chase and the parse run only when fewer than
+   * kRefillBelow sequences are left; on text a round takes all 64 and every round refills, as before. */
+  constexpr uint32_t kRefillBelow = 24;
+  lz::Seq s;
+  s.lit_src = 0;
+  s.lit_len = 0;
+  s.match_off = 0;
+  s.match_len = 0;
   for (;;) {
     if (count == 0 && c.q >= ir.vend) {
       break;
     }
-    /* keep the stream resident from the oldest unexecuted token to well past the chase */
-    const uint32_t oldest = count ? wave::read_lane(seqpos, 0) : c.q;
-    LZW_T(10);
-    lzw::in_ensure(ir, oldest, (c.q & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
-    LZW_T(0);
-    const uint32_t before = count;
+    if (count < kRefillBelow && c.q < ir.vend) {
+      /* keep the stream resident from the oldest unexecuted token to well past the chase */
+      const uint32_t oldest = count ? wave::read_lane(seqpos, 0) : c.q;
+      LZW_T(10);
+      lzw::in_ensure(ir, oldest, (c.q & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
+      LZW_T(0);
+      const uint32_t before = count;
 #if NVCOMP_LZW_PCHASE
-    count = lzw::chase_tokens(c, ir, seqpos, count, DeltaFn(), SlowFn());
+      count = lzw::chase_tokens(c, ir, seqpos, count, DeltaFn(), SlowFn());
 #else
-    count = chase(c, ir, seqpos, count);
+      count = chase(c, ir, seqpos, count);
 #endif
-    (void)before;
-    if (ABLATE == 1) {
-      op += wave::reduce_add(lane < count ? seqpos : 0u) & 1u;
-      count = 0;
-      continue;
-    }
-    lz::Seq s;
-    bool bad;
-    parse(ir, seqpos, lane < count, s, bad);
-    LZW_T(3);
-    if (ABLATE == 2) {
-      op += wave::reduce_add(s.lit_len + s.match_len + s.match_off) & 1u;
-      count = 0;
-      continue;
-    }
-    if (wave::ballot(bad)) {
-      err |= lz::kErrInput;
-      return 0;
+      if (ABLATE == 1) {
+        op += wave::reduce_add(lane < count ? seqpos : 0u) & 1u;
+        count = 0;
+        continue;
+      }
+      lz::Seq fresh;
+      bool bad;
+      parse(ir, seqpos, lane >= before && lane < count, fresh, bad);
+      LZW_T(3);
+      if (lane >= before) {
+        s = fresh;
+      }
+      if (ABLATE == 2) {
+        op += wave::reduce_add(s.lit_len + s.match_len + s.match_off) & 1u;
+        count = 0;
+        continue;
+      }
+      if (wave::ballot(bad)) {
+        err |= lz::kErrInput;
+        return 0;
+      }
     }
     bool big;
     uint32_t take = lzg::execute_batch<CHECKED>(ir, ow, out_cap, op, count, s, err, big);
@@ -332,8 +347,15 @@ __device__ __forceinline__ uint32_t decode_chunk(
       lzg::restart_window(ow, op);
       take = 1;
     }
-    /* drop the executed sequences, keep the rest for the next round */
-    seqpos = wave::shuffle(seqpos, (lane + take) & 63u);
+    /* drop the executed sequences, keep the rest (parsed) for the next round */
+    if (take < count) {
+      const uint32_t from = (lane + take) & 63u;
+      seqpos = wave::shuffle(seqpos, from);
+      s.lit_src = wave::shuffle(s.lit_src, from);
+      s.lit_len = wave::shuffle(s.lit_len, from);
+      s.match_off = wave::shuffle(s.match_off, from);
+      s.match_len = wave::shuffle(s.match_len, from);
+    }
     count -= take;
   }
   lzw::out_flush_all(ow, op);

@@ -322,23 +322,37 @@ __device__ __forceinline__ uint32_t decode_chunk(
   uint32_t op = 0;
   uint32_t seqpos = 0;
   uint32_t count = 0;
+  /* parsed elements stay in registers until they are executed; chase and parse run only when few are left
+   * (lz4_decode_window.hip.h: decode_chunk) */
+  constexpr uint32_t kRefillBelow = 24;
+  lz::Seq s;
+  s.lit_src = 0;
+  s.lit_len = 0;
+  s.match_off = 0;
+  s.match_len = 0;
   for (;;) {
     if (count == 0 && c.q >= ir.vend) {
       break;
     }
-    const uint32_t oldest = count ? wave::read_lane(seqpos, 0) : c.q;
-    lzw::in_ensure(ir, oldest, (c.q & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
+    if (count < kRefillBelow && c.q < ir.vend) {
+      const uint32_t oldest = count ? wave::read_lane(seqpos, 0) : c.q;
+      lzw::in_ensure(ir, oldest, (c.q & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
+      const uint32_t before = count;
 #if NVCOMP_LZW_PCHASE
-    count = lzw::chase_tokens(c, ir, seqpos, count, DeltaFn(), SlowFn());
+      count = lzw::chase_tokens(c, ir, seqpos, count, DeltaFn(), SlowFn());
 #else
-    count = chase(c, ir, seqpos, count);
+      count = chase(c, ir, seqpos, count);
 #endif
-    lz::Seq s;
-    bool bad;
-    parse(ir, seqpos, lane < count, s, bad);
-    if (wave::ballot(bad)) {
-      err |= lz::kErrInput;
-      return 0;
+      lz::Seq fresh;
+      bool bad;
+      parse(ir, seqpos, lane >= before && lane < count, fresh, bad);
+      if (lane >= before) {
+        s = fresh;
+      }
+      if (wave::ballot(bad)) {
+        err |= lz::kErrInput;
+        return 0;
+      }
     }
     /* A copy that continues the copy before it (same offset, nothing in between) is the same match going on: the
      * compressor cuts matches into 64-byte elements, so runs and periodic columns arrive as long trains of them.
@@ -390,7 +404,14 @@ __device__ __forceinline__ uint32_t decode_chunk(
       lzg::restart_window(ow, op);
       take = 1 + wave::ctz64(~(train >> 1)); /* sequence 0 and the empty sequences of its train */
     }
-    seqpos = wave::shuffle(seqpos, (lane + take) & 63u);
+    if (take < count) {
+      const uint32_t from = (lane + take) & 63u;
+      seqpos = wave::shuffle(seqpos, from);
+      s.lit_src = wave::shuffle(s.lit_src, from);
+      s.lit_len = wave::shuffle(s.lit_len, from);
+      s.match_off = wave::shuffle(s.match_off, from);
+      s.match_len = wave::shuffle(s.match_len, from);
+    }
     count -= take;
   }
   if (CHECKED && (op != total || c.q != ir.vend)) {

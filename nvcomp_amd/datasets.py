@@ -173,6 +173,19 @@ def example_float_columns(size: int, seed: int = 0) -> np.ndarray:
     return np.tile(unit, size // unit.size + 1)[:size].copy()
 
 
+def mortgage_col0_like(size: int, seed: int = 0) -> np.ndarray:
+    """The shape of the one dataset the reference publishes LZ4 numbers for (doc/Benchmarks.md:88-95: Mortgage 2009Q2,
+    column 0 as int64, 329 055 928 bytes, LZ4 ratio 38.89): a sorted key column of a fact table -- 12-digit loan ids,
+    each repeated once per monthly record (a few dozen rows), ids growing by irregular gaps. liblz4 compresses it
+    39x: one 8-byte-period match per run of equal ids."""
+    rng = np.random.RandomState(seed + 909)
+    n = size // 8 + 1
+    runs = rng.randint(16, 86, size=n // 16 + 2)  # rows per loan
+    ids = 100000000000 + np.cumsum(rng.randint(1, 5000, size=runs.size).astype(np.int64))
+    col = np.repeat(ids, runs)[:n]
+    return col.view(np.uint8)[:size].copy()
+
+
 def int32_column(size: int, seed: int = 0) -> np.ndarray:
     """Sorted keys with runs (low-cardinality dimension column), int32."""
     rng = np.random.RandomState(seed + 505)
@@ -183,6 +196,7 @@ def int32_column(size: int, seed: int = 0) -> np.ndarray:
 
 CLASSES: Dict[str, Callable[[int, int], np.ndarray]] = {
     "example_float_columns": example_float_columns,
+    "mortgage_col0_like": mortgage_col0_like,
     "text": text,
     "table": table_rows,
     "float_csv": float_csv,
