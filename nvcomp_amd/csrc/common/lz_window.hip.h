@@ -73,6 +73,10 @@ constexpr uint32_t kInLds = kInRing + 16; /* first 16 bytes mirrored after the e
 #ifndef NVCOMP_LZW_PCHASE
 #define NVCOMP_LZW_PCHASE 1 /* 1: jump-table token chase (below); 0: the serial v_readlane walk */
 #endif
+#ifndef NVCOMP_LZW_CHASE_ENOUGH
+#define NVCOMP_LZW_CHASE_ENOUGH 64 /* tokens in hand from which the chase does not open another window (A/B: 40, 48) */
+#endif
+constexpr uint32_t kChaseEnough = NVCOMP_LZW_CHASE_ENOUGH;
 constexpr uint32_t kChaseWin = 256;                 /* stream positions one chase window covers */
 constexpr uint32_t kChaseLevels = 6;                /* jump tables for 1, 2, 4, 8, 16, 32 tokens ahead */
 constexpr uint32_t kChaseLds = NVCOMP_LZW_PCHASE ? kChaseLevels * kChaseWin : 0;
@@ -283,26 +287,24 @@ __device__ __forceinline__ void chase_build(Chase& c, const InRing& r, Delta del
     }
   }
   uint32_t a[4];
-  uint32_t packed = 0;
 #pragma unroll
   for (uint32_t k = 0; k < 4; ++k) {
     a[k] = 4 * lane + k + c.nx[k] < limit ? c.nx[k] : 255u; /* the successor must be a token inside the window */
-    packed |= a[k] << (8 * k);
   }
-  *(uint32_t*)(c.tab + 4 * lane) = packed;
+  /* the four distances of a lane travel as two dwords of two 16-bit lanes (positions 0|1 and 2|3): a doubling round
+   * is two packed adds + two packed saturations instead of four of each, and one byte permute packs the table word */
+  uint32_t a01 = a[0] | (a[1] << 16), a23 = a[2] | (a[3] << 16);
+  *(uint32_t*)(c.tab + 4 * lane) = wave::perm_bytes(a23, a01, 0x06040200u);
   wave::sync();
 #pragma unroll
   for (uint32_t i = 1; i < kChaseLevels; ++i) {
     const uint8_t* prev = c.tab + (i - 1) * kChaseWin + 4 * lane;
-    packed = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 4; ++k) {
-      /* a == 255 reads past its table (into the next one, still inside kChaseLds): the sum saturates anyway */
-      const uint32_t sum = a[k] + prev[k + a[k]];
-      a[k] = sum < 255u ? sum : 255u; /* valid sums are <= 254: position + sum < 256 */
-      packed |= a[k] << (8 * k);
-    }
-    *(uint32_t*)(c.tab + i * kChaseWin + 4 * lane) = packed;
+    /* a == 255 reads past its table (into the next one, still inside kChaseLds): the sum saturates anyway */
+    const uint32_t g0 = prev[0 + (a01 & 0xffffu)], g1 = prev[1 + (a01 >> 16)];
+    const uint32_t g2 = prev[2 + (a23 & 0xffffu)], g3 = prev[3 + (a23 >> 16)];
+    a01 = wave::pk_add_sat255(a01, g0 | (g1 << 16)); /* valid sums are <= 254: position + sum < 256 */
+    a23 = wave::pk_add_sat255(a23, g2 | (g3 << 16));
+    *(uint32_t*)(c.tab + i * kChaseWin + 4 * lane) = wave::perm_bytes(a23, a01, 0x06040200u);
     wave::sync();
   }
 }
@@ -316,6 +318,9 @@ __device__ __forceinline__ uint32_t chase_tokens(
   const uint32_t lane = (uint32_t)wave::lane_id();
   while (k < 64 && c.q < r.vend) {
     if (c.q - c.wb >= kChaseWin) {
+      if (k >= kChaseEnough) {
+        break; /* a batch of what one window held is cheaper than a second build + enumeration for a few more tokens */
+      }
       chase_build(c, r, delta);
       LZW_T(1);
     }

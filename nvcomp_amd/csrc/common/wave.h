@@ -232,6 +232,22 @@ __device__ __forceinline__ uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32
   return __builtin_amdgcn_alignbyte(hi, lo, shift);
 }
 
+/* Two 16-bit lanes per dword: min(a + b, 255) in each (v_pk_add_u16 + v_pk_min_u16). */
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add_sat255(uint32_t a, uint32_t b)
+{
+  u16x2 x = __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b);
+  const u16x2 cap = {255, 255};
+  x = __builtin_elementwise_min(x, cap);
+  return __builtin_bit_cast(uint32_t, x);
+}
+
+/* Byte permute (v_perm_b32): result byte i = byte sel[i] of the 8-byte value hi:lo (0-3 = lo, 4-7 = hi). */
+__device__ __forceinline__ uint32_t perm_bytes(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+  return __builtin_amdgcn_perm(hi, lo, sel);
+}
+
 /* Number of set bits of m below the calling lane (v_mbcnt_lo/hi). */
 __device__ __forceinline__ uint32_t prefix_popc(uint64_t m)
 {

@@ -163,15 +163,18 @@ struct DeltaFn
   /* interior window: `w` = the stream bytes from p on (token in bits 0-7, the byte behind it in 8-15) */
   __device__ __forceinline__ uint32_t fast(const lzw::InRing& r, uint32_t p, uint64_t w) const
   {
+    /* straight-line on purpose (no ||, no early exit): the byte a match-length extension would use is read whatever
+     * the token says, so that the four positions of a lane compile to one instruction stream without exec-mask
+     * juggling -- the scalar unit is as busy as the vector unit in this kernel */
     const uint32_t t = (uint32_t)w & 0xffu;
     const uint32_t e1 = (uint32_t)(w >> 8) & 0xffu;
     const uint32_t lit_code = t >> 4;
-    const bool lit_ext = lit_code == 15;
+    const uint32_t lit_ext = lit_code == 15 ? 1u : 0u;
     const uint32_t d0 = 3 + lit_code + (lit_ext ? e1 + 1u : 0u); /* to the byte a match-length extension would use */
-    const bool m_ext = (t & 15u) == 15u;
+    const uint32_t m_ext = (t & 15u) == 15u ? 1u : 0u;
     const uint32_t e2 = r.ring[(p + d0) & (lzw::kInRing - 1)];
-    const bool unknown = (lit_ext && e1 == 255) || (m_ext && e2 == 255);
-    return unknown ? kUnknown : d0 + (m_ext ? 1u : 0u);
+    const uint32_t unknown = (lit_ext & (e1 == 255 ? 1u : 0u)) | (m_ext & (e2 == 255 ? 1u : 0u));
+    return unknown ? kUnknown : d0 + m_ext;
   }
 };
 struct SlowFn
@@ -241,6 +244,65 @@ __device__ __forceinline__ void parse(const lzw::InRing& r, uint32_t p, bool act
   s.match_len = mlen + 4;
 }
 
+/* The n (< 8) stream bytes at virtual position p, which must be resident with p + 7 below the ring's end of residency:
+ * two or three aligned dword reads (a misaligned ds_read_b32 is served lane by lane) and a funnel shift. */
+__device__ __forceinline__ uint64_t ring_bytes8(const lzw::InRing& r, uint32_t p)
+{
+  const uint32_t m = lzw::kInRing - 1;
+  const uint32_t a0 = p & ~3u;
+  const uint32_t d0 = *(const uint32_t*)(r.ring + (a0 & m));
+  const uint32_t d1 = *(const uint32_t*)(r.ring + ((a0 + 4) & m));
+  const uint32_t d2 = *(const uint32_t*)(r.ring + ((a0 + 8) & m));
+  const uint32_t lo = wave::align_bytes(d1, d0, p & 3u);
+  const uint32_t hi = wave::align_bytes(d2, d1, p & 3u);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t ring_bytes4(const lzw::InRing& r, uint32_t p)
+{
+  const uint32_t m = lzw::kInRing - 1;
+  const uint32_t a0 = p & ~3u;
+  const uint32_t d0 = *(const uint32_t*)(r.ring + (a0 & m));
+  const uint32_t d1 = *(const uint32_t*)(r.ring + ((a0 + 4) & m));
+  return wave::align_bytes(d1, d0, p & 3u);
+}
+
+/* parse() for the common batch: every lane's token, first length bytes and offset are resident, no length field is
+ * longer than one extension byte. Straight-line, two dependent LDS round trips, no exec-mask changes; returns false
+ * (wave-uniform) when some lane needs the general parser, which then redoes the whole batch. Same fields, same
+ * validation. */
+__device__ __forceinline__ bool parse_fast(const lzw::InRing& r, uint32_t p, bool active, lz::Seq& s, bool& bad)
+{
+  const uint32_t vend = r.vend;
+  /* the token + 7 bytes and, behind the literals, offset + one length byte must sit in the ring */
+  const bool head_in = p >= r.lo && p + 12 <= r.hi;
+  const uint64_t w = ring_bytes8(r, active && head_in ? p : r.lo);
+  const uint32_t t = (uint32_t)w & 0xffu;
+  const uint32_t e1 = (uint32_t)(w >> 8) & 0xffu;
+  const uint32_t code = t >> 4;
+  const bool lit_ext = code == 15;
+  const uint32_t lit = code + (lit_ext ? e1 : 0u);
+  const uint32_t lit_src = p + 1 + (lit_ext ? 1u : 0u);
+  const uint32_t q = lit_src + lit; /* offset position, or the end of the chunk for the last sequence */
+  const bool last = q == vend;
+  const bool tail_in = q + 12 <= r.hi; /* lit <= 270: q - p is small, p >= lo holds */
+  const uint32_t x = ring_bytes4(r, active && head_in && tail_in && !last ? q : r.lo);
+  const uint32_t mcode = t & 15u;
+  const bool m_ext = mcode == 15;
+  const uint32_t me = (x >> 16) & 0xffu;
+  const bool general = active && (!head_in || (lit_ext && e1 == 255) || (!last && (!tail_in || (m_ext && me == 255))) || q > vend
+                                  || (!last && vend - q < 2));
+  if (wave::ballot(general)) {
+    return false;
+  }
+  const uint32_t next = q + 2 + (m_ext ? 1u : 0u); /* a token must follow every match */
+  s.lit_src = active ? lit_src : 0;
+  s.lit_len = active ? lit : 0;
+  s.match_off = active && !last ? (x & 0xffffu) : 0;
+  s.match_len = active && !last ? mcode + 4 + (m_ext ? me : 0u) : 0;
+  bad = active && !last && next >= vend;
+  return true;
+}
+
 /* Decode one chunk with the calling wave; `lds` is this wave's kLdsPerWave bytes. */
 /* ABLATE (profiling builds only, results are wrong by construction): 1 = stop after the
  * token chase, 2 = after the parse, 0 = the real decoder. */
@@ -303,7 +365,9 @@ __device__ __forceinline__ uint32_t decode_chunk(
       }
       lz::Seq fresh;
       bool bad;
-      parse(ir, seqpos, lane >= before && lane < count, fresh, bad);
+      if (!parse_fast(ir, seqpos, lane >= before && lane < count, fresh, bad)) {
+        parse(ir, seqpos, lane >= before && lane < count, fresh, bad);
+      }
       LZW_T(3);
       if (lane >= before) {
         s = fresh;

@@ -179,6 +179,26 @@ inline uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t shift)
 {
   return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (shift & 3u)));
 }
+inline uint32_t pk_add_sat255(uint32_t a, uint32_t b)
+{
+  uint32_t lo = (a & 0xffffu) + (b & 0xffffu), hi = (a >> 16) + (b >> 16);
+  lo &= 0xffffu;
+  hi &= 0xffffu;
+  lo = lo < 255u ? lo : 255u;
+  hi = hi < 255u ? hi : 255u;
+  return lo | (hi << 16);
+}
+inline uint32_t perm_bytes(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+  const uint64_t v = ((uint64_t)hi << 32) | lo;
+  uint32_t r = 0;
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t k = (sel >> (8 * i)) & 0xffu;
+    const uint32_t b = k < 8 ? (uint32_t)(v >> (8 * k)) & 0xffu : k == 12 ? 0u : 0xffu;
+    r |= b << (8 * i);
+  }
+  return r;
+}
 inline uint32_t prefix_popc(uint64_t m)
 {
   const uint32_t l = (uint32_t)lane_id();
