@@ -729,11 +729,12 @@ def main():
         import ctypes
         import nvcomp_amd
         lib = nvcomp_amd.load_library()
-        slots = (ctypes.c_ulonglong * 12)()
-        if hasattr(lib, "nvcompAmdProfRead") and lib.nvcompAmdProfRead(slots, 12) > 0:
+        slots = (ctypes.c_ulonglong * 16)()
+        if hasattr(lib, "nvcompAmdProfRead") and lib.nvcompAmdProfRead(slots, 16) > 0:
             tot = float(sum(slots)) or 1.0
-            names = ["in_ensure", "chase_build", "chase_enum", "parse", "exec_prep", "make_room", "far_issue+literals",
-                     "far_store", "match_rounds", "flush", "loop_top", "-"]
+            names = ["in_ensure", "chase_build", "chase_enum", "parse", "exec_prep", "make_room", "literals_4_32",
+                     "far_store", "match_rounds", "flush", "loop_top", "far_issue", "literals_1_3", "literals_long",
+                     "matches_whole_wave", "-"]
             print(json.dumps({"phase_share": {n: round(v / tot, 4) for n, v in zip(names, slots)},
                               "cycles_total": tot}), file=sys.stderr, flush=True)
     ctx["rt"].shutdown()

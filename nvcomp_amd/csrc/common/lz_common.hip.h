@@ -210,6 +210,11 @@ struct Seq
   uint32_t lit_len;
   uint32_t match_off; /* distance back from the match destination */
   uint32_t match_len; /* 0: no match (LZ4 last sequence / Snappy literal element) */
+  /* Optional: the first literal bytes as the parser saw them, so that a short run is written without reading the
+   * stream again. lit_lo = bytes 0-3, lit_hi bits 0-15 = bytes 4-5, lit_hi bits 16-18 = how many bytes are held
+   * (0 = none; the run is then read from the stream). Only a run held completely is used. */
+  uint32_t lit_lo = 0;
+  uint32_t lit_hi = 0;
 };
 
 /*

@@ -73,6 +73,12 @@ constexpr uint32_t kInLds = kInRing + 16; /* first 16 bytes mirrored after the e
 #ifndef NVCOMP_LZW_PCHASE
 #define NVCOMP_LZW_PCHASE 1 /* 1: jump-table token chase (below); 0: the serial v_readlane walk */
 #endif
+/* A/B build: short literal runs written from the registers the parser read them into (lz::Seq::lit_lo / lit_hi) instead
+ * of being read from the stream ring again. Measured on MI355X: the two more live registers per lane cost more in
+ * spills at the 72-VGPR budget of 7 waves/SIMD than the saved LDS round trip returns (449 vs 502 GB/s). Off. */
+#ifndef NVCOMP_LZW_LIT_REGS
+#define NVCOMP_LZW_LIT_REGS 0
+#endif
 #ifndef NVCOMP_LZW_CHASE_ENOUGH
 #define NVCOMP_LZW_CHASE_ENOUGH 64 /* tokens in hand from which the chase does not open another window (A/B: 40, 48) */
 #endif
@@ -92,7 +98,7 @@ constexpr uint32_t kMatchShort = 32; /* lane-parallel matches:      up to 8 dwor
 
 /* ---- phase clock (profiling builds only: -DNVCOMP_LZW_PROF) ------------------ */
 #ifdef NVCOMP_LZW_PROF
-constexpr uint32_t kProfSlots = 12;
+constexpr uint32_t kProfSlots = 16;
 __device__ unsigned long long g_prof[kProfSlots];
 __device__ __forceinline__ unsigned long long* prof_slots()
 {
@@ -742,8 +748,9 @@ __device__ __forceinline__ uint32_t execute_window_batch(
   const uint32_t match_src = match_dst - s.match_off;
   const bool is_near = my_match != 0 && match_src >= ow.valid_lo;
 #if NVCOMP_LZW_FAR_ALIGNED
+  /* the data comes with one or two 16-byte loads, which must stay inside the chunk's buffer */
   const bool far_lane = my_match >= 4 && !is_near && my_match <= kMatchShort && match_src + my_match <= ow.flushed
-                        && (uint64_t)match_src + my_match + 3 <= out_cap; /* the dword loads may run 3 bytes past the match */
+                        && (uint64_t)match_src + (my_match > 16 ? 32u : 16u) <= out_cap;
   uint32_t far_l4 = 0;
 #else
   const bool far_lane = my_match >= 4 && !is_near && my_match <= kMatchShort && match_src + my_match <= ow.flushed;
@@ -757,12 +764,17 @@ __device__ __forceinline__ uint32_t execute_window_batch(
     const uint8_t* src = ow.out + match_src;
 #endif
 #if NVCOMP_LZW_FAR_ALIGNED
-    if (far_steps == 2) {
-      far_load_seq<2>(far_data, far_l4, src, my_match);
-    } else if (far_steps == 4) {
-      far_load_seq<4>(far_data, far_l4, src, my_match);
-    } else {
-      far_load_seq<8>(far_data, far_l4, src, my_match);
+    /* A scattered load costs the CU's address unit a slot per lane whatever its width (profiles/r02_decode_phases.json:
+     * issuing 3-9 dword loads per batch was 11 % of the wave's time): 16 bytes per load, two loads at most, plus the
+     * match's last dword. */
+    {
+      const wave::u32x4 f0 = wave::gload_u32x4(src);
+      far_data[0] = f0.x, far_data[1] = f0.y, far_data[2] = f0.z, far_data[3] = f0.w;
+      if (my_match > 16) {
+        const wave::u32x4 f1 = wave::gload_u32x4(src + 16);
+        far_data[4] = f1.x, far_data[5] = f1.y, far_data[6] = f1.z, far_data[7] = f1.w;
+      }
+      far_l4 = wave::gload_u32(src + my_match - 4);
     }
 #else
     if (far_steps == 2) {
@@ -775,14 +787,34 @@ __device__ __forceinline__ uint32_t execute_window_batch(
 #endif
   }
 
+  LZW_T(11); /* far classification + load issue */
   /* ---- literals ---- */
   if (!(NVCOMP_LZW_ABLATE_EXEC & 4)) {
+    uint8_t* dst = out_at(ow, lit_dst);
+    /* a run the parser still holds in registers is written from there: no stream read, no dependent LDS round trip */
+    const bool lit_held = NVCOMP_LZW_LIT_REGS && my_lit != 0 && (s.lit_hi >> 16) == my_lit;
+    if (wave::ballot(lit_held)) {
+      if (lit_held) {
+        const uint64_t v = ((uint64_t)(s.lit_hi & 0xffffu) << 32) | s.lit_lo;
+        if (my_lit >= 4) {
+          lz::st_u32(dst, (uint32_t)v);
+          lz::st_u32(dst + my_lit - 4, (uint32_t)(v >> (8 * (my_lit - 4))));
+        } else {
+          dst[0] = (uint8_t)v;
+          if (my_lit > 1) {
+            dst[1] = (uint8_t)(v >> 8);
+          }
+          if (my_lit > 2) {
+            dst[2] = (uint8_t)(v >> 16);
+          }
+        }
+      }
+    }
     const bool resident = in_resident(ir, s.lit_src, s.lit_src + my_lit);
-    const bool lit_lane = my_lit >= 4 && my_lit <= kLitShort && resident;
-    const bool lit_tiny = my_lit != 0 && my_lit < 4 && resident;
+    const bool lit_lane = my_lit >= 4 && my_lit <= kLitShort && resident && !lit_held;
+    const bool lit_tiny = my_lit != 0 && my_lit < 4 && resident && !lit_held;
     /* the ring wraps at kInRing; its 16-byte mirror covers a dword that starts before the end,
      * and a run crossing the end is split by the modulo per step */
-    uint8_t* dst = out_at(ow, lit_dst);
     const uint32_t lit_steps = steps_for(lit_lane, my_lit);
     if (lit_lane) {
       const uint32_t last = my_lit - 4;
@@ -802,6 +834,7 @@ __device__ __forceinline__ uint32_t execute_window_batch(
         }
       }
     }
+    LZW_T(6); /* literal runs of 4..32 bytes */
     if (wave::ballot(lit_tiny)) {
       if (lit_tiny) {
         dst[0] = ir.ring[s.lit_src & (kInRing - 1)];
@@ -813,7 +846,8 @@ __device__ __forceinline__ uint32_t execute_window_batch(
         }
       }
     }
-    uint64_t pending = wave::ballot(my_lit != 0 && !lit_lane && !lit_tiny);
+    LZW_T(12); /* literal runs of 1..3 bytes */
+    uint64_t pending = wave::ballot(my_lit != 0 && !lit_lane && !lit_tiny && !lit_held);
     LZ_STAT("lit_lanes", wave::popc64(wave::ballot(lit_lane || lit_tiny)));
     LZ_STAT("lit_coop", wave::popc64(pending));
     while (pending) {
@@ -826,7 +860,7 @@ __device__ __forceinline__ uint32_t execute_window_batch(
     }
   }
 
-  LZW_T(6);
+  LZW_T(13); /* long literal runs, whole wave */
   /* ---- far match data into the window ---- */
 #if NVCOMP_LZW_FAR_ALIGNED
   if (wave::ballot(far_lane) && !(NVCOMP_LZW_ABLATE_EXEC & 16)) {
@@ -884,6 +918,7 @@ __device__ __forceinline__ uint32_t execute_window_batch(
           }
         }
         pending &= ~(1ull << f);
+        LZW_T(14); /* matches copied by the whole wave */
         continue;
       }
       const bool ready = near_lane && (pending & lane_bit) && (lane == f || match_src + my_match <= hw);

@@ -299,6 +299,12 @@ __device__ __forceinline__ bool parse_fast(const lzw::InRing& r, uint32_t p, boo
   s.lit_len = active ? lit : 0;
   s.match_off = active && !last ? (x & 0xffffu) : 0;
   s.match_len = active && !last ? mcode + 4 + (m_ext ? me : 0u) : 0;
+  /* a run of up to 6 literals sits in the 8 bytes just read (token, then the literals: no length byte below 15) */
+#if NVCOMP_LZW_LIT_REGS
+  const uint32_t held = active && lit <= 6 ? lit : 0u;
+  s.lit_lo = (uint32_t)(w >> 8);
+  s.lit_hi = ((uint32_t)(w >> 40) & 0xffffu) | (held << 16);
+#endif
   bad = active && !last && next >= vend;
   return true;
 }
@@ -419,6 +425,10 @@ __device__ __forceinline__ uint32_t decode_chunk(
       s.lit_len = wave::shuffle(s.lit_len, from);
       s.match_off = wave::shuffle(s.match_off, from);
       s.match_len = wave::shuffle(s.match_len, from);
+#if NVCOMP_LZW_LIT_REGS
+      s.lit_lo = wave::shuffle(s.lit_lo, from);
+      s.lit_hi = wave::shuffle(s.lit_hi, from);
+#endif
     }
     count -= take;
   }
