@@ -271,6 +271,61 @@ __device__ __forceinline__ void parse(const lzw::InRing& r, uint32_t p, bool act
   }
 }
 
+/* The 8 stream bytes at virtual position p (resident, p + 11 below the end of residency): aligned dword reads and a
+ * funnel shift (a misaligned ds_read_b32 is served lane by lane). */
+__device__ __forceinline__ uint64_t ring_bytes8(const lzw::InRing& r, uint32_t p)
+{
+  const uint32_t m = lzw::kInRing - 1;
+  const uint32_t a0 = p & ~3u;
+  const uint32_t d0 = *(const uint32_t*)(r.ring + (a0 & m));
+  const uint32_t d1 = *(const uint32_t*)(r.ring + ((a0 + 4) & m));
+  const uint32_t d2 = *(const uint32_t*)(r.ring + ((a0 + 8) & m));
+  const uint32_t lo = wave::align_bytes(d1, d0, p & 3u);
+  const uint32_t hi = wave::align_bytes(d2, d1, p & 3u);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+/* parse() for the common batch: literal elements of at most 60 bytes (no length bytes), everything a lane looks at
+ * resident. Straight-line, two dependent LDS round trips; returns false (wave-uniform) when some lane needs the general
+ * parser, which then redoes the whole batch. Same fields, same validation, same fusing rule. */
+__device__ __forceinline__ bool parse_fast(const lzw::InRing& r, uint32_t p, bool active, lz::Seq& s, bool& bad)
+{
+  const uint32_t vend = r.vend;
+  const bool head_in = p >= r.lo && p + 12 <= r.hi;
+  const uint64_t w = ring_bytes8(r, active && head_in ? p : r.lo);
+  const uint32_t t = (uint32_t)w & 0xffu;
+  const uint32_t kind = t & 3u;
+  const bool is_lit = kind == 0;
+  const uint32_t code = t >> 2;
+  const uint32_t q = p + 2 + code; /* a literal element without length bytes ends here */
+  const bool lit_ok = code < 60 && q <= vend;
+  /* the copy element: the token itself, or the tag behind a fusable literal (kFuseMax >= 62: always fusable here) */
+  const bool look = is_lit && q < vend;
+  const bool tail_in = q + 12 <= r.hi;
+  const uint64_t y = ring_bytes8(r, active && head_in && look && tail_in && lit_ok ? q : r.lo);
+  const uint64_t c = is_lit ? y : w;
+  const uint32_t cp = is_lit ? q : p;
+  const uint32_t tag = (uint32_t)c & 0xffu;
+  const uint32_t k = tag & 3u;
+  const bool has_copy = !is_lit || (look && k != 0);
+  const uint32_t need = k == 3 ? 4u : k;
+  const bool general = active && (!head_in || (is_lit && (!lit_ok || (look && !tail_in))) || (has_copy && vend - (cp + 1) < need));
+  if (wave::ballot(general)) {
+    return false;
+  }
+  const uint32_t b1 = (uint32_t)(c >> 8) & 0xffu;
+  const uint32_t b12 = (uint32_t)(c >> 8) & 0xffffu;
+  const uint32_t b1234 = (uint32_t)(c >> 8);
+  const uint32_t off = k == 1 ? (((tag >> 5) << 8) | b1) : k == 2 ? b12 : b1234;
+  const uint32_t mlen = k == 1 ? 4 + ((tag >> 2) & 7u) : 1 + (tag >> 2);
+  s.lit_src = active && is_lit ? p + 1 : 0;
+  s.lit_len = active && is_lit ? code + 1 : 0;
+  s.match_off = active && has_copy ? off : 0;
+  s.match_len = active && has_copy ? mlen : 0;
+  bad = active && has_copy && off == 0;
+  return true;
+}
+
 template <bool CHECKED>
 __device__ __forceinline__ uint32_t decode_chunk(
     const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_cap, uint8_t* lds, uint32_t& err)
@@ -345,7 +400,9 @@ __device__ __forceinline__ uint32_t decode_chunk(
 #endif
       lz::Seq fresh;
       bool bad;
-      parse(ir, seqpos, lane >= before && lane < count, fresh, bad);
+      if (!parse_fast(ir, seqpos, lane >= before && lane < count, fresh, bad)) {
+        parse(ir, seqpos, lane >= before && lane < count, fresh, bad);
+      }
       if (lane >= before) {
         s = fresh;
       }
