@@ -385,7 +385,7 @@ def run_case(args, ctx):
             try:
                 rec = json.load(open(tpath))
                 if rec.get("algo") == args.algo and rec.get("chunks_per_gpu") == n and rec.get("dataset") == args.dataset:
-                    if rec.get("lib_source_digest") == library_source_digest():
+                    if rec.get("lib_source_digest") == library_source_digest(args.algo):
                         traffic = rec.get("hbm_bytes_per_launch")
                         traffic_source = f"{os.path.relpath(tpath, REPO)} (replayed PMC counters of this library build)"
                     else:
@@ -480,16 +480,19 @@ def run_case(args, ctx):
     return finish(result, args, world, rt, data)
 
 
-def library_source_digest():
-    """sha256 over the kernel sources the shared library is built from: PMC traffic recorded for one build must not be
-    replayed beside the timing of another (VERDICT r1 weak #10)."""
+def library_source_digest(algo="lz4"):
+    """sha256 over the kernel sources of one codec: PMC traffic recorded for one build of a kernel must not be replayed
+    beside the timing of another. LZ4 / Snappy: their own directories + common/ (the shared
+    decoder); the own formats: their own directory."""
     import glob
     import hashlib
 
+    dirs = ["lz4", "snappy", "common"] if algo in ("lz4", "snappy") else [algo]
     h = hashlib.sha256()
-    for path in sorted(glob.glob(os.path.join(REPO, "nvcomp_amd", "csrc", "**", "*.h*"), recursive=True)):
-        h.update(os.path.relpath(path, REPO).encode())
-        h.update(open(path, "rb").read())
+    for d in dirs:
+        for path in sorted(glob.glob(os.path.join(REPO, "nvcomp_amd", "csrc", d, "*.h*"))):
+            h.update(os.path.relpath(path, REPO).encode())
+            h.update(open(path, "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -29,6 +29,10 @@ constexpr unsigned kWavesPerBlock = 4; /* 256-thread workgroups, one chunk per w
 #define NVCOMP_LZ_DEC_WAVES_PER_BLOCK 4
 #endif
 constexpr unsigned kDecWaves = NVCOMP_LZ_DEC_WAVES_PER_BLOCK;
+#ifndef NVCOMP_LZM_WAVES_PER_BLOCK
+#define NVCOMP_LZM_WAVES_PER_BLOCK 4
+#endif
+constexpr unsigned kEncWaves = NVCOMP_LZM_WAVES_PER_BLOCK; /* the compressors' workgroup size, same reasoning */
 constexpr uint32_t kMaxOutCap = 1u << 26;
 
 /* A/B and ablation kernels exist in measurement builds only (scripts/build_variants.sh passes
@@ -201,7 +205,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lz4_decompress_size_kerne
 /* STRIDE: the element size the caller declared (nvcompBatchedLZ4Opts_t.data_type): matches are searched at element
  * boundaries only, a step covers 64 elements (common/lz_match.hip.h). */
 template <uint32_t STRIDE>
-__global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZM_WAVES_PER_SIMD) lz4_compress_kernel(
+__global__ void __launch_bounds__(64 * kEncWaves, NVCOMP_LZM_WAVES_PER_SIMD) lz4_compress_kernel(
     const void* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
     size_t max_chunk_bytes,
@@ -209,9 +213,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZM_WAVES_PER_SIMD
     void* const* __restrict__ out_ptrs,
     size_t* out_bytes)
 {
-  __shared__ uint16_t tables[kWavesPerBlock][lzm::kTableU16];
+  __shared__ uint16_t tables[kEncWaves][lzm::kTableU16];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
-  const size_t chunk = (size_t)blockIdx.x * kWavesPerBlock + w;
+  const size_t chunk = (size_t)blockIdx.x * kEncWaves + w;
   if (chunk >= batch_size) {
     return;
   }
@@ -436,7 +440,7 @@ nvcompStatus_t nvcompBatchedLZ4CompressAsync(
   }
   clear_stale_error();
 #define NVCOMP_LZ4_COMPRESS(STRIDE)                                                                                  \
-  hipLaunchKernelGGL((lz4_compress_kernel<STRIDE>), dim3(grid_for(batch_size)), dim3(64 * kWavesPerBlock), 0, stream,   \
+  hipLaunchKernelGGL((lz4_compress_kernel<STRIDE>), dim3((unsigned)((batch_size + kEncWaves - 1) / kEncWaves)), dim3(64 * kEncWaves), 0, stream,   \
                      device_uncompressed_ptrs, device_uncompressed_bytes, max_uncompressed_chunk_bytes, batch_size,     \
                      device_compressed_ptrs, device_compressed_bytes)
   switch (format_opts.data_type) {

@@ -24,6 +24,10 @@ constexpr unsigned kWavesPerBlock = 4; /* 256-thread workgroups, one chunk per w
 #define NVCOMP_LZ_DEC_WAVES_PER_BLOCK 4
 #endif
 constexpr unsigned kDecWaves = NVCOMP_LZ_DEC_WAVES_PER_BLOCK;
+#ifndef NVCOMP_LZM_WAVES_PER_BLOCK
+#define NVCOMP_LZM_WAVES_PER_BLOCK 4
+#endif
+constexpr unsigned kEncWaves = NVCOMP_LZM_WAVES_PER_BLOCK; /* the compressors' workgroup size, same reasoning */
 constexpr uint32_t kMaxOutCap = 1u << 26;
 
 /* A/B kernels exist in measurement builds only (scripts/build_variants.sh passes -DNVCOMP_AMD_SNAPPY_VARIANT=1 direct:
@@ -137,7 +141,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) snappy_decompress_size_ke
   }
 }
 
-__global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZM_WAVES_PER_SIMD) snappy_compress_kernel(
+__global__ void __launch_bounds__(64 * kEncWaves, NVCOMP_LZM_WAVES_PER_SIMD) snappy_compress_kernel(
     const void* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
     size_t max_chunk_bytes,
@@ -145,9 +149,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, NVCOMP_LZM_WAVES_PER_SIMD
     void* const* __restrict__ out_ptrs,
     size_t* out_bytes)
 {
-  __shared__ uint16_t tables[kWavesPerBlock][lzm::kTableU16];
+  __shared__ uint16_t tables[kEncWaves][lzm::kTableU16];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
-  const size_t chunk = (size_t)blockIdx.x * kWavesPerBlock + w;
+  const size_t chunk = (size_t)blockIdx.x * kEncWaves + w;
   if (chunk >= batch_size) {
     return;
   }
@@ -349,7 +353,7 @@ nvcompStatus_t nvcompBatchedSnappyCompressAsync(
     return nvcompErrorInvalidValue;
   }
   clear_stale_error();
-  hipLaunchKernelGGL(snappy_compress_kernel, dim3(grid_for(batch_size)), dim3(64 * kWavesPerBlock), 0, stream,
+  hipLaunchKernelGGL(snappy_compress_kernel, dim3((unsigned)((batch_size + kEncWaves - 1) / kEncWaves)), dim3(64 * kEncWaves), 0, stream,
                      device_uncompressed_ptrs, device_uncompressed_bytes, max_uncompressed_chunk_bytes, batch_size,
                      device_compressed_ptrs, device_compressed_bytes);
   return launch_status();
