@@ -337,11 +337,15 @@ __device__ __forceinline__ uint32_t decode_chunk(
   uint32_t op = 0;
   uint32_t seqpos = 0;
   uint32_t count = 0; /* sequences recorded in seqpos lanes [0, count) and not yet executed */
-  /* Parsed sequences stay in registers until they are executed. A batch ends at 1 KiB of output, so on data with long
-   * matches (runs, sorted key columns: 200-400 bytes per sequence) a round executes only a handful of the 64 sequences
-   * a chase delivers: re-chasing and re-parsing the rest every round was 5 000 cycles per SEQUENCE on the reference's
-   * own published shape (profiles/r02_mortgage_like.json). Now the chase and the parse run only when fewer than
-   * kRefillBelow sequences are left; on text a round takes all 64 and every round refills, as before. */
+  /* A batch ends at 1 KiB of output, so on data with long matches (runs, sorted key columns: 200-400 bytes per
+   * sequence) a round executes only a handful of the 64 sequences a chase delivers: chasing again for the rest every
+   * round was 5 000 cycles per SEQUENCE on the reference's own published shape (profiles/r02_mortgage_like.json).
+   * The chase runs only when fewer than kRefillBelow token positions are left; on text a round takes all 64 and
+   * every round refills, as before. NVCOMP_LZ4W_KEEP_PARSED = 1 also keeps the parsed FIELDS in registers across
+   * rounds (four more live registers); 0 parses the positions in hand again every round (two LDS round trips). */
+#ifndef NVCOMP_LZ4W_KEEP_PARSED
+#define NVCOMP_LZ4W_KEEP_PARSED 1 /* measured: headline 498 vs 500 GB/s (noise), mortgage-like column 545 vs 442 */
+#endif
   constexpr uint32_t kRefillBelow = 24;
   lz::Seq s;
   s.lit_src = 0;
@@ -352,13 +356,14 @@ __device__ __forceinline__ uint32_t decode_chunk(
     if (count == 0 && c.q >= ir.vend) {
       break;
     }
-    if (count < kRefillBelow && c.q < ir.vend) {
+    uint32_t before = NVCOMP_LZ4W_KEEP_PARSED ? count : 0u; /* lanes [before, count) are parsed this round */
+    const bool refill = count < kRefillBelow && c.q < ir.vend;
+    if (refill) {
       /* keep the stream resident from the oldest unexecuted token to well past the chase */
       const uint32_t oldest = count ? wave::read_lane(seqpos, 0) : c.q;
       LZW_T(10);
       lzw::in_ensure(ir, oldest, (c.q & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
       LZW_T(0);
-      const uint32_t before = count;
 #if NVCOMP_LZW_PCHASE
       count = lzw::chase_tokens(c, ir, seqpos, count, DeltaFn(), SlowFn());
 #else
@@ -369,6 +374,8 @@ __device__ __forceinline__ uint32_t decode_chunk(
         count = 0;
         continue;
       }
+    }
+    if (refill || !NVCOMP_LZ4W_KEEP_PARSED) {
       lz::Seq fresh;
       bool bad;
       if (!parse_fast(ir, seqpos, lane >= before && lane < count, fresh, bad)) {
@@ -417,10 +424,11 @@ __device__ __forceinline__ uint32_t decode_chunk(
       lzg::restart_window(ow, op);
       take = 1;
     }
-    /* drop the executed sequences, keep the rest (parsed) for the next round */
+    /* drop the executed sequences, keep the rest for the next round */
     if (take < count) {
       const uint32_t from = (lane + take) & 63u;
       seqpos = wave::shuffle(seqpos, from);
+#if NVCOMP_LZ4W_KEEP_PARSED
       s.lit_src = wave::shuffle(s.lit_src, from);
       s.lit_len = wave::shuffle(s.lit_len, from);
       s.match_off = wave::shuffle(s.match_off, from);
@@ -428,6 +436,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
 #if NVCOMP_LZW_LIT_REGS
       s.lit_lo = wave::shuffle(s.lit_lo, from);
       s.lit_hi = wave::shuffle(s.lit_hi, from);
+#endif
 #endif
     }
     count -= take;
