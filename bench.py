@@ -65,6 +65,8 @@ def parse_args():
     p.add_argument("--lz-index-min-batch", type=int, default=None,
                    help="include/nvcomp/amd_ext.h: smallest batch that takes the two-kernel (token index) LZ decode path; "
                         "0 = always, a huge value = never (the single-kernel chase decoder)")
+    p.add_argument("--lz-pair-max-batch", type=int, default=None,
+                   help="include/nvcomp/amd_ext.h: largest batch the LZ4 decoder runs with two waves per chunk; 0 = never")
     p.add_argument("--dry-run-emu", action="store_true",
                    help="CPU-only self-test of this script's plumbing against tests/emu (prints value=null)")
     return p.parse_args()
@@ -255,6 +257,8 @@ def run_case(args, ctx):
     codec = nvcomp_amd.BatchedCodec(lib, dev, fmt, opts)
     if args.lz_index_min_batch is not None:
         lib.nvcompAmdSetLZIndexMinBatch(args.lz_index_min_batch)
+    if args.lz_pair_max_batch is not None:
+        lib.nvcompAmdSetLZPairMaxBatch(args.lz_pair_max_batch)
     threads = len(os.sched_getaffinity(0))
 
     # ---- build the batch (untimed) ----

@@ -27,6 +27,13 @@ extern "C" {
 #define NVCOMP_AMD_LZ_INDEX_MIN_BATCH_DEFAULT ((size_t)-1)
 size_t nvcompAmdSetLZIndexMinBatch(size_t min_batch);
 
+/* nvcompBatchedLZ4DecompressAsync decodes a batch of at most this many chunks with TWO waves per chunk -- one chases and
+ * parses the tokens, the other executes the sequences, a queue in LDS between them -- because one wave per chunk cannot
+ * fill the card below ~7 000 chunks and a chunk's latency is its wave's own dependent chain. Larger batches use one wave
+ * per chunk (more chunks in flight per CU). 0 = never. Returns the previous value; process-wide. */
+#define NVCOMP_AMD_LZ_PAIR_MAX_BATCH_DEFAULT 3072
+size_t nvcompAmdSetLZPairMaxBatch(size_t max_batch);
+
 /* Pack the chunks of a batch (e.g. what nvcompBatched<Fmt>CompressAsync left in its worst-case-sized slots) into one
  * contiguous buffer, in batch order and without gaps: device_offsets[i] = sum of device_chunk_bytes[0..i),
  * device_offsets[batch_size] = the packed size; chunk i is copied to device_packed + device_offsets[i]. Everything

@@ -108,6 +108,9 @@ def declare(lib: C.CDLL, formats=FORMATS) -> C.CDLL:
             getattr(lib, pre + "DecompressGetTempSizeEx").argtypes = [sz, sz, szp, sz]
     if hasattr(lib, "nvcompAmdBatchedPackAsync"):  # include/nvcomp/amd_ext.h
         lib.nvcompAmdBatchedPackAsync.argtypes = [vp, vp, sz, vp, sz, vp, vp]
+    if hasattr(lib, "nvcompAmdSetLZPairMaxBatch"):  # include/nvcomp/amd_ext.h
+        lib.nvcompAmdSetLZPairMaxBatch.argtypes = [sz]
+        lib.nvcompAmdSetLZPairMaxBatch.restype = sz
     if hasattr(lib, "nvcompAmdSetLZIndexMinBatch"):  # include/nvcomp/amd_ext.h
         lib.nvcompAmdSetLZIndexMinBatch.argtypes = [sz]
         lib.nvcompAmdSetLZIndexMinBatch.restype = sz

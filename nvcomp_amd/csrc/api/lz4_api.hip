@@ -92,6 +92,59 @@ __global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_WAVES_PER_SIMD) lz4
   }
 }
 
+#if !NVCOMP_LZ_GATHER
+/* Small batches: two waves per chunk, a producer (chase + parse) and a consumer (execute), lz4w::pair. */
+template <bool CHECKED>
+__global__ void __launch_bounds__(128, 4) lz4_decompress_pair_kernel(
+    const void* const* __restrict__ comp_ptrs,
+    const size_t* __restrict__ comp_bytes,
+    const size_t* out_caps,
+    size_t* actual_bytes,
+    size_t batch_size,
+    void* const* __restrict__ out_ptrs,
+    nvcompStatus_t* statuses)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t lds[lz4w::pair::kLdsPerChunk];
+  const uint32_t w = wave::uniform(threadIdx.x >> 6);
+  const size_t chunk = blockIdx.x;
+  if (chunk >= batch_size) {
+    return;
+  }
+  if (threadIdx.x < 4) {
+    ((uint32_t*)(lds + lz4w::pair::kLdsPerChunk - lz4w::pair::kCtrlBytes))[threadIdx.x] = 0; /* both slots empty, no abort */
+  }
+  __syncthreads();
+  const uint8_t* in = wave::uniform_ptr((const uint8_t*)comp_ptrs[chunk]);
+  uint8_t* out = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
+  const size_t in_len64 = wave::uniform64(comp_bytes[chunk]);
+  size_t cap64 = wave::uniform64(out_caps[chunk]);
+  if (cap64 > kMaxOutCap) {
+    cap64 = kMaxOutCap;
+  }
+  const bool too_long = in_len64 > 0xffffffffull - 64;
+  const bool work = !too_long && in_len64 != 0;
+  if (w == 0) {
+    if (work) {
+      lz4w::pair::produce(in, (uint32_t)in_len64, lds);
+    }
+    return;
+  }
+  uint32_t err = too_long ? lz::kErrInput : lz::kErrNone;
+  uint32_t produced = 0;
+  if (work) {
+    produced = lz4w::pair::consume<CHECKED>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err);
+  }
+  if (wave::lane_id() == 0) {
+    if (actual_bytes != nullptr) {
+      actual_bytes[chunk] = err ? 0 : produced;
+    }
+    if (CHECKED) {
+      statuses[chunk] = err ? nvcompErrorCannotDecompress : nvcompSuccess;
+    }
+  }
+}
+#endif
+
 /* Token indexer: one LANE per chunk, 64 chunks per single-wave workgroup (common/lz_index.hip.h). */
 __global__ void __launch_bounds__(64) lz4_index_kernel(
     const void* const* __restrict__ comp_ptrs, const size_t* __restrict__ comp_bytes, size_t batch_size, lzi::Layout lay)
@@ -312,6 +365,18 @@ nvcompStatus_t nvcompBatchedLZ4DecompressAsync(
 #define NVCOMP_LZ4_ARGS                                                                                        \
   device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes, \
       batch_size, device_uncompressed_ptrs, device_statuses
+#if NVCOMP_AMD_LZ4_VARIANT == 0 && !NVCOMP_LZ_GATHER
+  /* Small batches cannot fill the card with one wave per chunk: two waves per chunk (producer / consumer). */
+  if (batch_size <= nvcomp_amd_tuning::lz_pair_max_batch) {
+    const dim3 pgrid((unsigned)batch_size), pblock(128);
+    if (checked) {
+      hipLaunchKernelGGL((lz4_decompress_pair_kernel<true>), pgrid, pblock, 0, stream, NVCOMP_LZ4_ARGS);
+    } else {
+      hipLaunchKernelGGL((lz4_decompress_pair_kernel<false>), pgrid, pblock, 0, stream, NVCOMP_LZ4_ARGS);
+    }
+    return launch_status();
+  }
+#endif
 #if NVCOMP_AMD_LZ4_VARIANT == 0
   /* Two-kernel path when the caller's temp buffer holds the token index and the batch is large enough to fill
    * the indexer's lanes (one lane per chunk; below the threshold the chase decoder's latency is lower). */

@@ -5,4 +5,5 @@
 
 namespace nvcomp_amd_tuning {
 extern size_t lz_index_min_batch;
+extern size_t lz_pair_max_batch;
 }

@@ -215,6 +215,23 @@ __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t bits)
   __hip_atomic_fetch_or(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+/* ---- two waves of one workgroup handing work to each other through LDS (producer / consumer) ----
+ * A flag word is written after, and read before, the data it guards; both sides are single instruction streams whose
+ * LDS operations are served in issue order, the release / acquire pair stops the compiler and drains the counters. */
+__device__ __forceinline__ void lds_store_release(uint32_t* p, uint32_t v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t lds_load_acquire(const uint32_t* p)
+{
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+/* Give the SIMD to the other waves for a few hundred cycles while polling. */
+__device__ __forceinline__ void nap()
+{
+  __builtin_amdgcn_s_sleep(4);
+}
+
 /* Trailing-zero / popcount helpers on ballots. */
 __device__ __forceinline__ uint32_t ctz64(uint64_t m)
 {

@@ -445,6 +445,209 @@ __device__ __forceinline__ uint32_t decode_chunk(
   return op;
 }
 
+/* ---- two waves per chunk (small batches) -----------------------------------------------------------------------
+ *
+ * One wave per chunk leaves the card under-filled below ~7 000 chunks, and a 64 KiB chunk takes a wave ~0.75 ms
+ * however idle the CU is: the wave's own dependent chain -- chase, parse, far loads, copy rounds, flush -- is what
+ * takes the time (profiles/r02_decode_phases.json). For small batches the chain is cut in two: wave 0 of a 128-thread
+ * workgroup (the PRODUCER) runs the token chase and the parse and hands batches of parsed sequences to wave 1 (the
+ * CONSUMER), which executes them; the two overlap, a chunk takes about as long as its slower half. Hand-over is a
+ * two-slot queue in LDS with one flag word per slot (wave::lds_store_release / lds_load_acquire). The producer never
+ * depends on anything the consumer does except a free slot; each wave keeps its own ring over the compressed stream
+ * (the consumer's serves the literal copies), so nothing else is shared. Same bytes as decode_chunk.
+ */
+namespace pair {
+
+constexpr uint32_t kSlotBytes = 16 + 4 * 64 * 4; /* n, flags, pad | lit_src[64] | lit_len[64] | match_off[64] | match_len[64] */
+constexpr uint32_t kFlagLast = 1, kFlagBad = 2;
+constexpr uint32_t kCtrlBytes = 16; /* state[2], abort, pad */
+/* window | consumer ring | producer ring | chase tables | two slots | control */
+constexpr uint32_t kLdsPerChunk = lzw::kOutLds + 2 * lzw::kInLds + lzw::kChaseLds + 2 * kSlotBytes + kCtrlBytes;
+
+struct Shared
+{
+  uint8_t* slot[2];
+  uint32_t* state; /* [2]: 0 = empty, 1 = full */
+  uint32_t* abort; /* the consumer gave up: the producer stops waiting */
+};
+
+__device__ __forceinline__ Shared shared_at(uint8_t* lds)
+{
+  uint8_t* q = lds + lzw::kOutLds + 2 * lzw::kInLds + lzw::kChaseLds;
+  Shared sh;
+  sh.slot[0] = q;
+  sh.slot[1] = q + kSlotBytes;
+  sh.state = (uint32_t*)(q + 2 * kSlotBytes);
+  sh.abort = sh.state + 2;
+  return sh;
+}
+
+/* lane 0's view of a flag word, the same for the whole wave */
+__device__ __forceinline__ uint32_t poll(const uint32_t* p)
+{
+  return wave::read_lane(wave::lds_load_acquire(p), 0);
+}
+
+__device__ __forceinline__ void produce(const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* lds)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  const Shared sh = shared_at(lds);
+  lzw::InRing ir;
+  lzw::in_init(ir, in, in_len, lds + lzw::kOutLds + lzw::kInLds);
+#if NVCOMP_LZW_PCHASE
+  lzw::Chase c;
+  lzw::chase_init(c, ir.vbeg, lds + lzw::kOutLds + 2 * lzw::kInLds);
+#else
+  Chase c;
+  c.q = ir.vbeg;
+  c.wb = c.q - 256;
+#endif
+  uint32_t k = 0;
+  for (;;) {
+    const bool last = c.q >= ir.vend;
+    uint32_t count = 0;
+    lz::Seq s;
+    s.lit_src = 0, s.lit_len = 0, s.match_off = 0, s.match_len = 0;
+    bool bad = false;
+    if (!last) {
+      lzw::in_ensure(ir, c.q, (c.q & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
+      uint32_t seqpos = 0;
+#if NVCOMP_LZW_PCHASE
+      count = lzw::chase_tokens(c, ir, seqpos, 0, DeltaFn(), SlowFn());
+#else
+      count = chase(c, ir, seqpos, 0);
+#endif
+      if (!parse_fast(ir, seqpos, lane < count, s, bad)) {
+        parse(ir, seqpos, lane < count, s, bad);
+      }
+    }
+    const uint32_t flags = (last ? kFlagLast : 0u) | (wave::ballot(bad) ? kFlagBad : 0u);
+    while (poll(sh.state + k) != 0) {
+      if (poll(sh.abort) != 0) {
+        return;
+      }
+      wave::nap();
+    }
+    uint32_t* f = (uint32_t*)(sh.slot[k] + 16);
+    f[lane] = s.lit_src;
+    f[64 + lane] = s.lit_len;
+    f[128 + lane] = s.match_off;
+    f[192 + lane] = s.match_len;
+    if (lane == 0) {
+      ((uint32_t*)sh.slot[k])[0] = count;
+      ((uint32_t*)sh.slot[k])[1] = flags;
+    }
+    wave::sync();
+    if (lane == 0) {
+      wave::lds_store_release(sh.state + k, 1u);
+    }
+    if (flags) {
+      return; /* the end of the chunk, or a malformed token: nothing follows */
+    }
+    k ^= 1;
+  }
+}
+
+template <bool CHECKED>
+__device__ __forceinline__ uint32_t consume(
+    const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_cap, uint8_t* lds, uint32_t& err)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  const Shared sh = shared_at(lds);
+  lzw::InRing ir;
+  lzw::OutWindow ow;
+  lzw::in_init(ir, in, in_len, lds + lzw::kOutLds);
+  lzw::out_init(ow, out, lds);
+  uint32_t op = 0;
+  uint32_t count = 0;
+  uint32_t k = 0;
+  lz::Seq s;
+  s.lit_src = 0, s.lit_len = 0, s.match_off = 0, s.match_len = 0;
+  for (;;) {
+    if (count == 0) {
+      while (poll(sh.state + k) != 1) {
+        wave::nap();
+      }
+      const uint32_t* f = (const uint32_t*)(sh.slot[k] + 16);
+      s.lit_src = f[lane];
+      s.lit_len = f[64 + lane];
+      s.match_off = f[128 + lane];
+      s.match_len = f[192 + lane];
+      const uint32_t n = wave::read_lane(((const uint32_t*)sh.slot[k])[0], 0);
+      const uint32_t flags = wave::read_lane(((const uint32_t*)sh.slot[k])[1], 0);
+      wave::sync();
+      if (lane == 0) {
+        wave::lds_store_release(sh.state + k, 0u);
+      }
+      k ^= 1;
+      if (flags & kFlagBad) {
+        err |= lz::kErrInput;
+        return 0;
+      }
+      if (flags & kFlagLast) {
+        break;
+      }
+      count = n;
+      if (count == 0) {
+        continue;
+      }
+    }
+    /* the literal copies read this wave's own ring */
+    {
+      const uint32_t oldest = wave::read_lane(s.lit_src, 0);
+      const uint32_t newest = wave::read_lane(s.lit_src, count - 1);
+      lzw::in_ensure(ir, oldest, (newest & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
+    }
+    bool big;
+    uint32_t take = lzg::execute_batch<CHECKED>(ir, ow, out_cap, op, count, s, err, big);
+    if (CHECKED && err) {
+      if (lane == 0) {
+        wave::lds_store_release(sh.abort, 1u);
+      }
+      return 0;
+    }
+    if (big) {
+      /* sequence 0 alone exceeds a batch: stream it HBM -> HBM and restart the window after it */
+      const uint32_t lsrc = wave::read_lane(s.lit_src, 0);
+      const uint32_t llen = wave::read_lane(s.lit_len, 0);
+      const uint32_t moff = wave::read_lane(s.match_off, 0);
+      const uint32_t mlen = wave::read_lane(s.match_len, 0);
+      if (CHECKED) {
+        const uint64_t end = (uint64_t)op + llen + mlen;
+        if (end > out_cap || (mlen != 0 && (moff == 0 || moff > op + llen))) {
+          err |= end > out_cap ? lz::kErrOutput : lz::kErrOffset;
+          if (lane == 0) {
+            wave::lds_store_release(sh.abort, 1u);
+          }
+          return 0;
+        }
+      }
+      lzw::out_flush_all(ow, op);
+      wave::sync();
+      lz::wave_copy(out + op, ir.base + lsrc, llen);
+      wave::sync();
+      if (mlen) {
+        lz::wave_match_copy(out + op + llen, moff, mlen);
+      }
+      op += llen + mlen;
+      lzg::restart_window(ow, op);
+      take = 1;
+    }
+    if (take < count) {
+      const uint32_t from = (lane + take) & 63u;
+      s.lit_src = wave::shuffle(s.lit_src, from);
+      s.lit_len = wave::shuffle(s.lit_len, from);
+      s.match_off = wave::shuffle(s.match_off, from);
+      s.match_len = wave::shuffle(s.match_len, from);
+    }
+    count -= take;
+  }
+  lzw::out_flush_all(ow, op);
+  return op;
+}
+
+} // namespace pair
+
 /*
  * The same decoder fed from the token index (common/lz_index.hip.h, lz4_index.hip.h): `toks` holds the virtual
  * positions of the chunk's n_tok tokens, found beforehand by the lane-per-chunk indexer, so a batch of 64

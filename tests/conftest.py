@@ -113,19 +113,23 @@ def gpu():
 
 @pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
 def backend(request):
-    """Every test through this fixture runs the LZ decoders on their two-kernel path (token index + indexed
-    decoder: the library takes it for large batches; include/nvcomp/amd_ext.h moves the threshold). Tests of the
-    LZ decoders additionally ask for `lz_path` to see the single-kernel chase decoder too."""
+    """Every test through this fixture runs the LZ4 decoder on its two-kernel path (token index + indexed decoder:
+    opt-in in the library, include/nvcomp/amd_ext.h). Tests of the LZ decoders additionally ask for `lz_path` to see
+    the single-kernel chase decoder (the default for large batches) and the two-waves-per-chunk decoder (the default
+    for small ones) too."""
     b = request.getfixturevalue(request.param)
+    b.lib.nvcompAmdSetLZPairMaxBatch(0)
     b.lib.nvcompAmdSetLZIndexMinBatch(1)
     return b
 
 
-@pytest.fixture(params=["indexed", "chase"])
+@pytest.fixture(params=["indexed", "chase", "pair"])
 def lz_path(request, backend):
-    """Both decode paths of nvcompBatched{LZ4,Snappy}DecompressAsync, whatever the batch size."""
+    """All decode paths of nvcompBatchedLZ4DecompressAsync, whatever the batch size."""
+    backend.lib.nvcompAmdSetLZPairMaxBatch((1 << 60) if request.param == "pair" else 0)
     backend.lib.nvcompAmdSetLZIndexMinBatch(1 if request.param == "indexed" else 1 << 60)
     yield request.param
+    backend.lib.nvcompAmdSetLZPairMaxBatch(0)
     backend.lib.nvcompAmdSetLZIndexMinBatch(1)
 
 
