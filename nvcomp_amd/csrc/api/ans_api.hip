@@ -19,6 +19,7 @@ constexpr uint32_t kMaxOutCap = 1u << 26;
 __global__ void __launch_bounds__(64 * kWavesPerBlock) ans_compress_kernel(
     const void* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
+    size_t max_chunk_bytes,
     size_t batch_size,
     void* const* __restrict__ out_ptrs,
     size_t* out_bytes)
@@ -31,8 +32,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) ans_compress_kernel(
   }
   const uint8_t* src = wave::uniform_ptr((const uint8_t*)in_ptrs[chunk]);
   uint8_t* dst = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
-  const uint32_t n = (uint32_t)wave::uniform64(in_bytes[chunk]);
-  const uint32_t produced = ans::encode_chunk(src, n, dst, lds[w]);
+  const size_t n64 = wave::uniform64(in_bytes[chunk]);
+  /* a chunk larger than the caller declared would overrun the slot sized from GetMaxOutputChunkSize: refused (size 0) */
+  const uint32_t produced = n64 > max_chunk_bytes ? 0u : ans::encode_chunk(src, (uint32_t)n64, dst, lds[w]);
   if (wave::lane_id() == 0) {
     out_bytes[chunk] = produced;
   }
@@ -171,8 +173,8 @@ nvcompStatus_t nvcompBatchedANSCompressAsync(
   }
   clear_stale_error();
   hipLaunchKernelGGL(ans_compress_kernel, dim3(grid_for(batch_size)), dim3(64 * kWavesPerBlock), 0, stream,
-                     device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
-                     device_compressed_bytes);
+                     device_uncompressed_ptrs, device_uncompressed_bytes, max_uncompressed_chunk_bytes, batch_size,
+                     device_compressed_ptrs, device_compressed_bytes);
   return launch_status();
 }
 

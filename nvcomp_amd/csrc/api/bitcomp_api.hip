@@ -20,6 +20,7 @@ template <class T, bool DELTA>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, 8) bitcomp_compress_kernel(
     const void* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
+    size_t max_chunk_bytes,
     size_t batch_size,
     void* const* __restrict__ out_ptrs,
     size_t* out_bytes)
@@ -30,8 +31,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 8) bitcomp_compress_kerne
   }
   const uint8_t* src = wave::uniform_ptr((const uint8_t*)in_ptrs[chunk]);
   uint8_t* dst = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
-  const uint32_t n = (uint32_t)wave::uniform64(in_bytes[chunk]);
-  const uint32_t produced = bitcomp::encode_chunk<T, DELTA>(src, n, dst);
+  const size_t n64 = wave::uniform64(in_bytes[chunk]);
+  /* a chunk larger than the caller declared would overrun the slot sized from GetMaxOutputChunkSize: refused (size 0) */
+  const uint32_t produced = n64 > max_chunk_bytes ? 0u : bitcomp::encode_chunk<T, DELTA>(src, (uint32_t)n64, dst);
   if (wave::lane_id() == 0) {
     out_bytes[chunk] = produced;
   }
@@ -190,7 +192,8 @@ nvcompStatus_t nvcompBatchedBitcompCompressAsync(
   const dim3 block(64 * kWavesPerBlock);
 #define NVCOMP_BITCOMP_LAUNCH(T, D)                                                                            \
   hipLaunchKernelGGL((bitcomp_compress_kernel<T, D>), grid, block, 0, stream, device_uncompressed_ptrs,        \
-                     device_uncompressed_bytes, batch_size, device_compressed_ptrs, device_compressed_bytes)
+                     device_uncompressed_bytes, max_uncompressed_chunk_bytes, batch_size, device_compressed_ptrs, \
+                     device_compressed_bytes)
   const bool delta = format_opts.algorithm_type == 0;
   switch (elem_size(format_opts.data_type)) {
   case 1:

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256, 8) cascaded_compress_kernel(
   const uint32_t n_bytes = (uint32_t)wave::uniform64(in_bytes[chunk]);
   const uint32_t w = casc::type_width(p.type);
   const uint32_t lane = (uint32_t)wave::lane_id();
-  if (n_bytes % w != 0) { /* contract: chunk sizes are multiples of the element size */
+  if (n_bytes % w != 0 || wave::uniform64(in_bytes[chunk]) > p.max_bytes) { /* contract: whole elements, within the declared size */
     if (lane == 0) {
       out_bytes[chunk] = 0;
       if (pass == 0 && todo != nullptr) {
@@ -355,6 +355,7 @@ nvcompStatus_t nvcompBatchedCascadedCompressAsync(
   p.num_rles = (uint32_t)format_opts.num_RLEs;
   p.num_deltas = (uint32_t)format_opts.num_deltas;
   p.use_bp = (uint32_t)format_opts.use_bp;
+  p.max_bytes = (uint32_t)max_uncompressed_chunk_bytes;
   const uint32_t w = 1u << (p.type >> 1);
   if (casc::decompress_lds_per_wave(p.sub_bytes, w, p.num_rles) + 64 > kBigBudget) { /* what the decoder may need */
     return nvcompErrorNotSupported;

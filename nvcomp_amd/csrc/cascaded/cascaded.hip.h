@@ -35,6 +35,7 @@ struct Params
   uint32_t num_rles;
   uint32_t num_deltas;
   uint32_t use_bp;
+  uint32_t max_bytes; /* compress: the chunk size the caller declared (its output slot is sized from it) */
 };
 
 __device__ __forceinline__ uint32_t type_width(uint32_t t)

@@ -95,3 +95,11 @@ def test_oversized_chunk_is_not_compressed(backend):
     if comp is None:
         pytest.skip("harness cannot declare a smaller max chunk")
     assert comp[1].size == 0 and comp[0].size > 0 and comp[2].size > 0
+
+
+@pytest.mark.parametrize("fmt,opts", [("Snappy", None), ("ANS", None), ("Bitcomp", (0, 1)), ("Cascaded", (4096, 4, 2, 1, 1))])
+def test_oversized_chunk_is_refused_by_every_compressor(backend, fmt, opts):
+    """Same rule for every format: a chunk larger than the declared max_uncompressed_chunk_bytes comes back with size 0."""
+    chunks = [datasets.int32_column(3000, 1), datasets.int32_column(9000, 2), datasets.int32_column(2000, 3)]
+    comp = backend.codec(fmt, opts).compress(chunks, max_chunk=4096)
+    assert comp[1].size == 0 and comp[0].size > 0 and comp[2].size > 0
