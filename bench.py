@@ -335,7 +335,17 @@ def run_case(args, ctx):
         replicas_to_check = replicas
     if statuses is not None:
         st = dev.download(statuses).view(np.int32)[:n]
-        assert (st == 0).all(), f"{int((st != 0).sum())} chunks failed"
+        if not (st == 0).all():
+            # say whether the INPUT was at fault: the same compressed chunks through the CPU decoder (checker only)
+            bad = np.nonzero(st != 0)[0]
+            detail = []
+            if not own_format:
+                dec = oracle.ref_lz4_decompress if args.algo == "lz4" else oracle.ref_snappy_decompress
+                for i in bad[:8]:
+                    u = int(i) % n_unique
+                    rc, ref = dec(comp[u], chunks[u].size) if oracle.have_ref() else (None, None)
+                    detail.append((int(i), int(st[i]), "cpu decoder: " + ("ok" if rc == 0 and np.array_equal(ref, chunks[u]) else f"rc={rc}")))
+            raise AssertionError(f"{bad.size} chunks failed: {detail}")
     act = dev.download(actual).view(np.uint64)[:n]
     assert args.no_verify or (act == np.tile(raw_sizes, replicas)).all(), "actual sizes differ from the originals"
     for r in range(replicas_to_check):

@@ -27,7 +27,7 @@ extern "C" {
 #define NVCOMP_AMD_LZ_INDEX_MIN_BATCH_DEFAULT ((size_t)-1)
 size_t nvcompAmdSetLZIndexMinBatch(size_t min_batch);
 
-/* nvcompBatchedLZ4DecompressAsync decodes a batch of at most this many chunks with TWO waves per chunk -- one chases and
+/* nvcompBatched{LZ4,Snappy}DecompressAsync decode a batch of at most this many chunks with TWO waves per chunk -- one chases and
  * parses the tokens, the other executes the sequences, a queue in LDS between them -- because one wave per chunk cannot
  * fill the card below ~7 000 chunks and a chunk's latency is its wave's own dependent chain. Larger batches use one wave
  * per chunk (more chunks in flight per CU). 0 = never. Returns the previous value; process-wide. */

@@ -12,6 +12,7 @@
 #include "common/log.h"
 
 #include "snappy/snappy_decode.hip.h"
+#include "common/tuning.h"
 #include "snappy/snappy_decode_window.hip.h"
 #include "snappy/snappy_encode.hip.h"
 
@@ -80,6 +81,58 @@ __global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_WAVES_PER_SIMD) sna
     }
   }
 }
+
+#if !NVCOMP_LZ_GATHER
+/* Small batches: two waves per chunk, a producer (chase + parse) and a consumer (execute), snappyw::pair. */
+template <bool CHECKED>
+__global__ void __launch_bounds__(128, 4) snappy_decompress_pair_kernel(
+    const void* const* __restrict__ comp_ptrs,
+    const size_t* __restrict__ comp_bytes,
+    const size_t* out_caps,
+    size_t* actual_bytes,
+    size_t batch_size,
+    void* const* __restrict__ out_ptrs,
+    nvcompStatus_t* statuses)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t lds[lzw::pair::kLdsPerChunk];
+  const uint32_t w = wave::uniform(threadIdx.x >> 6);
+  const size_t chunk = blockIdx.x;
+  if (chunk >= batch_size) {
+    return;
+  }
+  if (threadIdx.x < 4) {
+    ((uint32_t*)(lds + lzw::pair::kLdsPerChunk - lzw::pair::kCtrlBytes))[threadIdx.x] = 0; /* both slots empty, no abort */
+  }
+  __syncthreads();
+  const uint8_t* in = wave::uniform_ptr((const uint8_t*)comp_ptrs[chunk]);
+  uint8_t* out = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
+  const size_t in_len64 = wave::uniform64(comp_bytes[chunk]);
+  size_t cap64 = wave::uniform64(out_caps[chunk]);
+  if (cap64 > kMaxOutCap) {
+    cap64 = kMaxOutCap;
+  }
+  const bool work = in_len64 != 0 && in_len64 <= 0xffffffffull - 64; /* an empty stream has no preamble: malformed */
+  if (w == 0) {
+    if (work) {
+      snappyw::pair::produce<CHECKED>(in, (uint32_t)in_len64, lds);
+    }
+    return;
+  }
+  uint32_t err = work ? lz::kErrNone : lz::kErrInput;
+  uint32_t produced = 0;
+  if (work) {
+    produced = snappyw::pair::consume<CHECKED>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err);
+  }
+  if (wave::lane_id() == 0) {
+    if (actual_bytes != nullptr) {
+      actual_bytes[chunk] = err ? 0 : produced;
+    }
+    if (CHECKED) {
+      statuses[chunk] = err ? nvcompErrorCannotDecompress : nvcompSuccess;
+    }
+  }
+}
+#endif
 
 template <bool CHECKED, bool LANE_PARALLEL>
 __global__ void __launch_bounds__(64 * kDecWaves) snappy_decompress_kernel(
@@ -236,6 +289,22 @@ nvcompStatus_t nvcompBatchedSnappyDecompressAsync(
   const bool checked = device_statuses != nullptr;
   const int variant = snappy_decode_variant();
   const bool serial = variant == 2;
+#if !NVCOMP_LZ_GATHER
+  /* Small batches cannot fill the card with one wave per chunk: two waves per chunk (include/nvcomp/amd_ext.h). */
+  if (variant == 0 && batch_size <= nvcomp_amd_tuning::lz_pair_max_batch) {
+    const dim3 pgrid((unsigned)batch_size), pblock(128);
+    if (checked) {
+      hipLaunchKernelGGL((snappy_decompress_pair_kernel<true>), pgrid, pblock, 0, stream, device_compressed_ptrs,
+                         device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,
+                         batch_size, device_uncompressed_ptrs, device_statuses);
+    } else {
+      hipLaunchKernelGGL((snappy_decompress_pair_kernel<false>), pgrid, pblock, 0, stream, device_compressed_ptrs,
+                         device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,
+                         batch_size, device_uncompressed_ptrs, device_statuses);
+    }
+    return launch_status();
+  }
+#endif
   if (variant == 0) {
     if (checked) {
       hipLaunchKernelGGL((snappy_decompress_window_kernel<true>), grid, block, 0, stream, device_compressed_ptrs,

@@ -458,35 +458,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
  */
 namespace pair {
 
-constexpr uint32_t kSlotBytes = 16 + 4 * 64 * 4; /* n, flags, pad | lit_src[64] | lit_len[64] | match_off[64] | match_len[64] */
-constexpr uint32_t kFlagLast = 1, kFlagBad = 2;
-constexpr uint32_t kCtrlBytes = 16; /* state[2], abort, pad */
-/* window | consumer ring | producer ring | chase tables | two slots | control */
-constexpr uint32_t kLdsPerChunk = lzw::kOutLds + 2 * lzw::kInLds + lzw::kChaseLds + 2 * kSlotBytes + kCtrlBytes;
-
-struct Shared
-{
-  uint8_t* slot[2];
-  uint32_t* state; /* [2]: 0 = empty, 1 = full */
-  uint32_t* abort; /* the consumer gave up: the producer stops waiting */
-};
-
-__device__ __forceinline__ Shared shared_at(uint8_t* lds)
-{
-  uint8_t* q = lds + lzw::kOutLds + 2 * lzw::kInLds + lzw::kChaseLds;
-  Shared sh;
-  sh.slot[0] = q;
-  sh.slot[1] = q + kSlotBytes;
-  sh.state = (uint32_t*)(q + 2 * kSlotBytes);
-  sh.abort = sh.state + 2;
-  return sh;
-}
-
-/* lane 0's view of a flag word, the same for the whole wave */
-__device__ __forceinline__ uint32_t poll(const uint32_t* p)
-{
-  return wave::read_lane(wave::lds_load_acquire(p), 0);
-}
+using namespace lzw::pair;
 
 __device__ __forceinline__ void produce(const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* lds)
 {

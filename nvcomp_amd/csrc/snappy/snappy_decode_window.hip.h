@@ -326,6 +326,49 @@ __device__ __forceinline__ bool parse_fast(const lzw::InRing& r, uint32_t p, boo
   return true;
 }
 
+/* The varint32 preamble (uncompressed length) at the start of the stream, whose first block must be resident:
+ * q = position of the first element. False: malformed. */
+__device__ __forceinline__ bool read_preamble(const lzw::InRing& ir, uint32_t& q, uint32_t& total)
+{
+  q = ir.vbeg;
+  total = 0;
+  for (uint32_t shift = 0; shift <= 28 && q < ir.vend; shift += 7) {
+    const uint32_t b = lzw::in_byte_uniform(ir, q);
+    ++q;
+    total |= (b & 127u) << shift;
+    if (!(b & 128u)) {
+      return !(shift == 28 && b > 15);
+    }
+  }
+  return false;
+}
+
+/* A copy that continues the copy before it (same offset, nothing in between) is the same match going on: the
+ * compressor cuts matches into 64-byte elements, so runs and periodic columns arrive as long trains of them.
+ * The first lane of a train takes the whole length, the others become empty sequences. Returns the mask of the
+ * continuing lanes. */
+__device__ __forceinline__ uint64_t merge_trains(lz::Seq& s, uint32_t count)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t prev_off = wave::shuffle(s.match_off, (lane - 1) & 63u);
+  const uint32_t prev_len = wave::shuffle(s.match_len, (lane - 1) & 63u);
+  const bool cont = lane > 0 && lane < count && s.lit_len == 0 && s.match_len != 0 && prev_len != 0 && prev_off == s.match_off;
+  const uint64_t train = wave::ballot(cont);
+  if (train) {
+    const uint32_t incl = wave::scan_add_inclusive(lane < count ? s.match_len : 0u);
+    const uint64_t above = lane < 63 ? train >> (lane + 1) : 0ull;
+    const uint32_t followers = wave::ctz64(~above); /* consecutive continuing lanes right after this one */
+    const uint32_t end_incl = wave::shuffle(incl, (lane + followers) & 63u);
+    if (cont) {
+      s.match_len = 0;
+      s.match_off = 0;
+    } else if (followers) {
+      s.match_len += end_incl - incl;
+    }
+  }
+  return train;
+}
+
 template <bool CHECKED>
 __device__ __forceinline__ uint32_t decode_chunk(
     const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_cap, uint8_t* lds, uint32_t& err)
@@ -342,24 +385,10 @@ __device__ __forceinline__ uint32_t decode_chunk(
   lzw::out_init(ow, out, lds);
   lzg::attach_scratch(ow, lds + lzw::kOutLds + lzw::kInLds + lzw::kChaseLds);
   lzw::in_ensure(ir, ir.vbeg, ir.vbeg + lzw::kInBlock);
-  /* varint32 preamble */
-  uint32_t q = ir.vbeg;
-  uint32_t total = 0;
-  {
-    bool ok = false;
-    for (uint32_t shift = 0; shift <= 28 && q < ir.vend; shift += 7) {
-      const uint32_t b = lzw::in_byte_uniform(ir, q);
-      ++q;
-      total |= (b & 127u) << shift;
-      if (!(b & 128u)) {
-        ok = !(shift == 28 && b > 15);
-        break;
-      }
-    }
-    if (!ok) {
-      err = lz::kErrInput;
-      return 0;
-    }
+  uint32_t q, total;
+  if (!read_preamble(ir, q, total)) {
+    err = lz::kErrInput;
+    return 0;
   }
   if (CHECKED && total > out_cap) {
     err = lz::kErrOutput;
@@ -411,28 +440,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
         return 0;
       }
     }
-    /* A copy that continues the copy before it (same offset, nothing in between) is the same match going on: the
-     * compressor cuts matches into 64-byte elements, so runs and periodic columns arrive as long trains of them.
-     * The first lane of a train takes the whole length, the others become empty sequences. */
-    uint64_t train = 0;
-    {
-      const uint32_t prev_off = wave::shuffle(s.match_off, (lane - 1) & 63u);
-      const uint32_t prev_len = wave::shuffle(s.match_len, (lane - 1) & 63u);
-      const bool cont = lane > 0 && lane < count && s.lit_len == 0 && s.match_len != 0 && prev_len != 0 && prev_off == s.match_off;
-      train = wave::ballot(cont);
-      if (train) {
-        const uint32_t incl = wave::scan_add_inclusive(lane < count ? s.match_len : 0u);
-        const uint64_t above = lane < 63 ? train >> (lane + 1) : 0ull;
-        const uint32_t followers = wave::ctz64(~above); /* consecutive continuing lanes right after this one */
-        const uint32_t end_incl = wave::shuffle(incl, (lane + followers) & 63u);
-        if (cont) {
-          s.match_len = 0;
-          s.match_off = 0;
-        } else if (followers) {
-          s.match_len += end_incl - incl;
-        }
-      }
-    }
+    const uint64_t train = merge_trains(s, count);
     bool big;
     uint32_t take = lzg::execute_batch<CHECKED>(ir, ow, limit, op, count, s, err, big);
     if (CHECKED && err) {
@@ -478,5 +486,195 @@ __device__ __forceinline__ uint32_t decode_chunk(
   lzw::out_flush_all(ow, op);
   return op;
 }
+
+/* ---- two waves per chunk (small batches): lz4_decode_window.hip.h has the description ---- */
+namespace pair {
+
+using namespace lzw::pair;
+
+template <bool CHECKED>
+__device__ __forceinline__ void produce(const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* lds)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  const Shared sh = shared_at(lds);
+  lzw::InRing ir;
+  lzw::in_init(ir, in, in_len, lds + lzw::kOutLds + lzw::kInLds);
+  lzw::in_ensure(ir, ir.vbeg, ir.vbeg + lzw::kInBlock);
+  uint32_t q, total;
+  const bool preamble_ok = read_preamble(ir, q, total);
+#if NVCOMP_LZW_PCHASE
+  lzw::Chase c;
+  lzw::chase_init(c, q, lds + lzw::kOutLds + 2 * lzw::kInLds);
+#else
+  Chase c;
+  c.q = q;
+  c.wb = c.q - 256;
+#endif
+  uint32_t k = 0;
+  for (;;) {
+    const bool last = !preamble_ok || c.q >= ir.vend;
+    uint32_t count = 0;
+    lz::Seq s;
+    s.lit_src = 0, s.lit_len = 0, s.match_off = 0, s.match_len = 0;
+    bool bad = !preamble_ok || (last && CHECKED && c.q != ir.vend); /* the elements must end exactly at the end */
+    if (!last) {
+      lzw::in_ensure(ir, c.q, (c.q & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
+      uint32_t seqpos = 0;
+#if NVCOMP_LZW_PCHASE
+      count = lzw::chase_tokens(c, ir, seqpos, 0, DeltaFn(), SlowFn());
+#else
+      count = chase(c, ir, seqpos, 0);
+#endif
+      if (!parse_fast(ir, seqpos, lane < count, s, bad)) {
+        parse(ir, seqpos, lane < count, s, bad);
+      }
+      (void)merge_trains(s, count);
+    }
+    const uint32_t flags = (last ? kFlagLast : 0u) | (wave::ballot(bad) ? kFlagBad : 0u);
+    while (poll(sh.state + k) != 0) {
+      if (poll(sh.abort) != 0) {
+        return;
+      }
+      wave::nap();
+    }
+    uint32_t* f = (uint32_t*)(sh.slot[k] + 16);
+    f[lane] = s.lit_src;
+    f[64 + lane] = s.lit_len;
+    f[128 + lane] = s.match_off;
+    f[192 + lane] = s.match_len;
+    if (lane == 0) {
+      ((uint32_t*)sh.slot[k])[0] = count;
+      ((uint32_t*)sh.slot[k])[1] = flags;
+    }
+    wave::sync();
+    if (lane == 0) {
+      wave::lds_store_release(sh.state + k, 1u);
+    }
+    if (flags) {
+      return;
+    }
+    k ^= 1;
+  }
+}
+
+template <bool CHECKED>
+__device__ __forceinline__ uint32_t consume(
+    const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_cap, uint8_t* lds, uint32_t& err)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  const Shared sh = shared_at(lds);
+  lzw::InRing ir;
+  lzw::OutWindow ow;
+  lzw::in_init(ir, in, in_len, lds + lzw::kOutLds);
+  lzw::out_init(ow, out, lds);
+  lzw::in_ensure(ir, ir.vbeg, ir.vbeg + lzw::kInBlock);
+  uint32_t q, total;
+  const bool preamble_ok = read_preamble(ir, q, total);
+  if (!preamble_ok || (CHECKED && total > out_cap)) {
+    err = preamble_ok ? lz::kErrOutput : lz::kErrInput;
+    if (lane == 0) {
+      wave::lds_store_release(sh.abort, 1u);
+    }
+    return 0;
+  }
+  const uint32_t limit = CHECKED ? total : out_cap;
+  uint32_t op = 0;
+  uint32_t count = 0;
+  uint32_t k = 0;
+  lz::Seq s;
+  s.lit_src = 0, s.lit_len = 0, s.match_off = 0, s.match_len = 0;
+  for (;;) {
+    if (count == 0) {
+      while (poll(sh.state + k) != 1) {
+        wave::nap();
+      }
+      const uint32_t* f = (const uint32_t*)(sh.slot[k] + 16);
+      s.lit_src = f[lane];
+      s.lit_len = f[64 + lane];
+      s.match_off = f[128 + lane];
+      s.match_len = f[192 + lane];
+      const uint32_t n = wave::read_lane(((const uint32_t*)sh.slot[k])[0], 0);
+      const uint32_t flags = wave::read_lane(((const uint32_t*)sh.slot[k])[1], 0);
+      wave::sync();
+      if (lane == 0) {
+        wave::lds_store_release(sh.state + k, 0u);
+      }
+      k ^= 1;
+      if (flags & kFlagBad) {
+        err |= lz::kErrInput;
+        return 0;
+      }
+      if (flags & kFlagLast) {
+        break;
+      }
+      count = n;
+      if (count == 0) {
+        continue;
+      }
+    }
+    {
+      /* the literal copies read this wave's own ring; copy elements carry no stream position */
+      const bool has_lit = lane < count && s.lit_len != 0;
+      if (wave::ballot(has_lit)) {
+        const uint32_t hi = wave::reduce_max(has_lit ? s.lit_src : 0u);
+        const uint32_t lo = ~wave::reduce_max(has_lit ? ~s.lit_src : 0u);
+        lzw::in_ensure(ir, lo, (hi & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
+      }
+    }
+    bool big;
+    uint32_t take = lzg::execute_batch<CHECKED>(ir, ow, limit, op, count, s, err, big);
+    if (CHECKED && err) {
+      if (lane == 0) {
+        wave::lds_store_release(sh.abort, 1u);
+      }
+      return 0;
+    }
+    if (big) {
+      const uint32_t lsrc = wave::read_lane(s.lit_src, 0);
+      const uint32_t llen = wave::read_lane(s.lit_len, 0);
+      const uint32_t moff = wave::read_lane(s.match_off, 0);
+      const uint32_t mlen = wave::read_lane(s.match_len, 0);
+      if (CHECKED) {
+        const uint64_t end = (uint64_t)op + llen + mlen;
+        if (end > limit || (mlen != 0 && (moff == 0 || moff > op + llen))) {
+          err |= end > limit ? lz::kErrOutput : lz::kErrOffset;
+          if (lane == 0) {
+            wave::lds_store_release(sh.abort, 1u);
+          }
+          return 0;
+        }
+      }
+      lzw::out_flush_all(ow, op);
+      wave::sync();
+      lz::wave_copy(out + op, ir.base + lsrc, llen);
+      wave::sync();
+      if (mlen) {
+        lz::wave_match_copy(out + op + llen, moff, mlen);
+      }
+      op += llen + mlen;
+      lzg::restart_window(ow, op);
+      /* sequence 0 and the empty sequences (the followers of its copy train) right behind it */
+      const uint64_t empty = wave::ballot(lane < count && s.lit_len + s.match_len == 0);
+      take = 1 + wave::ctz64(~(empty >> 1));
+      take = take < count ? take : count;
+    }
+    if (take < count) {
+      const uint32_t from = (lane + take) & 63u;
+      s.lit_src = wave::shuffle(s.lit_src, from);
+      s.lit_len = wave::shuffle(s.lit_len, from);
+      s.match_off = wave::shuffle(s.match_off, from);
+      s.match_len = wave::shuffle(s.match_len, from);
+    }
+    count -= take;
+  }
+  if (CHECKED && op != total) {
+    err |= lz::kErrInput;
+    return 0;
+  }
+  lzw::out_flush_all(ow, op);
+  return op;
+}
+
+} // namespace pair
 
 } // namespace snappyw
