@@ -267,6 +267,7 @@ __global__ void __launch_bounds__(64 * kEncWaves, NVCOMP_LZM_WAVES_PER_SIMD) lz4
     size_t* out_bytes)
 {
   __shared__ uint16_t tables[kEncWaves][lzm::kTableU16];
+  __shared__ __attribute__((aligned(8))) uint8_t images[kEncWaves][lzm::kStageBytes];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
   const size_t chunk = (size_t)blockIdx.x * kEncWaves + w;
   if (chunk >= batch_size) {
@@ -277,7 +278,7 @@ __global__ void __launch_bounds__(64 * kEncWaves, NVCOMP_LZM_WAVES_PER_SIMD) lz4
   const size_t n64 = wave::uniform64(in_bytes[chunk]);
   /* a chunk larger than the caller declared would overrun the output slot sized from GetMaxOutputChunkSize: it is
    * not compressed, its size reads 0 */
-  const uint32_t produced = n64 > max_chunk_bytes ? 0u : lz4::encode_chunk<STRIDE>(src, (uint32_t)n64, dst, tables[w]);
+  const uint32_t produced = n64 > max_chunk_bytes ? 0u : lz4::encode_chunk<STRIDE>(src, (uint32_t)n64, dst, tables[w], images[w]);
   if (wave::lane_id() == 0) {
     out_bytes[chunk] = produced;
   }

@@ -38,6 +38,13 @@ namespace lzm {
 /* One-byte tags beside the positions (A/B build): a probe would look at the candidate's bytes in memory only when eight
  * more hash bits agree. Measured (profiles/r02_lz_compress.json): no gain -- the compressor is bound by the LENGTH of its
  * dependent chain per window, not by the candidate fetches -- and the extra 4 KiB of LDS per wave cost occupancy. Off. */
+/* The position side of a window (the 40 bytes around each of its 64 positions) comes out of a per-wave LDS image of the
+ * input, filled 512 bytes at a time by ONE coalesced load per lane, instead of four byte-strided lane loads per window:
+ * those cost the L1 (TCP) one tag lookup per lane and instruction -- 10.3 G lookups per GiB, one per cycle and CU for
+ * the whole kernel (profiles/r02_lz_compress.json, counters). 0 = the round-2 register path (A/B build). */
+#ifndef NVCOMP_LZM_STAGE
+#define NVCOMP_LZM_STAGE 1
+#endif
 #ifndef NVCOMP_LZM_TAGS
 #define NVCOMP_LZM_TAGS 0
 #endif
@@ -45,10 +52,12 @@ namespace lzm {
 #define NVCOMP_LZM_WAVES_PER_SIMD 5 /* what the 8 KiB hash table per wave allows (4-wave workgroups, 160 KB LDS per CU) */
 #endif
 constexpr uint32_t kHashBits = NVCOMP_LZM_HASH_BITS;
-/* Entries of the per-wave table. A power of two by default; -DNVCOMP_LZM_HASH_ENTRIES=3072 (a multiple of 128) gives
- * the 6 KiB table that fits 6 waves/SIMD (with -DNVCOMP_LZM_WAVES_PER_SIMD=6) -- an A/B build, not yet measured. */
+/* Entries of the per-wave table (any multiple of 128). With the input image beside it a wave has 8 KiB of LDS at
+ * 5 waves/SIMD (4-wave workgroups, 160 KB per CU): 3456 two-byte entries + 1072 bytes of image. */
 #ifdef NVCOMP_LZM_HASH_ENTRIES
 constexpr uint32_t kHashSize = NVCOMP_LZM_HASH_ENTRIES;
+#elif NVCOMP_LZM_STAGE
+constexpr uint32_t kHashSize = 3456;
 #else
 constexpr uint32_t kHashSize = 1u << kHashBits;
 #endif
@@ -160,6 +169,54 @@ __device__ __forceinline__ void load_around(Around& r, const uint8_t* __restrict
   }
 }
 
+/* ---- the input image (NVCOMP_LZM_STAGE) ----
+ * Two 512-byte blocks of the chunk, block b (bytes [512 b, 512 b + 512)) in slot b & 1, so that byte p lives at image
+ * offset p & 1023; the first kStageMirror bytes of slot 0 are repeated behind slot 1, which lets a lane read its 44
+ * bytes from ascending addresses whichever way round the two blocks lie. A window needs at most two consecutive
+ * blocks. Lane l carries bytes [8 l, 8 l + 8) of a block. */
+constexpr uint32_t kStageBlock = 512;
+constexpr uint32_t kStageMirror = 48;
+constexpr uint32_t kStageBytes = NVCOMP_LZM_STAGE ? 2 * kStageBlock + kStageMirror : 8;
+constexpr uint32_t kNoBlock = ~0u;
+
+__device__ __forceinline__ uint64_t stage_fetch(const uint8_t* __restrict__ src, uint32_t n, uint32_t blk)
+{
+  const uint32_t at = blk * kStageBlock + 8 * (uint32_t)wave::lane_id();
+  return at + 8 <= n ? wave::gload_u64(src + at) : 0ull; /* a piece that crosses the end is never looked at */
+}
+
+__device__ __forceinline__ void stage_commit(uint8_t* image, uint32_t blk, uint64_t piece)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t slot = blk & 1u;
+  *(uint64_t*)(image + slot * kStageBlock + 8 * lane) = piece;
+  if (slot == 0 && lane < kStageMirror / 8) {
+    *(uint64_t*)(image + 2 * kStageBlock + 8 * lane) = piece;
+  }
+}
+
+/* load_around() out of the image: eleven aligned dwords, realigned by the position's low two bits. */
+__device__ __forceinline__ void stage_around(Around& r, const uint8_t* image, uint32_t pos)
+{
+  const uint32_t from = (pos - 8u) & (2 * kStageBlock - 1);
+  const uint32_t* q = (const uint32_t*)(image + (from & ~3u));
+  const uint32_t sh = pos & 3u;
+  uint32_t w[11];
+#pragma unroll
+  for (uint32_t i = 0; i < 11; ++i) {
+    w[i] = q[i];
+  }
+  r.pre[0] = wave::align_bytes(w[1], w[0], sh);
+  r.pre[1] = wave::align_bytes(w[2], w[1], sh);
+#pragma unroll
+  for (uint32_t i = 0; i < 8; ++i) {
+    r.fwd[i] = wave::align_bytes(w[i + 3], w[i + 2], sh);
+  }
+  if (pos < 8) { /* the first eight positions of a chunk have nothing before them */
+    r.pre[0] = 0, r.pre[1] = 0;
+  }
+}
+
 /* What one lane knows about its position after the probe. */
 struct Probe
 {
@@ -234,7 +291,26 @@ __device__ __forceinline__ Probe probe_fast(
   }
   c.pre[0] = 0, c.pre[1] = 0;
   if (ok) {
+#if NVCOMP_LZM_STAGE
+    /* 40 bytes from 8 before the candidate in three loads (a candidate in the first 8 bytes of the chunk: 40 from it) */
+    const bool cback = p.cand >= kBackMax;
+    const uint8_t* cp = src + p.cand - (cback ? kBackMax : 0u);
+    const wave::u32x4 a = wave::gload_u32x4(cp);
+    const wave::u32x4 b = wave::gload_u32x4(cp + 16);
+    const uint64_t d = wave::gload_u64(cp + 32);
+    c.pre[0] = cback ? a.x : 0u;
+    c.pre[1] = cback ? a.y : 0u;
+    c.fwd[0] = cback ? a.z : a.x;
+    c.fwd[1] = cback ? a.w : a.y;
+    c.fwd[2] = cback ? b.x : a.z;
+    c.fwd[3] = cback ? b.y : a.w;
+    c.fwd[4] = cback ? b.z : b.x;
+    c.fwd[5] = cback ? b.w : b.y;
+    c.fwd[6] = cback ? (uint32_t)d : b.z;
+    c.fwd[7] = cback ? (uint32_t)(d >> 32) : b.w;
+#else
     load_around(c, src, p.cand, p.cand >= kBackMax);
+#endif
   }
   uint32_t x[8];
 #pragma unroll
@@ -320,7 +396,7 @@ __device__ __forceinline__ Probe probe_safe(
  */
 template <class Emitter, uint32_t STRIDE = 1>
 __device__ __forceinline__ uint32_t encode_chunk(
-    const uint8_t* __restrict__ src, uint32_t n, uint8_t* dst, uint16_t* table, uint32_t last_start,
+    const uint8_t* __restrict__ src, uint32_t n, uint8_t* dst, uint16_t* table, uint8_t* image, uint32_t last_start,
     uint32_t match_end, bool any_match)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
@@ -336,6 +412,11 @@ __device__ __forceinline__ uint32_t encode_chunk(
     uint32_t ip = 0;
     constexpr uint32_t kWin = 64 * STRIDE; /* bytes a window covers */
     uint32_t skip = 0;        /* leading BYTES of the window that the previous step's last match already covers */
+#if NVCOMP_LZM_STAGE
+    uint32_t have0 = kNoBlock, have1 = kNoBlock; /* the blocks in the image's two slots */
+    uint32_t coming = kNoBlock;                  /* the block requested ahead, in `piece` until its slot is free */
+    uint64_t piece = 0;
+#else
     Around ahead;             /* position side of window `ahead_ip`, requested one step early */
     uint32_t ahead_ip = ~0u;
 #pragma unroll
@@ -343,15 +424,49 @@ __device__ __forceinline__ uint32_t encode_chunk(
       ahead.fwd[i] = 0;
     }
     ahead.pre[0] = 0, ahead.pre[1] = 0;
+#endif
     while (ip <= last_start) {
       const uint32_t pos = ip + lane * STRIDE;
       const bool eligible = pos <= last_start;
-      const bool fast = ip + 63 * STRIDE + 32 <= n; /* wave-uniform: every lane may read its 32 bytes */
+      /* wave-uniform: every lane may read its 32 bytes (and the 8-byte pieces holding them lie inside the chunk) */
+      const bool fast = ip + 63 * STRIDE + 32 + (NVCOMP_LZM_STAGE ? 7 : 0) <= n;
       LZM_T(0); /* loop top */
       Probe pr;
       Around me; /* fast windows: the bytes around this lane's position stay in registers until its literals are written */
       me.pre[0] = 0, me.pre[1] = 0;
       if (fast) {
+#if NVCOMP_LZM_STAGE
+        const uint32_t first = (ip >= 8 ? ip - 8 : 0u) / kStageBlock;
+        const uint32_t last = (ip + 63 * STRIDE + 31) / kStageBlock; /* first or first + 1 */
+        if (coming != kNoBlock) {
+          const uint32_t there = coming & 1u ? have1 : have0;
+          if (there != first && there != last) { /* nothing this window reads is overwritten */
+            stage_commit(image, coming, piece);
+            have0 = coming & 1u ? have0 : coming;
+            have1 = coming & 1u ? coming : have1;
+            coming = kNoBlock;
+          }
+        }
+        if ((first & 1u ? have1 : have0) != first) { /* start of the chunk, or the window behind a long match */
+          stage_commit(image, first, stage_fetch(src, n, first));
+          have0 = first & 1u ? have0 : first;
+          have1 = first & 1u ? first : have1;
+        }
+        if ((last & 1u ? have1 : have0) != last) {
+          stage_commit(image, last, stage_fetch(src, n, last));
+          have0 = last & 1u ? have0 : last;
+          have1 = last & 1u ? last : have1;
+        }
+        wave::sync();
+        stage_around(me, image, pos);
+        if (coming == kNoBlock) { /* the block behind this window travels while the window is worked on */
+          const uint32_t next = last + 1;
+          if (next * kStageBlock < n && (next & 1u ? have1 : have0) != next) {
+            piece = stage_fetch(src, n, next);
+            coming = next;
+          }
+        }
+#else
         if (ahead_ip == ip) {
           me = ahead;
         } else {
@@ -361,6 +476,7 @@ __device__ __forceinline__ uint32_t encode_chunk(
           ahead_ip = ip + kWin;
           load_around(ahead, src, pos + kWin, true);
         }
+#endif
         pr = probe_fast(src, table, me, pos, eligible, match_end, STRIDE);
       } else {
         pr = probe_safe(src, table, pos, eligible, match_end, STRIDE);

@@ -31,6 +31,10 @@ struct __attribute__((packed)) PackedU32x4
 {
   uint32_t v[4];
 };
+struct __attribute__((packed)) PackedU32x2
+{
+  uint32_t v[2];
+};
 __device__ __forceinline__ uint32_t gload_u8(const uint8_t* p)
 {
   return *(const WAVE_GLOBAL uint8_t*)p;
@@ -48,6 +52,11 @@ __device__ __forceinline__ u32x4 gload_u32x4(const uint8_t* p) /* any alignment 
   const WAVE_GLOBAL PackedU32x4* q = (const WAVE_GLOBAL PackedU32x4*)p;
   u32x4 r = {q->v[0], q->v[1], q->v[2], q->v[3]};
   return r;
+}
+__device__ __forceinline__ uint64_t gload_u64(const uint8_t* p) /* any alignment (global_load_dwordx2) */
+{
+  const WAVE_GLOBAL PackedU32x2* q = (const WAVE_GLOBAL PackedU32x2*)p;
+  return ((uint64_t)q->v[1] << 32) | q->v[0];
 }
 __device__ __forceinline__ uint32_t gload_u16(const uint16_t* p)
 {

@@ -109,15 +109,16 @@ struct Emitter
 };
 
 /* Compress src[0,n) into dst (capacity >= n + n/255 + 16) with the calling
- * wave; `table` is this wave's LDS hash table, lzm::kTableU16 x uint16. Returns
+ * wave; `table` is this wave's LDS hash table, lzm::kTableU16 x uint16, `image` its
+ * lzm::kStageBytes of LDS for the input image (8-byte aligned). Returns
  * the compressed size. */
 template <uint32_t STRIDE = 1>
 __device__ __forceinline__ uint32_t encode_chunk(
-    const uint8_t* __restrict__ src, uint32_t n, uint8_t* dst, uint16_t* table)
+    const uint8_t* __restrict__ src, uint32_t n, uint8_t* dst, uint16_t* table, uint8_t* image)
 {
   const bool any = n > kMfLimit;
   return lzm::encode_chunk<Emitter, STRIDE>(
-      src, n, dst, table, any ? n - kMfLimit : 0, any ? n - kLastLiterals : 0, any);
+      src, n, dst, table, image, any ? n - kMfLimit : 0, any ? n - kLastLiterals : 0, any);
 }
 
 } // namespace lz4

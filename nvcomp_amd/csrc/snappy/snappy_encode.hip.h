@@ -159,7 +159,7 @@ struct Emitter
 
 /* Compress src[0,n) into dst (capacity >= 32 + n + n/6). Returns compressed size. */
 __device__ __forceinline__ uint32_t encode_chunk(
-    const uint8_t* __restrict__ src, uint32_t n, uint8_t* dst, uint16_t* table)
+    const uint8_t* __restrict__ src, uint32_t n, uint8_t* dst, uint16_t* table, uint8_t* image)
 {
   /* preamble: varint32 of n */
   uint32_t hdr = 0;
@@ -178,7 +178,7 @@ __device__ __forceinline__ uint32_t encode_chunk(
     }
   }
   const bool any = n >= 8;
-  return hdr + lzm::encode_chunk<Emitter>(src, n, dst + hdr, table, any ? n - 4 : 0, n, any);
+  return hdr + lzm::encode_chunk<Emitter>(src, n, dst + hdr, table, image, any ? n - 4 : 0, n, any);
 }
 
 } // namespace snappy

@@ -117,6 +117,12 @@ inline u32x4 gload_u32x4(const uint8_t* p)
   memcpy(&v, p, 16);
   return v;
 }
+inline uint64_t gload_u64(const uint8_t* p)
+{
+  uint64_t v;
+  memcpy(&v, p, 8);
+  return v;
+}
 inline uint32_t gload_u16(const uint16_t* p) { return *p; }
 inline void gstore_u8(uint8_t* p, uint32_t v) { *p = (uint8_t)v; }
 inline void gstore_u32x4_aligned(uint8_t* p, u32x4 v) { *(u32x4*)p = v; }
