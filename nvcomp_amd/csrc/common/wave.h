@@ -101,10 +101,14 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v)
   return ((uint64_t)hi << 32) | lo;
 }
 
+/* A wave-uniform pointer to DEVICE memory (every chunk pointer of a batch is one): it is rebuilt through the global
+ * address space, so that the compiler addresses everything derived from it with global_load / global_store. A pointer
+ * read out of a pointer array is otherwise generic, and flat_* instructions pay the LDS aperture check and count on
+ * lgkmcnt as well as vmcnt. */
 template <typename T>
 __device__ __forceinline__ T* uniform_ptr(T* p)
 {
-  return (T*)uniform64((uint64_t)p);
+  return (T*)(WAVE_GLOBAL T*)uniform64((uint64_t)p);
 }
 
 /* `vec` with lane `lane` (wave-uniform) replaced by the uniform value `val`. */
