@@ -44,7 +44,7 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--algo", choices=["lz4", "snappy", "cascaded", "bitcomp", "ans"], default="lz4",
+    p.add_argument("--algo", choices=["lz4", "snappy", "cascaded", "bitcomp", "ans", "deflate"], default="lz4",
                    help="lz4 is the headline (BASELINE.json configs[1]); cascaded/bitcomp/ans are this library's own stream "
                         "formats: their inputs are made by the HIP compressor (checked against the CPU model) outside the timed region")
     p.add_argument("--opts", default="", help="cascaded: chunk_size,type,num_RLEs,num_deltas,use_bp; bitcomp: algo,type")
@@ -75,6 +75,20 @@ def parse_args():
 def cpu_compress(oracle, algo, chunks, producer, threads):
     """Host-side producer of the compressed inputs (outside every timed region)."""
     caps = None
+    if algo == "deflate":
+        # the reference's CPU producers (examples/deflate_cpu_compression.cu:58-104): zlib deflateInit2(level 9, -15);
+        # "fast" = level 1. zlib releases the GIL: one thread per core.
+        import zlib
+        from multiprocessing.pool import ThreadPool
+
+        level = 1 if producer == "fast" else 9
+
+        def one(c):
+            o = zlib.compressobj(level, zlib.DEFLATED, -15, 8)
+            return np.frombuffer(o.compress(c.tobytes()) + o.flush(), dtype=np.uint8)
+
+        with ThreadPool(threads) as pool:
+            return pool.map(one, chunks), f"zlib deflate level {level}, raw streams (windowBits -15)"
     if producer != "port" and oracle.have_ref():
         if algo == "lz4":
             codec = oracle.LZ4_ENC_HC if producer == "hc" else oracle.LZ4_ENC
@@ -249,7 +263,8 @@ def run_case(args, ctx):
     from nvcomp_amd.batched import DeviceBatch
 
     rank, world, lib, dev, rt = ctx["rank"], ctx["world"], ctx["lib"], ctx["dev"], ctx["rt"]
-    fmt = {"lz4": "LZ4", "snappy": "Snappy", "cascaded": "Cascaded", "bitcomp": "Bitcomp", "ans": "ANS"}[args.algo]
+    fmt = {"lz4": "LZ4", "snappy": "Snappy", "cascaded": "Cascaded", "bitcomp": "Bitcomp", "ans": "ANS",
+           "deflate": "Deflate"}[args.algo]
     own_format = args.algo in OWN_FORMAT_OPTS
     opts = None
     if own_format:
@@ -339,7 +354,7 @@ def run_case(args, ctx):
             # say whether the INPUT was at fault: the same compressed chunks through the CPU decoder (checker only)
             bad = np.nonzero(st != 0)[0]
             detail = []
-            if not own_format:
+            if not own_format and args.algo != "deflate":
                 dec = oracle.ref_lz4_decompress if args.algo == "lz4" else oracle.ref_snappy_decompress
                 for i in bad[:8]:
                     u = int(i) % n_unique
@@ -373,7 +388,9 @@ def run_case(args, ctx):
         "config": {
             "workload": (f"{fmt} batched decompress, 64 KiB chunks, inputs from this library's HIP compressor"
                          + (" (BASELINE.json configs[3])" if args.algo == "cascaded" else "")) if own_format else
-                        f"{fmt} batched decompress, CPU-compressed 64 KiB chunks (BASELINE.json configs[1])",
+                        f"{fmt} batched decompress, CPU-compressed 64 KiB chunks "
+                        + ("(SURVEY.md 8 f4; the LZ4 line is BASELINE.json configs[1])" if args.algo == "deflate"
+                           else "(BASELINE.json configs[1])"),
             "dataset": args.dataset,
             "producer": producer,
             "chunk_bytes": CHUNK,
@@ -409,7 +426,8 @@ def run_case(args, ctx):
                 traffic = None
         result["roofline"] = {
             "bound": "hbm",
-            "kernel": f"{args.algo}_decompress_kernel" if own_format else f"{args.algo}_decompress_window_kernel",
+            "kernel": (f"{args.algo}_decompress_kernel" if own_format or args.algo == "deflate"
+                       else f"{args.algo}_decompress_window_kernel"),
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
@@ -419,7 +437,10 @@ def run_case(args, ctx):
             "traffic": traffic,
             "traffic_source": traffic_source,
         }
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and args.algo == "deflate":
+        result["extras"] = {"gpu_compress": "nvcompBatchedDeflateCompressAsync writes stored blocks (ratio 1.0): not timed; "
+                                            "the scope row is the decoder (SURVEY.md 8 f4)"}
+    elif rank == 0 and world == 1 and not args.no_extras:
         # compress leg on the GPU (ratio + compress GB/s of the metric string); not part of `value`
         from nvcomp_amd.batched import empty_batch
 
@@ -458,6 +479,9 @@ def run_case(args, ctx):
         if own_format:
             result["cpu_baseline"] = own_format_cpu_baseline(oracle, args.algo, comp, chunks, threads)
             return finish(result, args, world, rt, data)
+        if args.algo == "deflate":
+            result["cpu_baseline"] = deflate_cpu_baseline(comp, chunks, threads, unique)
+            return finish(result, args, world, rt, data)
         use_ref = oracle.have_ref()
         code = oracle.LZ4_DEC if args.algo == "lz4" else oracle.SNAPPY_DEC
         # bounded sample: the unique set repeated so that every thread gets >= 16 MiB per run (thread start-up
@@ -494,6 +518,30 @@ def run_case(args, ctx):
     return finish(result, args, world, rt, data)
 
 
+def deflate_cpu_baseline(comp, chunks, threads, unique):
+    """zlib inflate (the reference's CPU peer, examples/deflate_cpu_decompression.cu:128-170) over the unique set, one
+    thread per core (zlib releases the GIL), best of 3."""
+    import zlib
+    from multiprocessing.pool import ThreadPool
+
+    blobs = [c.tobytes() for c in comp]
+
+    def one(b):
+        return len(zlib.decompress(b, -15))
+
+    best = None
+    with ThreadPool(threads) as pool:
+        for _ in range(3):
+            t0 = time.perf_counter()
+            sizes = pool.map(one, blobs, chunksize=max(1, len(blobs) // (4 * threads)))
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+    assert sizes == [c.size for c in chunks]
+    return {"value": round(unique / best / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "reference",
+            "sample": f"{unique >> 20} MiB ({len(blobs)} chunks) of the same workload, best of 3, zlib {zlib.ZLIB_VERSION} "
+                      "inflate from Python threads"}
+
+
 def library_source_digest(algo="lz4"):
     """sha256 over the kernel sources of one codec: PMC traffic recorded for one build of a kernel must not be replayed
     beside the timing of another. LZ4 / Snappy: their own directories + common/ (the shared
@@ -501,7 +549,7 @@ def library_source_digest(algo="lz4"):
     import glob
     import hashlib
 
-    dirs = ["lz4", "snappy", "common"] if algo in ("lz4", "snappy") else [algo]
+    dirs = ["lz4", "snappy", "common"] if algo in ("lz4", "snappy") else ["deflate", "common"] if algo == "deflate" else [algo]
     h = hashlib.sha256()
     for d in dirs:
         for path in sorted(glob.glob(os.path.join(REPO, "nvcomp_amd", "csrc", d, "*.h*"))):

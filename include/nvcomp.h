@@ -16,5 +16,7 @@
 #include "nvcomp/cascaded.h"
 #include "nvcomp/bitcomp.h"
 #include "nvcomp/ans.h"
+#include "nvcomp/deflate.h"
+#include "nvcomp/gzip.h"
 
 #endif /* NVCOMP_H */

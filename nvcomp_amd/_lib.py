@@ -59,10 +59,15 @@ class ANSOpts(C.Structure):
     _fields_ = [("type", C.c_int)]
 
 
-OPTS = {"LZ4": LZ4Opts, "Snappy": SnappyOpts, "Cascaded": CascadedOpts, "Bitcomp": BitcompOpts, "ANS": ANSOpts}
+class DeflateOpts(C.Structure):
+    _fields_ = [("algo", C.c_int)]
+
+
+OPTS = {"LZ4": LZ4Opts, "Snappy": SnappyOpts, "Cascaded": CascadedOpts, "Bitcomp": BitcompOpts, "ANS": ANSOpts,
+        "Deflate": DeflateOpts}
 FORMATS = tuple(OPTS)
 
-# Every symbol include/nvcomp/{lz4,snappy,cascaded,bitcomp,ans}.h declares, per format.
+# Every symbol include/nvcomp/{lz4,snappy,cascaded,bitcomp,ans,deflate}.h declares, per format.
 ENTRY_POINTS = (
     "CompressGetTempSize",
     "CompressGetMaxOutputChunkSize",
@@ -77,7 +82,10 @@ EXTRA_ENTRY_POINTS = {
     "Cascaded": ("CompressGetTempSizeEx", "DecompressGetTempSizeEx"),
     "Bitcomp": ("CompressGetTempSizeEx", "DecompressGetTempSizeEx"),
     "ANS": ("CompressGetTempSizeEx", "DecompressGetTempSizeEx"),
+    "Deflate": ("CompressGetTempSizeEx", "DecompressGetTempSizeEx"),
 }
+# include/nvcomp/gzip.h: decompression only
+GZIP_ENTRY_POINTS = ("DecompressGetTempSize", "DecompressGetTempSizeEx", "DecompressAsync", "GetDecompressSizeAsync")
 
 
 def build_library(verbose: bool = False) -> str:
@@ -106,6 +114,13 @@ def declare(lib: C.CDLL, formats=FORMATS) -> C.CDLL:
         if "CompressGetTempSizeEx" in EXTRA_ENTRY_POINTS[fmt]:
             getattr(lib, pre + "CompressGetTempSizeEx").argtypes = [sz, sz, opts, szp, sz]
             getattr(lib, pre + "DecompressGetTempSizeEx").argtypes = [sz, sz, szp, sz]
+    if hasattr(lib, "nvcompBatchedGzipDecompressAsync"):  # include/nvcomp/gzip.h
+        lib.nvcompBatchedGzipDecompressGetTempSize.argtypes = [sz, sz, szp]
+        lib.nvcompBatchedGzipDecompressGetTempSizeEx.argtypes = [sz, sz, szp, sz]
+        lib.nvcompBatchedGzipDecompressAsync.argtypes = [vp, vp, vp, vp, sz, vp, sz, vp, vp, vp]
+        lib.nvcompBatchedGzipGetDecompressSizeAsync.argtypes = [vp, vp, vp, sz, vp]
+        for name in GZIP_ENTRY_POINTS:
+            getattr(lib, "nvcompBatchedGzip" + name).restype = C.c_int
     if hasattr(lib, "nvcompAmdBatchedPackAsync"):  # include/nvcomp/amd_ext.h
         lib.nvcompAmdBatchedPackAsync.argtypes = [vp, vp, sz, vp, sz, vp, vp]
     if hasattr(lib, "nvcompAmdSetLZPairMaxBatch"):  # include/nvcomp/amd_ext.h

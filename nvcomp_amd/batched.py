@@ -127,11 +127,15 @@ class BatchedCodec:
 
     def __init__(self, lib: C.CDLL, dev, fmt: str = "LZ4", opts=None) -> None:
         self.lib, self.dev, self.fmt = lib, dev, fmt
+        self._p = "nvcompBatched" + fmt
+        if fmt == "Gzip":  # include/nvcomp/gzip.h: decompression only, no options
+            self.opts_t = self.opts = None
+            return
         self.opts_t = OPTS[fmt]
         if opts is None:
-            opts = {"LZ4": (0,), "Snappy": (0,), "Cascaded": (4096, 4, 2, 1, 1), "Bitcomp": (0, 1), "ANS": (0,)}[fmt]
+            opts = {"LZ4": (0,), "Snappy": (0,), "Cascaded": (4096, 4, 2, 1, 1), "Bitcomp": (0, 1), "ANS": (0,),
+                    "Deflate": (0,)}[fmt]
         self.opts = opts if isinstance(opts, self.opts_t) else self.opts_t(*opts)
-        self._p = "nvcompBatched" + fmt
 
     def _fn(self, name: str):
         return getattr(self.lib, self._p + name)

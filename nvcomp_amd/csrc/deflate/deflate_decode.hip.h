@@ -1,0 +1,663 @@
+/*
+ * deflate/deflate_decode.hip.h -- batched DEFLATE (RFC 1951) / gzip (RFC 1952) decoder for gfx950.
+ *
+ * Replaces the device side of nvcompBatchedDeflateDecompressAsync / nvcompBatchedGzipDecompressAsync (reference call
+ * sites: examples/deflate_cpu_compression.cu:133-187 -- raw deflate streams written by libdeflate, zlib compress2 with
+ * the wrapper cut off, or deflateInit2(-15) -- and examples/gzip_gpu_decompression.cu:110-164 -- deflateInit2(15 | 16)).
+ * The wire formats are the public ones; the CPU peers are the oracle (zlib in tests/).
+ *
+ * One wavefront per chunk, in two halves:
+ *   front end  the Huffman symbols are decoded one after the other with WAVE-UNIFORM arithmetic (the scalar unit: a
+ *              64-bit bit buffer in SGPRs, table lookups in LDS). Literals go into a 2 KiB literal ring in LDS;
+ *              every length/distance pair closes a sequence record {literal run, match length, distance};
+ *   back end   64 records at a time (at most lzw::kBatchMax output bytes) are executed by the LZ window executor the
+ *              LZ4 and Snappy decoders use (common/lz_window.hip.h): lane k copies sequence k inside the LDS output
+ *              window, far matches (up to 32 KiB back) come from HBM, the window is flushed in aligned 16-byte stores.
+ * The literal ring is handed to the executor as its "input ring": a literal run is what LZ4 calls the literals of a
+ * sequence, only that here the bytes were decoded rather than copied from the stream. Runs are cut at 32 bytes so
+ * that every run is copied by its own lane.
+ *
+ * Decoding tables (per wave, LDS): a 10-bit lookup for the literal/length code and an 8-bit one for the distance
+ * code, entry = symbol << 4 | code length; longer codes (rare: each has probability < 2^-10 / 2^-8) are decoded
+ * canonically, bit by bit, from the per-length counts and the symbols sorted by code. Tables are built by the whole
+ * wave: counts and sorted symbols with ballots, lookup entries 16 per lane.
+ */
+#pragma once
+
+#include "common/lz_gather.hip.h"
+
+namespace deflate {
+
+constexpr uint32_t kMaxBits = 15;
+constexpr uint32_t kLitLenSyms = 288;
+constexpr uint32_t kDistSyms = 32;
+constexpr uint32_t kLutBits = 10;
+constexpr uint32_t kDistLutBits = 8;
+constexpr uint32_t kClLutBits = 7; /* the code-length code: at most 7 bits, always decoded by lookup */
+constexpr uint32_t kRunMax = lzw::kLitShort; /* literal bytes per sequence record */
+
+/* ---- LDS of one wave, behind the executor's window and the stream ring ---- */
+constexpr uint32_t kOffLit = 0;                                  /* literal ring: lzw::kInLds bytes */
+constexpr uint32_t kOffLutLL = kOffLit + lzw::kInLds;            /* uint16[1 << kLutBits] */
+constexpr uint32_t kOffLutD = kOffLutLL + (2u << kLutBits);      /* uint16[1 << kDistLutBits] (also the code-length code's) */
+constexpr uint32_t kOffCntLL = kOffLutD + (2u << kDistLutBits);  /* uint16[16] */
+constexpr uint32_t kOffCntD = kOffCntLL + 32;                    /* uint16[16] */
+constexpr uint32_t kOffSymLL = kOffCntD + 32;                    /* uint16[288] */
+constexpr uint32_t kOffSymD = kOffSymLL + 2 * kLitLenSyms;       /* uint16[32] */
+constexpr uint32_t kOffRec = kOffSymD + 2 * kDistSyms;           /* 64 records x 8 bytes; the 320 code lengths of a */
+constexpr uint32_t kRecBytes = 64 * 8;                           /* dynamic header while it is read */
+constexpr uint32_t kFrontLds = kOffRec + kRecBytes;
+static_assert(kRecBytes >= kLitLenSyms + kDistSyms, "the code lengths share the record area");
+constexpr uint32_t kLdsPerWave = lzg::kLdsPerWave - lzw::kChaseLds + kFrontLds; /* window + stream ring + the above */
+static_assert(kFrontLds % 16 == 0 && (lzw::kOutLds + lzw::kInLds) % 16 == 0, "16-byte alignment of the rings");
+
+enum : uint32_t { kGzip = 1 };
+
+/* ---- the bit reader: wave-uniform, over the stream ring ---- */
+struct Bits
+{
+  uint64_t buf;  /* bits not yet consumed, LSB first */
+  uint32_t cnt;  /* how many */
+  uint32_t next; /* virtual position (multiple of 4) of the next dword to load */
+
+  __device__ __forceinline__ uint32_t dword(const lzw::InRing& ir, uint32_t v) const
+  {
+    return wave::uniform(*(const uint32_t*)(ir.ring + (v & (lzw::kInRing - 1))));
+  }
+  /* continue at virtual byte position v */
+  __device__ __forceinline__ void seek(const lzw::InRing& ir, uint32_t v)
+  {
+    next = v & ~3u;
+    buf = (uint64_t)dword(ir, next) >> (8 * (v & 3u));
+    cnt = 32 - 8 * (v & 3u);
+    next += 4;
+  }
+  /* at least 32 bits in hand */
+  __device__ __forceinline__ void refill(const lzw::InRing& ir)
+  {
+    if (cnt < 32) {
+      buf |= (uint64_t)dword(ir, next) << cnt;
+      cnt += 32;
+      next += 4;
+    }
+  }
+  __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)buf & ((1u << n) - 1u); }
+  __device__ __forceinline__ void drop(uint32_t n)
+  {
+    buf >>= n;
+    cnt -= n;
+  }
+  __device__ __forceinline__ uint32_t take(uint32_t n)
+  {
+    const uint32_t v = peek(n);
+    drop(n);
+    return v;
+  }
+  /* virtual position of the first byte no bit of which was consumed */
+  __device__ __forceinline__ uint32_t byte_pos() const { return next - (cnt >> 3); }
+};
+
+/* ---- tables ---- */
+struct Code
+{
+  uint16_t* lut;
+  uint16_t* cnt;  /* codes per length, [0..15] */
+  uint16_t* syms; /* symbols in code order */
+};
+
+/*
+ * Build the decoding tables of one canonical Huffman code from its code lengths (lens[0, n), n <= 320 -- 0 = unused
+ * symbol). Returns false for an over-subscribed set of lengths. An incomplete set is accepted: a bit pattern
+ * without a symbol fails when (if) it is met.
+ */
+template <uint32_t LUT_BITS>
+__device__ __forceinline__ bool build_code(const Code& code, const uint8_t* lens, uint32_t n)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  uint32_t count[kMaxBits + 1];
+#pragma unroll
+  for (uint32_t l = 0; l <= kMaxBits; ++l) {
+    count[l] = 0;
+  }
+  for (uint32_t base = 0; base < n; base += 64) {
+    const uint32_t len = base + lane < n ? lens[base + lane] : 0u;
+#pragma unroll
+    for (uint32_t l = 1; l <= kMaxBits; ++l) {
+      count[l] += wave::popc64(wave::ballot(len == l));
+    }
+  }
+  int32_t left = 1;
+  uint32_t offs[kMaxBits + 2];
+  offs[1] = 0;
+#pragma unroll
+  for (uint32_t l = 1; l <= kMaxBits; ++l) {
+    left = 2 * left - (int32_t)count[l];
+    offs[l + 1] = offs[l] + count[l];
+  }
+  if (lane <= kMaxBits) {
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t l = 1; l <= kMaxBits; ++l) {
+      mine = lane == l ? count[l] : mine;
+    }
+    code.cnt[lane] = (uint16_t)mine;
+  }
+  if (left < 0) {
+    return false;
+  }
+  /* symbols in code order: by length, then by symbol */
+  for (uint32_t base = 0; base < n; base += 64) {
+    const uint32_t len = base + lane < n ? lens[base + lane] : 0u;
+#pragma unroll
+    for (uint32_t l = 1; l <= kMaxBits; ++l) {
+      const uint64_t same = wave::ballot(len == l);
+      if (len == l) {
+        code.syms[offs[l] + wave::prefix_popc(same)] = (uint16_t)(base + lane);
+      }
+      offs[l] += wave::popc64(same);
+    }
+  }
+  wave::sync();
+  /* lookup entries: the bits of the index, first bit read = bit 0, walked as a canonical code */
+  for (uint32_t e = lane; e < (1u << LUT_BITS); e += 64) {
+    uint32_t entry = 0, c = 0, first = 0, index = 0;
+#pragma unroll
+    for (uint32_t l = 1; l <= LUT_BITS; ++l) {
+      c |= (e >> (l - 1)) & 1u;
+      if (entry == 0 && c - first < count[l]) {
+        entry = ((uint32_t)code.syms[index + (c - first)] << 4) | l;
+      }
+      index += count[l];
+      first = (first + count[l]) << 1;
+      c <<= 1;
+    }
+    code.lut[e] = (uint16_t)entry;
+  }
+  wave::sync();
+  return true;
+}
+
+/* A symbol whose code is longer than the lookup (or does not exist): canonical walk, wave-uniform. Returns the
+ * symbol, or ~0u when no code matches the next 15 bits; `len` = bits it took. */
+__device__ __forceinline__ uint32_t slow_symbol(const Code& code, uint32_t bits, uint32_t& len)
+{
+  uint32_t c = 0, first = 0, index = 0;
+  for (uint32_t l = 1; l <= kMaxBits; ++l) {
+    c |= (bits >> (l - 1)) & 1u;
+    const uint32_t count = wave::uniform(code.cnt[l]);
+    if (c - first < count) {
+      len = l;
+      return wave::uniform(code.syms[index + (c - first)]);
+    }
+    index += count;
+    first = (first + count) << 1;
+    c <<= 1;
+  }
+  len = kMaxBits;
+  return ~0u;
+}
+
+template <uint32_t LUT_BITS>
+__device__ __forceinline__ uint32_t next_symbol(const Code& code, Bits& b, bool& bad)
+{
+  const uint32_t e = wave::uniform(code.lut[b.peek(LUT_BITS)]);
+  uint32_t len = e & 15u;
+  uint32_t sym = e >> 4;
+  if (len == 0) {
+    sym = slow_symbol(code, (uint32_t)b.buf, len);
+    bad = bad || sym == ~0u;
+  }
+  b.drop(len);
+  return sym;
+}
+
+/* ---- what the front end keeps between batches ---- */
+struct Front
+{
+  lzw::InRing lit;   /* the literal ring, in the executor's clothes: lo/hi = the literal positions it may read */
+  uint32_t lw;       /* literal bytes written so far (= virtual literal position of the next one) */
+  uint32_t run;      /* literal bytes of the sequence being assembled */
+  uint32_t* rec;     /* 64 records: {lit_src, lit_len | match_len << 8 | match_off << 17} */
+  uint32_t n;        /* records in hand */
+  uint32_t bytes;    /* output bytes they produce */
+  uint32_t carry0, carry1; /* a record that did not fit the batch (carry1 == 0: none) */
+  uint64_t produced; /* SIZE_ONLY: bytes so far */
+};
+
+/* Execute the records in hand. Returns false on error. */
+template <bool CHECKED>
+__device__ __forceinline__ bool run_batch(Front& f, lzw::OutWindow& ow, uint32_t limit, uint32_t& op, uint32_t& err)
+{
+  if (f.n == 0) {
+    return true;
+  }
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  wave::sync();
+  lz::Seq s;
+  s.lit_src = 0, s.lit_len = 0, s.match_off = 0, s.match_len = 0;
+  if (lane < f.n) {
+    const uint32_t a = f.rec[2 * lane], b = f.rec[2 * lane + 1];
+    s.lit_src = a;
+    s.lit_len = b & 0x3fu;
+    s.match_len = (b >> 6) & 0x1ffu;
+    s.match_off = b >> 15;
+  }
+  f.lit.lo = wave::read_lane(s.lit_src, 0);
+  f.lit.hi = f.lw;
+  bool big;
+  const uint32_t took = lzg::execute_batch<CHECKED>(f.lit, ow, limit, op, f.n, s, err, big);
+  if (err) {
+    return false;
+  }
+  if (took != f.n || big) { /* cannot happen: a batch is cut at lzw::kBatchMax bytes */
+    err |= lz::kErrInput;
+    return false;
+  }
+  wave::sync();
+  f.n = 0;
+  f.bytes = 0;
+  return true;
+}
+
+/* Run the batch in hand; a record that did not fit becomes the first of the next batch. */
+template <bool CHECKED>
+__device__ __forceinline__ bool drain(Front& f, lzw::OutWindow& ow, uint32_t limit, uint32_t& op, uint32_t& err)
+{
+  if (!run_batch<CHECKED>(f, ow, limit, op, err)) {
+    return false;
+  }
+  if (f.carry1 != 0) {
+    f.rec[0] = f.carry0; /* every lane writes the same words */
+    f.rec[1] = f.carry1 & 0x7fffffffu;
+    f.n = 1;
+    f.bytes = (f.carry1 & 0x3fu) + ((f.carry1 >> 6) & 0x1ffu);
+    f.carry1 = 0;
+  }
+  return true;
+}
+
+/* ... and that one too: the record area is empty afterwards. */
+template <bool CHECKED>
+__device__ __forceinline__ bool drain_all(Front& f, lzw::OutWindow& ow, uint32_t limit, uint32_t& op, uint32_t& err)
+{
+  return drain<CHECKED>(f, ow, limit, op, err) && run_batch<CHECKED>(f, ow, limit, op, err);
+}
+
+/* Close a sequence: literal run f.run (ending at f.lw) + a match. */
+template <bool SIZE_ONLY>
+__device__ __forceinline__ void close_sequence(Front& f, uint32_t match_len, uint32_t match_off)
+{
+  const uint32_t size = f.run + match_len;
+  if (SIZE_ONLY) {
+    f.produced += size;
+    f.run = 0;
+    return;
+  }
+  const uint32_t r0 = f.lw - f.run;
+  const uint32_t r1 = f.run | (match_len << 6) | (match_off << 15);
+  f.run = 0;
+  if (f.n == 64 || f.bytes + size > lzw::kBatchMax) {
+    f.carry0 = r0; /* the caller runs the batch and puts this record first in the next one */
+    f.carry1 = r1 | (1u << 31);
+    return;
+  }
+  f.rec[2 * f.n] = r0; /* every lane writes the same words */
+  f.rec[2 * f.n + 1] = r1;
+  f.n += 1;
+  f.bytes += size;
+}
+
+template <bool SIZE_ONLY>
+__device__ __forceinline__ void put_literal(Front& f, uint32_t byte)
+{
+  if (!SIZE_ONLY) {
+    const uint32_t at = f.lw & (lzw::kInRing - 1);
+    f.lit.ring[at] = (uint8_t)byte;
+    if (at < 16) {
+      f.lit.ring[lzw::kInRing + at] = (uint8_t)byte; /* the mirror the executor's dword reads rely on */
+    }
+  }
+  f.lw += 1;
+  f.run += 1;
+}
+
+/*
+ * Decode one chunk. `flags & kGzip`: the chunk is a gzip member (header skipped, ISIZE checked). SIZE_ONLY: nothing
+ * is written, the return value is the uncompressed size (mod 2^32). Returns the bytes produced.
+ */
+template <bool CHECKED, bool SIZE_ONLY>
+__device__ __forceinline__ uint32_t decode_chunk(
+    const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_cap, uint8_t* lds, uint32_t flags, uint32_t& err)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  err = lz::kErrNone;
+  if (in_len == 0) {
+    err = lz::kErrInput;
+    return 0;
+  }
+  lzw::InRing ir;
+  lzw::OutWindow ow;
+  lzw::in_init(ir, in, in_len, lds + lzw::kOutLds);
+  lzw::out_init(ow, out, lds);
+  uint8_t* front = lds + lzw::kOutLds + lzw::kInLds;
+  lzg::attach_scratch(ow, front + kFrontLds);
+  lzw::in_ensure(ir, ir.vbeg, ir.vbeg + 2 * lzw::kInBlock);
+
+  const Code ll = {(uint16_t*)(front + kOffLutLL), (uint16_t*)(front + kOffCntLL), (uint16_t*)(front + kOffSymLL)};
+  const Code dd = {(uint16_t*)(front + kOffLutD), (uint16_t*)(front + kOffCntD), (uint16_t*)(front + kOffSymD)};
+  uint8_t* lens = front + kOffRec;
+
+  Front f;
+  f.lit.base = nullptr;
+  f.lit.ring = front + kOffLit;
+  f.lit.vbeg = 0, f.lit.vend = ~0u, f.lit.lo = 0, f.lit.hi = 0;
+  f.lw = 0, f.run = 0, f.n = 0, f.bytes = 0, f.carry0 = 0, f.carry1 = 0, f.produced = 0;
+  f.rec = (uint32_t*)(front + kOffRec);
+
+  uint32_t start = ir.vbeg;
+  uint32_t stream_end = ir.vend; /* where the deflate stream must have ended by */
+  if (flags & kGzip) {
+    /* RFC 1952: ID1 ID2 CM FLG MTIME(4) XFL OS [XLEN + extra] [name 0] [comment 0] [CRC16] ... CRC32 ISIZE */
+    if (in_len < 18) {
+      err = lz::kErrInput;
+      return 0;
+    }
+    const uint32_t id = lzw::in_byte_uniform(ir, start) | (lzw::in_byte_uniform(ir, start + 1) << 8)
+                        | (lzw::in_byte_uniform(ir, start + 2) << 16);
+    const uint32_t flg = lzw::in_byte_uniform(ir, start + 3);
+    if (id != 0x088b1fu || (flg & 0xe0u)) {
+      err = lz::kErrInput;
+      return 0;
+    }
+    uint32_t p = start + 10;
+    if (flg & 4u) {
+      if (p + 2 > ir.vend) {
+        err = lz::kErrInput;
+        return 0;
+      }
+      p += 2 + (lzw::in_byte_uniform(ir, p) | (lzw::in_byte_uniform(ir, p + 1) << 8));
+    }
+    for (uint32_t field = 8; field <= 16; field += 8) { /* FNAME, FCOMMENT: zero-terminated */
+      if (flg & field) {
+        while (p < ir.vend && lzw::in_byte_uniform(ir, p) != 0) {
+          ++p;
+        }
+        ++p;
+      }
+    }
+    if (flg & 2u) {
+      p += 2;
+    }
+    if (p + 8 > ir.vend) {
+      err = lz::kErrInput;
+      return 0;
+    }
+    start = p;
+    stream_end = ir.vend - 8;
+  }
+
+  Bits b;
+  lzw::in_ensure(ir, start, (start & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
+  b.seek(ir, start);
+  uint32_t op = 0;
+  const uint32_t limit = out_cap;
+  bool bad = false;
+  bool last = false;
+
+  while (!last) {
+    /* ---- block header ---- */
+    lzw::in_ensure(ir, b.byte_pos() & ~3u, (b.byte_pos() & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
+    b.refill(ir);
+    last = b.take(1) != 0;
+    const uint32_t type = b.take(2);
+    if (type == 3 || b.byte_pos() > stream_end) {
+      bad = true;
+      break;
+    }
+    if (type == 0) {
+      /* stored: LEN, ~LEN, then LEN bytes from the next byte boundary */
+      b.drop(b.cnt & 7u);
+      b.refill(ir);
+      const uint32_t len = b.take(16);
+      const uint32_t nlen = b.take(16);
+      uint32_t from = b.byte_pos();
+      if ((len ^ nlen) != 0xffffu || from + len > stream_end) {
+        bad = true;
+        break;
+      }
+      if (SIZE_ONLY) {
+        f.produced += len;
+        from += len;
+      } else {
+        if (f.run != 0) {
+          close_sequence<SIZE_ONLY>(f, 0, 0);
+        }
+        if (!drain_all<CHECKED>(f, ow, limit, op, err)) {
+          return 0;
+        }
+        /* the bytes travel stream ring -> literal ring -> window, at most kBatchMax per round */
+        uint32_t left = len;
+        while (left != 0) {
+          const uint32_t now = left < lzw::kBatchMax ? left : lzw::kBatchMax;
+          lzw::in_ensure(ir, from, from + now);
+          for (uint32_t i = lane; i < now; i += 64) {
+            const uint32_t at = (f.lw + i) & (lzw::kInRing - 1);
+            const uint8_t v = (uint8_t)lzw::in_byte(ir, from + i);
+            f.lit.ring[at] = v;
+            if (at < 16) {
+              f.lit.ring[lzw::kInRing + at] = v;
+            }
+          }
+          const uint32_t recs = (now + kRunMax - 1) / kRunMax;
+          if (lane < recs) {
+            f.rec[2 * lane] = f.lw + kRunMax * lane;
+            f.rec[2 * lane + 1] = lane + 1 < recs ? kRunMax : now - kRunMax * (recs - 1);
+          }
+          f.lw += now;
+          f.n = recs;
+          f.bytes = now;
+          if (!run_batch<CHECKED>(f, ow, limit, op, err)) {
+            return 0;
+          }
+          from += now;
+          left -= now;
+        }
+      }
+      lzw::in_ensure(ir, from & ~3u, (from & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
+      b.seek(ir, from);
+      continue;
+    }
+    /* the code lengths are written where the records are kept */
+    if (!SIZE_ONLY && !drain_all<CHECKED>(f, ow, limit, op, err)) {
+      return 0;
+    }
+    uint32_t n_d = kDistSyms;
+    if (type == 1) {
+      /* fixed code: 8 bits for 0-143, 9 for 144-255, 7 for 256-279, 8 for 280-287; distances 5 bits */
+      for (uint32_t i = lane; i < kLitLenSyms + kDistSyms; i += 64) {
+        lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5);
+      }
+      wave::sync();
+    } else {
+      b.refill(ir);
+      const uint32_t n_ll = 257 + b.take(5);
+      n_d = 1 + b.take(5);
+      const uint32_t n_cl = 4 + b.take(4);
+      if (n_ll > 286 || n_d > 30) {
+        bad = true;
+        break;
+      }
+      /* the code-length code: 3-bit lengths in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 */
+      uint32_t cl_len[19];
+#pragma unroll
+      for (uint32_t i = 0; i < 19; ++i) {
+        cl_len[i] = 0;
+        if (i < n_cl) {
+          b.refill(ir);
+          cl_len[i] = b.take(3);
+        }
+      }
+      if (lane < 19) {
+        constexpr uint8_t kOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        uint32_t mine = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 19; ++i) {
+          mine = kOrder[i] == lane ? cl_len[i] : mine;
+        }
+        lens[lane] = (uint8_t)mine;
+      }
+      wave::sync();
+      if (!build_code<kClLutBits>(dd, lens, 19)) {
+        bad = true;
+        break;
+      }
+      /* the literal/length and distance code lengths, run-length coded with that code; the distance lengths are
+       * kept behind the 288 literal/length ones */
+      uint32_t i = 0, prev = 0;
+      while (i < n_ll + n_d && !bad) {
+        if (b.next + 16 > ir.hi && ir.hi < ir.vend) {
+          lzw::in_ensure(ir, b.byte_pos() & ~3u, (b.byte_pos() & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
+        }
+        b.refill(ir);
+        const uint32_t sym = next_symbol<kClLutBits>(dd, b, bad);
+        uint32_t rep = 1, val = sym;
+        if (sym == 16) {
+          rep = 3 + b.take(2);
+          val = prev;
+          bad = bad || i == 0;
+        } else if (sym == 17) {
+          rep = 3 + b.take(3);
+          val = 0;
+        } else if (sym == 18) {
+          rep = 11 + b.take(7);
+          val = 0;
+        } else if (sym > 18) {
+          bad = true;
+        }
+        if (bad || i + rep > n_ll + n_d || b.byte_pos() > stream_end) {
+          bad = true;
+          break;
+        }
+        for (uint32_t k = 0; k < rep; ++k) {
+          const uint32_t at = i + k < n_ll ? i + k : kLitLenSyms + (i + k - n_ll);
+          lens[at] = (uint8_t)val; /* every lane writes the same byte */
+        }
+        prev = val;
+        i += rep;
+      }
+      if (bad) {
+        break;
+      }
+      wave::sync();
+      for (uint32_t k = n_ll + lane; k < kLitLenSyms; k += 64) {
+        lens[k] = 0;
+      }
+      wave::sync();
+      if (wave::uniform(lens[256]) == 0) { /* no end-of-block code */
+        bad = true;
+        break;
+      }
+    }
+    if (!build_code<kLutBits>(ll, lens, kLitLenSyms) || !build_code<kDistLutBits>(dd, lens + kLitLenSyms, n_d)) {
+      bad = true;
+      break;
+    }
+
+    /* ---- the block's symbols ---- */
+    bool in_block = true;
+    while (in_block && !bad) {
+      /* until 64 records or kBatchMax bytes are in hand, the block ends, or the resident part of the stream runs out */
+      while (f.carry1 == 0) {
+        if (b.next + 16 > ir.hi && ir.hi < ir.vend) {
+          break; /* more of the stream has to come in */
+        }
+        if (b.byte_pos() > stream_end) {
+          bad = true;
+          break;
+        }
+        b.refill(ir);
+        const uint32_t sym = next_symbol<kLutBits>(ll, b, bad);
+        if (sym < 256) {
+          put_literal<SIZE_ONLY>(f, sym);
+          if (f.run == kRunMax) {
+            close_sequence<SIZE_ONLY>(f, 0, 0);
+          }
+          continue;
+        }
+        if (sym == 256) {
+          in_block = false;
+          break;
+        }
+        if (sym > 285 || bad) {
+          bad = true;
+          break;
+        }
+        uint32_t mlen;
+        if (sym < 265) {
+          mlen = sym - 254;
+        } else if (sym == 285) {
+          mlen = 258;
+        } else {
+          const uint32_t k = (sym - 261) >> 2;
+          mlen = ((4 + ((sym - 261) & 3u)) << k) + 3 + b.take(k);
+        }
+        b.refill(ir);
+        const uint32_t dsym = next_symbol<kDistLutBits>(dd, b, bad);
+        if (dsym > 29 || bad) {
+          bad = true;
+          break;
+        }
+        uint32_t dist;
+        if (dsym < 4) {
+          dist = dsym + 1;
+        } else {
+          const uint32_t k = (dsym >> 1) - 1;
+          dist = ((2 + (dsym & 1u)) << k) + 1 + b.take(k);
+        }
+        close_sequence<SIZE_ONLY>(f, mlen, dist);
+      }
+      if (bad) {
+        break;
+      }
+      if (!SIZE_ONLY && in_block && !drain<CHECKED>(f, ow, limit, op, err)) {
+        return 0;
+      }
+      if (in_block) {
+        lzw::in_ensure(ir, b.byte_pos() & ~3u, (b.byte_pos() & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
+      }
+    }
+    if (bad) {
+      break;
+    }
+  }
+  if (bad) {
+    err |= lz::kErrInput;
+    return 0;
+  }
+  if (b.byte_pos() > stream_end) { /* bits were taken from behind the end of the stream */
+    err |= lz::kErrInput;
+    return 0;
+  }
+  if (SIZE_ONLY) {
+    return (uint32_t)(f.produced + f.run);
+  }
+  if (f.run != 0) {
+    close_sequence<SIZE_ONLY>(f, 0, 0);
+  }
+  if (!drain_all<CHECKED>(f, ow, limit, op, err)) {
+    return 0;
+  }
+  lzw::out_flush_all(ow, op);
+  if (flags & kGzip) {
+    const uint32_t t = ir.vend - 4;
+    const uint32_t isize = lzw::in_byte_uniform(ir, t) | (lzw::in_byte_uniform(ir, t + 1) << 8)
+                           | (lzw::in_byte_uniform(ir, t + 2) << 16) | (lzw::in_byte_uniform(ir, t + 3) << 24);
+    if (CHECKED && isize != op) {
+      err |= lz::kErrInput;
+      return 0;
+    }
+  }
+  return op;
+}
+
+} // namespace deflate

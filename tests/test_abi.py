@@ -15,7 +15,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_functions():
     names = set()
-    for h in ("lz4.h", "snappy.h", "cascaded.h", "bitcomp.h", "ans.h"):
+    for h in ("lz4.h", "snappy.h", "cascaded.h", "bitcomp.h", "ans.h", "deflate.h", "gzip.h"):
         text = open(os.path.join(REPO, "include", "nvcomp", h)).read()
         names |= set(re.findall(r"nvcompStatus_t\s+(nvcompBatched\w+)\s*\(", text))
     return sorted(names)
@@ -30,7 +30,8 @@ def lib():
 
 def test_every_declared_symbol_is_exported(lib):
     names = declared_functions()
-    assert len(names) == 8 * 5  # six entry points per format + the *GetTempSizeEx pair (CHANGELOG.md:36-41, 114-117)
+    # six entry points per format + the *GetTempSizeEx pair (CHANGELOG.md:36-41, 114-117); gzip: decompression only
+    assert len(names) == 8 * 6 + 4
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
 
@@ -49,12 +50,21 @@ def test_host_only_queries_work_without_gpu(lib):
     assert lib.nvcompBatchedBitcompCompressGetMaxOutputChunkSize(65536, _lib.BitcompOpts(0, 5), C.byref(out)) == 0
     assert out.value == 12 + 8 * (32 + 8192) + 4  # 8 full blocks of 2048 uint32 at width 32, rounded to 8
     assert lib.nvcompBatchedLZ4CompressGetTempSize(10, 65536, _lib.LZ4Opts(0), None) == _lib.NvcompStatus.ErrorInvalidValue
+    assert lib.nvcompBatchedDeflateDecompressGetTempSize(1000, 65536, C.byref(out)) == 0 and out.value == 0
+    assert lib.nvcompBatchedGzipDecompressGetTempSize(1000, 65536, C.byref(out)) == 0 and out.value == 0
+    assert lib.nvcompBatchedDeflateCompressGetMaxOutputChunkSize(65536, _lib.DeflateOpts(0), C.byref(out)) == 0
+    assert out.value >= 65536 + 10
+    assert lib.nvcompBatchedDeflateCompressGetMaxOutputChunkSize(65537, _lib.DeflateOpts(0), C.byref(out)) \
+        == _lib.NvcompStatus.ErrorChunkSizeTooLarge  # benchmarks/benchmark_deflate_chunked.cu:53-63
+    assert lib.nvcompBatchedDeflateCompressGetTempSize(10, 65536, _lib.DeflateOpts(3), C.byref(out)) \
+        == _lib.NvcompStatus.ErrorInvalidValue  # "Deflate algorithm must be 0, 1, or 2" (:43)
 
 
 def test_struct_and_enum_layout():
     assert C.sizeof(_lib.LZ4Opts) == 4 and C.sizeof(_lib.SnappyOpts) == 4
     assert C.sizeof(_lib.CascadedOpts) == 24 and _lib.CascadedOpts.type.offset == 8
     assert C.sizeof(_lib.BitcompOpts) == 8 and _lib.BitcompOpts.data_type.offset == 4 and C.sizeof(_lib.ANSOpts) == 4
+    assert C.sizeof(_lib.DeflateOpts) == 4  # {int algo}: benchmarks/benchmark_deflate_chunked.cu:32,47
     text = open(os.path.join(REPO, "include", "nvcomp", "shared_types.h")).read()
     for name, val in (("nvcompSuccess", 0), ("nvcompErrorCannotDecompress", 12), ("nvcompErrorBadChecksum", 13),
                       ("nvcompErrorAlignment", 17), ("NVCOMP_TYPE_CHAR", 0), ("NVCOMP_TYPE_ULONGLONG", 7)):
