@@ -735,7 +735,7 @@ __device__ __forceinline__ void copy_to_lds(uint8_t* dst, const uint8_t* src, ui
  * and nothing is consumed). Returns the number of sequences consumed and adds
  * the bytes produced to op.
  */
-template <bool CHECKED>
+template <bool CHECKED, bool RING_LITERALS = false>
 __device__ __forceinline__ uint32_t execute_window_batch(
     InRing& ir, OutWindow& ow, uint32_t out_cap, uint32_t& op, uint32_t n, const lz::Seq& s, uint32_t& err, bool& big)
 {
@@ -891,7 +891,16 @@ __device__ __forceinline__ uint32_t execute_window_batch(
       const uint32_t jsrc = wave::read_lane(s.lit_src, j);
       const uint32_t jlen = wave::read_lane(my_lit, j);
       const uint32_t jdst = wave::read_lane(lit_dst, j);
-      copy_to_lds(out_at(ow, jdst), ir.base + jsrc, jlen);
+      if (!RING_LITERALS) {
+        copy_to_lds(out_at(ow, jdst), ir.base + jsrc, jlen);
+      } else {
+        /* a ring without a stream behind it (deflate/deflate_decode.hip.h: the literals were decoded, not copied out
+         * of the chunk): the run is resident by construction */
+        uint8_t* d = out_at(ow, jdst);
+        for (uint32_t i = lane; i < jlen; i += 64) {
+          d[i] = ir.ring[(jsrc + i) & (kInRing - 1)];
+        }
+      }
     }
   }
 

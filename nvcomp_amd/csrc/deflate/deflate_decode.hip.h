@@ -7,15 +7,22 @@
  * The wire formats are the public ones; the CPU peers are the oracle (zlib in tests/).
  *
  * One wavefront per chunk, in two halves:
- *   front end  the Huffman symbols are decoded one after the other with WAVE-UNIFORM arithmetic (the scalar unit: a
- *              64-bit bit buffer in SGPRs, table lookups in LDS). Literals go into a 2 KiB literal ring in LDS;
- *              every length/distance pair closes a sequence record {literal run, match length, distance};
+ *   front end  Huffman symbols -> sequence records {literal run, match length, distance} + literal bytes in a 2 KiB
+ *              literal ring in LDS. A symbol's length is only known once it is decoded, so the wave decodes
+ *              SPECULATIVELY at every bit position of a 256-bit window (four per lane: one lookup for the
+ *              literal/length code, one for the distance code), turns the lengths into jump tables by pointer
+ *              doubling (the token chase of common/lz_window.hip.h, on bit positions) and reads the true chain of
+ *              symbol starts off them, 32 at a time; lane k then decodes symbol k for good and the records are
+ *              assembled with ballots. What the lookups cannot tell (a code longer than the lookup, end of block,
+ *              an illegal symbol) is left to a wave-uniform decoder that takes one symbol at a time (the scalar
+ *              unit: a 64-bit bit buffer in SGPRs); block headers and table construction are wave-uniform /
+ *              wave-cooperative too. The symbol-at-a-time decoder alone runs at 23 GB/s: the CU's single scalar
+ *              unit is the bound (profiles/r02_deflate.json);
  *   back end   64 records at a time (at most lzw::kBatchMax output bytes) are executed by the LZ window executor the
  *              LZ4 and Snappy decoders use (common/lz_window.hip.h): lane k copies sequence k inside the LDS output
  *              window, far matches (up to 32 KiB back) come from HBM, the window is flushed in aligned 16-byte stores.
  * The literal ring is handed to the executor as its "input ring": a literal run is what LZ4 calls the literals of a
- * sequence, only that here the bytes were decoded rather than copied from the stream. Runs are cut at 32 bytes so
- * that every run is copied by its own lane.
+ * sequence, only that here the bytes were decoded rather than copied from the stream.
  *
  * Decoding tables (per wave, LDS): a 10-bit lookup for the literal/length code and an 8-bit one for the distance
  * code, entry = symbol << 4 | code length; longer codes (rare: each has probability < 2^-10 / 2^-8) are decoded
@@ -34,7 +41,10 @@ constexpr uint32_t kDistSyms = 32;
 constexpr uint32_t kLutBits = 10;
 constexpr uint32_t kDistLutBits = 8;
 constexpr uint32_t kClLutBits = 7; /* the code-length code: at most 7 bits, always decoded by lookup */
-constexpr uint32_t kRunMax = lzw::kLitShort; /* literal bytes per sequence record */
+constexpr uint32_t kRunMax = 255;  /* literal bytes per sequence record (8 bits of the record) */
+constexpr uint32_t kRunClose = 192; /* a pending run this long is closed as a record of its own between rounds */
+constexpr uint32_t kScanWin = 256;   /* bit positions one speculative window covers */
+constexpr uint32_t kScanLevels = 5;  /* jump tables for 1, 2, 4, 8, 16 symbols ahead: 32 symbols per enumeration */
 
 /* ---- LDS of one wave, behind the executor's window and the stream ring ---- */
 constexpr uint32_t kOffLit = 0;                                  /* literal ring: lzw::kInLds bytes */
@@ -46,9 +56,10 @@ constexpr uint32_t kOffSymLL = kOffCntD + 32;                    /* uint16[288] 
 constexpr uint32_t kOffSymD = kOffSymLL + 2 * kLitLenSyms;       /* uint16[32] */
 constexpr uint32_t kOffRec = kOffSymD + 2 * kDistSyms;           /* 64 records x 8 bytes; the 320 code lengths of a */
 constexpr uint32_t kRecBytes = 64 * 8;                           /* dynamic header while it is read */
-constexpr uint32_t kFrontLds = kOffRec + kRecBytes;
+constexpr uint32_t kOffScan = kOffRec + kRecBytes;               /* kScanLevels byte tables of kScanWin entries */
+constexpr uint32_t kFrontLds = kOffScan + kScanLevels * kScanWin;
 static_assert(kRecBytes >= kLitLenSyms + kDistSyms, "the code lengths share the record area");
-constexpr uint32_t kLdsPerWave = lzg::kLdsPerWave - lzw::kChaseLds + kFrontLds; /* window + stream ring + the above */
+constexpr uint32_t kLdsPerWave = lzw::kOutLds + lzw::kInLds + kFrontLds; /* window + stream ring + the above */
 static_assert(kFrontLds % 16 == 0 && (lzw::kOutLds + lzw::kInLds) % 16 == 0, "16-byte alignment of the rings");
 
 enum : uint32_t { kGzip = 1 };
@@ -95,6 +106,15 @@ struct Bits
   }
   /* virtual position of the first byte no bit of which was consumed */
   __device__ __forceinline__ uint32_t byte_pos() const { return next - (cnt >> 3); }
+  /* the same in bits (8 x virtual byte position + bit) */
+  __device__ __forceinline__ uint32_t bit_pos() const { return 8 * next - cnt; }
+  __device__ __forceinline__ void seek_bit(const lzw::InRing& ir, uint32_t q)
+  {
+    next = (q >> 5) << 2;
+    buf = (uint64_t)dword(ir, next) >> (q & 31u);
+    cnt = 32 - (q & 31u);
+    next += 4;
+  }
 };
 
 /* ---- tables ---- */
@@ -216,13 +236,20 @@ struct Front
 {
   lzw::InRing lit;   /* the literal ring, in the executor's clothes: lo/hi = the literal positions it may read */
   uint32_t lw;       /* literal bytes written so far (= virtual literal position of the next one) */
-  uint32_t run;      /* literal bytes of the sequence being assembled */
-  uint32_t* rec;     /* 64 records: {lit_src, lit_len | match_len << 8 | match_off << 17} */
+  uint32_t run;      /* literal bytes of the sequence being assembled (the last `run` bytes before lw) */
+  uint32_t* rec;     /* 64 records: {lit_src, packed} */
   uint32_t n;        /* records in hand */
   uint32_t bytes;    /* output bytes they produce */
-  uint32_t carry0, carry1; /* a record that did not fit the batch (carry1 == 0: none) */
+  uint32_t carry0, carry1; /* a record that did not fit the batch */
+  bool carried;
   uint64_t produced; /* SIZE_ONLY: bytes so far */
 };
+
+/* literal run (<= 255) | match length code (0 = none, else length - 2) << 8 | (distance - 1) << 17 */
+__device__ __forceinline__ uint32_t pack_record(uint32_t lit_len, uint32_t match_len, uint32_t match_off)
+{
+  return match_len ? lit_len | ((match_len - 2) << 8) | ((match_off - 1) << 17) : lit_len;
+}
 
 /* Execute the records in hand. Returns false on error. */
 template <bool CHECKED>
@@ -237,15 +264,16 @@ __device__ __forceinline__ bool run_batch(Front& f, lzw::OutWindow& ow, uint32_t
   s.lit_src = 0, s.lit_len = 0, s.match_off = 0, s.match_len = 0;
   if (lane < f.n) {
     const uint32_t a = f.rec[2 * lane], b = f.rec[2 * lane + 1];
+    const uint32_t code = (b >> 8) & 0x1ffu;
     s.lit_src = a;
-    s.lit_len = b & 0x3fu;
-    s.match_len = (b >> 6) & 0x1ffu;
-    s.match_off = b >> 15;
+    s.lit_len = b & 0xffu;
+    s.match_len = code ? code + 2 : 0u;
+    s.match_off = code ? (b >> 17) + 1 : 0u;
   }
   f.lit.lo = wave::read_lane(s.lit_src, 0);
   f.lit.hi = f.lw;
   bool big;
-  const uint32_t took = lzg::execute_batch<CHECKED>(f.lit, ow, limit, op, f.n, s, err, big);
+  const uint32_t took = lzw::execute_window_batch<CHECKED, true>(f.lit, ow, limit, op, f.n, s, err, big);
   if (err) {
     return false;
   }
@@ -266,24 +294,18 @@ __device__ __forceinline__ bool drain(Front& f, lzw::OutWindow& ow, uint32_t lim
   if (!run_batch<CHECKED>(f, ow, limit, op, err)) {
     return false;
   }
-  if (f.carry1 != 0) {
+  if (f.carried) {
     f.rec[0] = f.carry0; /* every lane writes the same words */
-    f.rec[1] = f.carry1 & 0x7fffffffu;
+    f.rec[1] = f.carry1;
     f.n = 1;
-    f.bytes = (f.carry1 & 0x3fu) + ((f.carry1 >> 6) & 0x1ffu);
-    f.carry1 = 0;
+    const uint32_t code = (f.carry1 >> 8) & 0x1ffu;
+    f.bytes = (f.carry1 & 0xffu) + (code ? code + 2 : 0u);
+    f.carried = false;
   }
   return true;
 }
 
-/* ... and that one too: the record area is empty afterwards. */
-template <bool CHECKED>
-__device__ __forceinline__ bool drain_all(Front& f, lzw::OutWindow& ow, uint32_t limit, uint32_t& op, uint32_t& err)
-{
-  return drain<CHECKED>(f, ow, limit, op, err) && run_batch<CHECKED>(f, ow, limit, op, err);
-}
-
-/* Close a sequence: literal run f.run (ending at f.lw) + a match. */
+/* Close a sequence, symbol-at-a-time path: literal run f.run (ending at f.lw) + a match. */
 template <bool SIZE_ONLY>
 __device__ __forceinline__ void close_sequence(Front& f, uint32_t match_len, uint32_t match_off)
 {
@@ -294,11 +316,12 @@ __device__ __forceinline__ void close_sequence(Front& f, uint32_t match_len, uin
     return;
   }
   const uint32_t r0 = f.lw - f.run;
-  const uint32_t r1 = f.run | (match_len << 6) | (match_off << 15);
+  const uint32_t r1 = pack_record(f.run, match_len, match_off);
   f.run = 0;
   if (f.n == 64 || f.bytes + size > lzw::kBatchMax) {
     f.carry0 = r0; /* the caller runs the batch and puts this record first in the next one */
-    f.carry1 = r1 | (1u << 31);
+    f.carry1 = r1;
+    f.carried = true;
     return;
   }
   f.rec[2 * f.n] = r0; /* every lane writes the same words */
@@ -321,6 +344,218 @@ __device__ __forceinline__ void put_literal(Front& f, uint32_t byte)
   f.run += 1;
 }
 
+/* ---- the lane-parallel front end ---- */
+
+/* 64 stream bits from bit position p on (the top ones may be missing: at least 48 are there), per lane. */
+__device__ __forceinline__ uint64_t bits_at(const lzw::InRing& ir, uint32_t p)
+{
+  const uint32_t a0 = (p >> 5) << 2;
+  const uint32_t s = p & 31u;
+  const uint32_t d0 = *(const uint32_t*)(ir.ring + (a0 & (lzw::kInRing - 1)));
+  const uint32_t d1 = *(const uint32_t*)(ir.ring + ((a0 + 4) & (lzw::kInRing - 1)));
+  const uint32_t d2 = *(const uint32_t*)(ir.ring + ((a0 + 8) & (lzw::kInRing - 1)));
+  const uint64_t lo = (((uint64_t)d1 << 32) | d0) >> s;
+  return s ? lo | ((uint64_t)d2 << (64 - s)) : lo;
+}
+
+/*
+ * The symbol that starts with bit 0 of w, by table lookups alone, per lane: a literal (value = the byte, dist = 0)
+ * or a length/distance pair with its extra bits (value = match length, dist = distance). Returns the bits it
+ * takes (<= 48), or 0 when the lookups cannot tell: a code longer than a lookup, end of block, an illegal symbol.
+ */
+__device__ __forceinline__ uint32_t decode_at(const Code& ll, const Code& dd, uint64_t w, uint32_t& value, uint32_t& dist)
+{
+  const uint32_t e = ll.lut[(uint32_t)w & ((1u << kLutBits) - 1u)];
+  const uint32_t len = e & 15u, sym = e >> 4;
+  value = sym;
+  dist = 0;
+  if (len == 0 || sym == 256 || sym > 285) {
+    return 0;
+  }
+  if (sym < 256) {
+    return len;
+  }
+  const bool plain = sym < 265 || sym == 285;
+  const uint32_t k = plain ? 0u : (sym - 261) >> 2;
+  const uint32_t base = sym < 265 ? sym - 254 : sym == 285 ? 258u : ((4 + ((sym - 261) & 3u)) << k) + 3;
+  uint32_t used = len;
+  value = base + ((uint32_t)(w >> used) & ((1u << k) - 1u));
+  used += k;
+  const uint32_t e2 = dd.lut[(uint32_t)(w >> used) & ((1u << kDistLutBits) - 1u)];
+  const uint32_t len2 = e2 & 15u, dsym = e2 >> 4;
+  if (len2 == 0 || dsym > 29) {
+    return 0;
+  }
+  used += len2;
+  const uint32_t k2 = dsym < 4 ? 0u : (dsym >> 1) - 1;
+  const uint32_t dbase = dsym < 4 ? dsym + 1 : ((2 + (dsym & 1u)) << k2) + 1;
+  dist = dbase + ((uint32_t)(w >> used) & ((1u << k2) - 1u));
+  return used + k2;
+}
+
+struct Scan
+{
+  uint32_t wb;    /* bit position of window slot 0 */
+  uint32_t nx[4]; /* lane l: bits the symbol at wb + 4 l + k would take (0 = the lookups cannot tell) */
+  uint8_t* tab;   /* LDS: kScanLevels tables of kScanWin bytes */
+  bool built;     /* the tables are those of this block's codes */
+};
+
+/* Tables of the window that starts at bit position q: J_i[p] = bits from p to the 2^i-th symbol after it (255 = it
+ * leaves the window, or a symbol on the way cannot be told). lz_window.hip.h: chase_build, on bit positions. */
+__device__ __forceinline__ void scan_build(Scan& c, const lzw::InRing& ir, const Code& ll, const Code& dd, uint32_t q)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  c.wb = q;
+  c.built = true;
+  const uint32_t p0 = q + 4 * lane;
+  const uint32_t a0 = (p0 >> 5) << 2;
+  const uint32_t s0 = p0 & 31u;
+  const uint32_t d0 = *(const uint32_t*)(ir.ring + (a0 & (lzw::kInRing - 1)));
+  const uint32_t d1 = *(const uint32_t*)(ir.ring + ((a0 + 4) & (lzw::kInRing - 1)));
+  const uint32_t d2 = *(const uint32_t*)(ir.ring + ((a0 + 8) & (lzw::kInRing - 1)));
+  const uint64_t lo64 = ((uint64_t)d1 << 32) | d0;
+  uint32_t a[4];
+#pragma unroll
+  for (uint32_t k = 0; k < 4; ++k) {
+    const uint32_t s = s0 + k; /* <= 34 */
+    const uint64_t w = s ? (lo64 >> s) | ((uint64_t)d2 << (64 - s)) : lo64;
+    uint32_t value, dist;
+    c.nx[k] = decode_at(ll, dd, w, value, dist);
+    a[k] = c.nx[k] != 0 && 4 * lane + k + c.nx[k] < kScanWin ? c.nx[k] : 255u;
+  }
+  uint32_t a01 = a[0] | (a[1] << 16), a23 = a[2] | (a[3] << 16);
+  *(uint32_t*)(c.tab + 4 * lane) = wave::perm_bytes(a23, a01, 0x06040200u);
+  wave::sync();
+#pragma unroll
+  for (uint32_t i = 1; i < kScanLevels; ++i) {
+    const uint8_t* prev = c.tab + (i - 1) * kScanWin + 4 * lane;
+    /* a == 255 reads past its table (into the next one, or the 3 bytes behind the last): the sum saturates anyway */
+    const uint32_t g0 = prev[0 + (a01 & 0xffffu)], g1 = prev[1 + (a01 >> 16)];
+    const uint32_t g2 = prev[2 + (a23 & 0xffffu)], g3 = prev[3 + (a23 >> 16)];
+    a01 = wave::pk_add_sat255(a01, g0 | (g1 << 16));
+    a23 = wave::pk_add_sat255(a23, g2 | (g3 << 16));
+    *(uint32_t*)(c.tab + i * kScanWin + 4 * lane) = wave::perm_bytes(a23, a01, 0x06040200u);
+    wave::sync();
+  }
+}
+
+/*
+ * One round of the lane-parallel front end: up to 64 symbols from bit position q on become records and literal
+ * bytes. Stops early where a symbol cannot be told by lookups (`stuck`: the caller decodes that one wave-uniformly),
+ * where the batch is full, or where the resident part of the stream ends. Returns the bit position to go on from.
+ */
+__device__ __forceinline__ uint32_t scan_round(
+    Scan& c, Front& f, const lzw::InRing& ir, const Code& ll, const Code& dd, uint32_t q, bool& stuck)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  uint32_t tokpos = 0; /* lane k: bit position of the round's k-th symbol */
+  uint32_t t = 0;
+  stuck = false;
+  const uint32_t cap = 64 - f.n; /* a symbol makes at most one record */
+  while (t < cap) {
+    if (!c.built || q - c.wb >= kScanWin) {
+      if ((q >> 3) + 64 > ir.hi && ir.hi < ir.vend) {
+        break; /* the window would look at bytes that are not resident yet */
+      }
+      scan_build(c, ir, ll, dd, q);
+    }
+    /* lane n < 32: the n-th symbol from q, if the chain gets there inside this window */
+    uint32_t pos = q - c.wb;
+    bool valid = lane < (1u << kScanLevels);
+#pragma unroll
+    for (uint32_t i = 0; i < kScanLevels; ++i) {
+      const uint32_t a = c.tab[i * kScanWin + pos];
+      const bool step = valid && ((lane >> i) & 1u) != 0;
+      const bool out = step && a == 255u;
+      valid = valid && !out;
+      pos += step && !out ? a : 0u;
+    }
+    uint32_t count = wave::popc64(wave::ballot(valid)); /* a prefix of the lanes; lane 0 always */
+    /* the chain's last symbol in hand: its own length says where to go on */
+    const uint32_t last = wave::read_lane(pos, count - 1);
+    const uint32_t sel = last & 3u;
+    const uint32_t v = sel == 0 ? c.nx[0] : sel == 1 ? c.nx[1] : sel == 2 ? c.nx[2] : c.nx[3];
+    const uint32_t d = wave::read_lane(v, last >> 2);
+    if (d == 0) {
+      count -= 1; /* the last one cannot be told: it is not part of the round */
+    }
+    const uint32_t room = cap - t;
+    const uint32_t take = count < room ? count : room;
+    const uint32_t shifted = t ? wave::shuffle(pos, (lane - t) & 63u) : pos;
+    if (lane >= t && lane < t + take) {
+      tokpos = c.wb + shifted;
+    }
+    t += take;
+    if (take < count) {
+      q = c.wb + wave::read_lane(pos, take);
+      break;
+    }
+    q = c.wb + last + d; /* d == 0: stays on the symbol that cannot be told */
+    if (d == 0) {
+      stuck = true;
+      break;
+    }
+  }
+  if (t == 0) {
+    return q;
+  }
+  /* ---- lane k decodes symbol k ---- */
+  uint32_t value = 0, dist = 0;
+  const bool mine0 = lane < t;
+  if (mine0) {
+    (void)decode_at(ll, dd, bits_at(ir, tokpos), value, dist);
+  }
+  const bool is_match0 = mine0 && dist != 0;
+  const uint32_t size = mine0 ? (is_match0 ? value : 1u) : 0u;
+  const uint32_t incl = wave::scan_add_inclusive(size);
+  /* the batch holds kBatchMax output bytes: the pending literal run counts, it joins the first record */
+  const uint32_t budget = lzw::kBatchMax - f.bytes - f.run;
+  const uint64_t over = wave::ballot(mine0 && incl > budget);
+  if (over) {
+    const uint32_t cut = wave::ctz64(over); /* >= 1: one symbol is at most 258 bytes */
+    q = wave::read_lane(tokpos, cut);
+    t = cut;
+    stuck = false;
+  }
+  const bool mine = lane < t;
+  const bool is_match = mine && dist != 0;
+  const bool is_lit = mine && dist == 0;
+  const uint64_t lits = wave::ballot(is_lit);
+  const uint64_t matches = wave::ballot(is_match);
+  const uint64_t below = (1ull << lane) - 1ull;
+  const uint32_t cum = wave::popc64(lits & below); /* literal symbols before this lane */
+  if (is_lit) {
+    const uint32_t at = (f.lw + cum) & (lzw::kInRing - 1);
+    f.lit.ring[at] = (uint8_t)value;
+    if (at < 16) {
+      f.lit.ring[lzw::kInRing + at] = (uint8_t)value;
+    }
+  }
+  const uint32_t n_lit = wave::popc64(lits);
+  const uint32_t n_match = wave::popc64(matches);
+  if (is_match) {
+    const uint64_t prev = matches & below;
+    const uint32_t before = prev ? wave::popc64(lits & ((1ull << (63 - (uint32_t)__builtin_clzll(prev))) - 1ull)) : 0u;
+    const uint32_t run = prev ? cum - before : cum + f.run;
+    const uint32_t src = prev ? f.lw + before : f.lw - f.run;
+    const uint32_t r = f.n + wave::popc64(prev);
+    f.rec[2 * r] = src;
+    f.rec[2 * r + 1] = pack_record(run, value, dist);
+  }
+  if (n_match) {
+    const uint32_t jl = 63 - (uint32_t)__builtin_clzll(matches);
+    const uint32_t upto = wave::read_lane(incl, jl);
+    f.bytes += f.run + upto;
+    f.run = n_lit - wave::popc64(lits & ((1ull << jl) - 1ull));
+    f.n += n_match;
+  } else {
+    f.run += n_lit;
+  }
+  f.lw += n_lit;
+  return q;
+}
+
 /*
  * Decode one chunk. `flags & kGzip`: the chunk is a gzip member (header skipped, ISIZE checked). SIZE_ONLY: nothing
  * is written, the return value is the uncompressed size (mod 2^32). Returns the bytes produced.
@@ -340,7 +575,6 @@ __device__ __forceinline__ uint32_t decode_chunk(
   lzw::in_init(ir, in, in_len, lds + lzw::kOutLds);
   lzw::out_init(ow, out, lds);
   uint8_t* front = lds + lzw::kOutLds + lzw::kInLds;
-  lzg::attach_scratch(ow, front + kFrontLds);
   lzw::in_ensure(ir, ir.vbeg, ir.vbeg + 2 * lzw::kInBlock);
 
   const Code ll = {(uint16_t*)(front + kOffLutLL), (uint16_t*)(front + kOffCntLL), (uint16_t*)(front + kOffSymLL)};
@@ -351,7 +585,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
   f.lit.base = nullptr;
   f.lit.ring = front + kOffLit;
   f.lit.vbeg = 0, f.lit.vend = ~0u, f.lit.lo = 0, f.lit.hi = 0;
-  f.lw = 0, f.run = 0, f.n = 0, f.bytes = 0, f.carry0 = 0, f.carry1 = 0, f.produced = 0;
+  f.lw = 0, f.run = 0, f.n = 0, f.bytes = 0, f.carry0 = 0, f.carry1 = 0, f.carried = false, f.produced = 0;
   f.rec = (uint32_t*)(front + kOffRec);
 
   uint32_t start = ir.vbeg;
@@ -396,196 +630,193 @@ __device__ __forceinline__ uint32_t decode_chunk(
     stream_end = ir.vend - 8;
   }
 
+  Scan sc;
+  sc.wb = 0, sc.built = false, sc.tab = front + kOffScan;
+  sc.nx[0] = sc.nx[1] = sc.nx[2] = sc.nx[3] = 0;
   Bits b;
   lzw::in_ensure(ir, start, (start & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
   b.seek(ir, start);
   uint32_t op = 0;
   const uint32_t limit = out_cap;
   bool bad = false;
-  bool last = false;
 
-  while (!last) {
-    /* ---- block header ---- */
-    lzw::in_ensure(ir, b.byte_pos() & ~3u, (b.byte_pos() & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
-    b.refill(ir);
-    last = b.take(1) != 0;
-    const uint32_t type = b.take(2);
-    if (type == 3 || b.byte_pos() > stream_end) {
-      bad = true;
-      break;
-    }
-    if (type == 0) {
-      /* stored: LEN, ~LEN, then LEN bytes from the next byte boundary */
-      b.drop(b.cnt & 7u);
-      b.refill(ir);
-      const uint32_t len = b.take(16);
-      const uint32_t nlen = b.take(16);
-      uint32_t from = b.byte_pos();
-      if ((len ^ nlen) != 0xffffu || from + len > stream_end) {
-        bad = true;
-        break;
-      }
-      if (SIZE_ONLY) {
-        f.produced += len;
-        from += len;
+  /* One loop, one place where a batch is executed (the executor is large: a single copy of it in the kernel). Each
+   * turn does one thing -- read a block header, decode symbols, move stored bytes -- and then runs whatever records
+   * are in hand. A header is read only when none are: the code lengths are written where the records are kept. */
+  enum : uint32_t { kHeader, kSymbols, kStored, kFlush, kDone };
+  uint32_t state = kHeader;
+  bool last = false;         /* the block being decoded is the final one */
+  uint32_t stored_from = 0;  /* kStored: the next byte of the block in the stream, and how many are left */
+  uint32_t stored_left = 0;
+  for (;;) {
+    if (state == kHeader && f.n == 0 && !f.carried) {
+      if (last) {
+        state = kFlush;
       } else {
-        if (f.run != 0) {
-          close_sequence<SIZE_ONLY>(f, 0, 0);
-        }
-        if (!drain_all<CHECKED>(f, ow, limit, op, err)) {
-          return 0;
-        }
-        /* the bytes travel stream ring -> literal ring -> window, at most kBatchMax per round */
-        uint32_t left = len;
-        while (left != 0) {
-          const uint32_t now = left < lzw::kBatchMax ? left : lzw::kBatchMax;
-          lzw::in_ensure(ir, from, from + now);
-          for (uint32_t i = lane; i < now; i += 64) {
-            const uint32_t at = (f.lw + i) & (lzw::kInRing - 1);
-            const uint8_t v = (uint8_t)lzw::in_byte(ir, from + i);
-            f.lit.ring[at] = v;
-            if (at < 16) {
-              f.lit.ring[lzw::kInRing + at] = v;
-            }
-          }
-          const uint32_t recs = (now + kRunMax - 1) / kRunMax;
-          if (lane < recs) {
-            f.rec[2 * lane] = f.lw + kRunMax * lane;
-            f.rec[2 * lane + 1] = lane + 1 < recs ? kRunMax : now - kRunMax * (recs - 1);
-          }
-          f.lw += now;
-          f.n = recs;
-          f.bytes = now;
-          if (!run_batch<CHECKED>(f, ow, limit, op, err)) {
-            return 0;
-          }
-          from += now;
-          left -= now;
-        }
-      }
-      lzw::in_ensure(ir, from & ~3u, (from & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
-      b.seek(ir, from);
-      continue;
-    }
-    /* the code lengths are written where the records are kept */
-    if (!SIZE_ONLY && !drain_all<CHECKED>(f, ow, limit, op, err)) {
-      return 0;
-    }
-    uint32_t n_d = kDistSyms;
-    if (type == 1) {
-      /* fixed code: 8 bits for 0-143, 9 for 144-255, 7 for 256-279, 8 for 280-287; distances 5 bits */
-      for (uint32_t i = lane; i < kLitLenSyms + kDistSyms; i += 64) {
-        lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5);
-      }
-      wave::sync();
-    } else {
-      b.refill(ir);
-      const uint32_t n_ll = 257 + b.take(5);
-      n_d = 1 + b.take(5);
-      const uint32_t n_cl = 4 + b.take(4);
-      if (n_ll > 286 || n_d > 30) {
-        bad = true;
-        break;
-      }
-      /* the code-length code: 3-bit lengths in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 */
-      uint32_t cl_len[19];
-#pragma unroll
-      for (uint32_t i = 0; i < 19; ++i) {
-        cl_len[i] = 0;
-        if (i < n_cl) {
-          b.refill(ir);
-          cl_len[i] = b.take(3);
-        }
-      }
-      if (lane < 19) {
-        constexpr uint8_t kOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-        uint32_t mine = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < 19; ++i) {
-          mine = kOrder[i] == lane ? cl_len[i] : mine;
-        }
-        lens[lane] = (uint8_t)mine;
-      }
-      wave::sync();
-      if (!build_code<kClLutBits>(dd, lens, 19)) {
-        bad = true;
-        break;
-      }
-      /* the literal/length and distance code lengths, run-length coded with that code; the distance lengths are
-       * kept behind the 288 literal/length ones */
-      uint32_t i = 0, prev = 0;
-      while (i < n_ll + n_d && !bad) {
-        if (b.next + 16 > ir.hi && ir.hi < ir.vend) {
-          lzw::in_ensure(ir, b.byte_pos() & ~3u, (b.byte_pos() & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
-        }
+        lzw::in_ensure(ir, b.byte_pos() & ~3u, (b.byte_pos() & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
         b.refill(ir);
-        const uint32_t sym = next_symbol<kClLutBits>(dd, b, bad);
-        uint32_t rep = 1, val = sym;
-        if (sym == 16) {
-          rep = 3 + b.take(2);
-          val = prev;
-          bad = bad || i == 0;
-        } else if (sym == 17) {
-          rep = 3 + b.take(3);
-          val = 0;
-        } else if (sym == 18) {
-          rep = 11 + b.take(7);
-          val = 0;
-        } else if (sym > 18) {
-          bad = true;
-        }
-        if (bad || i + rep > n_ll + n_d || b.byte_pos() > stream_end) {
+        last = b.take(1) != 0;
+        const uint32_t type = b.take(2);
+        if (type == 3 || b.byte_pos() > stream_end) {
           bad = true;
           break;
         }
-        for (uint32_t k = 0; k < rep; ++k) {
-          const uint32_t at = i + k < n_ll ? i + k : kLitLenSyms + (i + k - n_ll);
-          lens[at] = (uint8_t)val; /* every lane writes the same byte */
+        if (type == 0) {
+          /* stored: LEN, ~LEN, then LEN bytes from the next byte boundary */
+          b.drop(b.cnt & 7u);
+          b.refill(ir);
+          const uint32_t len = b.take(16);
+          const uint32_t nlen = b.take(16);
+          stored_from = b.byte_pos();
+          stored_left = len;
+          if ((len ^ nlen) != 0xffffu || stored_from + len > stream_end) {
+            bad = true;
+            break;
+          }
+          if (SIZE_ONLY) {
+            f.produced += len;
+            stored_from += len;
+            stored_left = 0;
+          } else if (f.run != 0) {
+            close_sequence<SIZE_ONLY>(f, 0, 0);
+          }
+          state = kStored;
+        } else {
+          uint32_t n_d = kDistSyms;
+          if (type == 1) {
+            /* fixed code: 8 bits for 0-143, 9 for 144-255, 7 for 256-279, 8 for 280-287; distances 5 bits */
+            for (uint32_t i = lane; i < kLitLenSyms + kDistSyms; i += 64) {
+              lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5);
+            }
+            wave::sync();
+          } else {
+            b.refill(ir);
+            const uint32_t n_ll = 257 + b.take(5);
+            n_d = 1 + b.take(5);
+            const uint32_t n_cl = 4 + b.take(4);
+            if (n_ll > 286 || n_d > 30) {
+              bad = true;
+              break;
+            }
+            /* the code-length code: 3-bit lengths in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 */
+            uint32_t cl_len[19];
+#pragma unroll
+            for (uint32_t i = 0; i < 19; ++i) {
+              cl_len[i] = 0;
+              if (i < n_cl) {
+                b.refill(ir);
+                cl_len[i] = b.take(3);
+              }
+            }
+            if (lane < 19) {
+              constexpr uint8_t kOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+              uint32_t mine = 0;
+#pragma unroll
+              for (uint32_t i = 0; i < 19; ++i) {
+                mine = kOrder[i] == lane ? cl_len[i] : mine;
+              }
+              lens[lane] = (uint8_t)mine;
+            }
+            wave::sync();
+            if (!build_code<kClLutBits>(dd, lens, 19)) {
+              bad = true;
+              break;
+            }
+            /* the literal/length and distance code lengths, run-length coded with that code; the distance lengths
+             * are kept behind the 288 literal/length ones */
+            uint32_t i = 0, prev = 0;
+            while (i < n_ll + n_d && !bad) {
+              if (b.next + 16 > ir.hi && ir.hi < ir.vend) {
+                lzw::in_ensure(ir, b.byte_pos() & ~3u, (b.byte_pos() & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
+              }
+              b.refill(ir);
+              const uint32_t sym = next_symbol<kClLutBits>(dd, b, bad);
+              uint32_t rep = 1, val = sym;
+              if (sym == 16) {
+                rep = 3 + b.take(2);
+                val = prev;
+                bad = bad || i == 0;
+              } else if (sym == 17) {
+                rep = 3 + b.take(3);
+                val = 0;
+              } else if (sym == 18) {
+                rep = 11 + b.take(7);
+                val = 0;
+              } else if (sym > 18) {
+                bad = true;
+              }
+              if (bad || i + rep > n_ll + n_d || b.byte_pos() > stream_end) {
+                bad = true;
+                break;
+              }
+              for (uint32_t k = 0; k < rep; ++k) {
+                const uint32_t at = i + k < n_ll ? i + k : kLitLenSyms + (i + k - n_ll);
+                lens[at] = (uint8_t)val; /* every lane writes the same byte */
+              }
+              prev = val;
+              i += rep;
+            }
+            if (bad) {
+              break;
+            }
+            wave::sync();
+            for (uint32_t k = n_ll + lane; k < kLitLenSyms; k += 64) {
+              lens[k] = 0;
+            }
+            wave::sync();
+            if (wave::uniform(lens[256]) == 0) { /* no end-of-block code */
+              bad = true;
+              break;
+            }
+          }
+          if (!build_code<kLutBits>(ll, lens, kLitLenSyms) || !build_code<kDistLutBits>(dd, lens + kLitLenSyms, n_d)) {
+            bad = true;
+            break;
+          }
+          sc.built = false;
+          state = kSymbols;
         }
-        prev = val;
-        i += rep;
       }
-      if (bad) {
-        break;
+    } else if (state == kSymbols && !f.carried) {
+      {
+        /* the round reads the stream ring from the byte the current BIT lies in (the bit buffer may already hold it) */
+        const uint32_t at = b.bit_pos() >> 3;
+        lzw::in_ensure(ir, at & ~3u, (at & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
       }
-      wave::sync();
-      for (uint32_t k = n_ll + lane; k < kLitLenSyms; k += 64) {
-        lens[k] = 0;
+      bool one_symbol = SIZE_ONLY; /* SIZE_ONLY: the whole block symbol by symbol; else: what the round could not tell */
+      if (!SIZE_ONLY) {
+        if (f.run >= kRunClose) {
+          close_sequence<SIZE_ONLY>(f, 0, 0);
+        }
+        if (!f.carried) {
+          const uint32_t q = scan_round(sc, f, ir, ll, dd, b.bit_pos(), one_symbol);
+          b.seek_bit(ir, q);
+          if (b.byte_pos() > stream_end) {
+            bad = true;
+            break;
+          }
+        }
       }
-      wave::sync();
-      if (wave::uniform(lens[256]) == 0) { /* no end-of-block code */
-        bad = true;
-        break;
-      }
-    }
-    if (!build_code<kLutBits>(ll, lens, kLitLenSyms) || !build_code<kDistLutBits>(dd, lens + kLitLenSyms, n_d)) {
-      bad = true;
-      break;
-    }
-
-    /* ---- the block's symbols ---- */
-    bool in_block = true;
-    while (in_block && !bad) {
-      /* until 64 records or kBatchMax bytes are in hand, the block ends, or the resident part of the stream runs out */
-      while (f.carry1 == 0) {
+      while (one_symbol && !f.carried) {
         if (b.next + 16 > ir.hi && ir.hi < ir.vend) {
-          break; /* more of the stream has to come in */
+          lzw::in_ensure(ir, b.byte_pos() & ~3u, (b.byte_pos() & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
         }
         if (b.byte_pos() > stream_end) {
           bad = true;
           break;
         }
+        one_symbol = SIZE_ONLY;
         b.refill(ir);
         const uint32_t sym = next_symbol<kLutBits>(ll, b, bad);
         if (sym < 256) {
-          put_literal<SIZE_ONLY>(f, sym);
           if (f.run == kRunMax) {
             close_sequence<SIZE_ONLY>(f, 0, 0);
           }
+          put_literal<SIZE_ONLY>(f, sym);
           continue;
         }
         if (sym == 256) {
-          in_block = false;
+          state = kHeader;
           break;
         }
         if (sym > 285 || bad) {
@@ -619,14 +850,49 @@ __device__ __forceinline__ uint32_t decode_chunk(
       if (bad) {
         break;
       }
-      if (!SIZE_ONLY && in_block && !drain<CHECKED>(f, ow, limit, op, err)) {
+    } else if (state == kStored && f.n == 0 && !f.carried) {
+      /* the bytes travel stream ring -> literal ring -> window, at most kBatchMax per turn */
+      if (stored_left == 0) {
+        lzw::in_ensure(ir, stored_from & ~3u, (stored_from & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
+        b.seek(ir, stored_from);
+        state = kHeader;
+      } else {
+        const uint32_t now = stored_left < lzw::kBatchMax ? stored_left : lzw::kBatchMax;
+        lzw::in_ensure(ir, stored_from, stored_from + now);
+        for (uint32_t i = lane; i < now; i += 64) {
+          const uint32_t at = (f.lw + i) & (lzw::kInRing - 1);
+          const uint8_t v = (uint8_t)lzw::in_byte(ir, stored_from + i);
+          f.lit.ring[at] = v;
+          if (at < 16) {
+            f.lit.ring[lzw::kInRing + at] = v;
+          }
+        }
+        const uint32_t recs = (now + kRunMax - 1) / kRunMax;
+        if (lane < recs) {
+          f.rec[2 * lane] = f.lw + kRunMax * lane;
+          f.rec[2 * lane + 1] = lane + 1 < recs ? kRunMax : now - kRunMax * (recs - 1);
+        }
+        f.lw += now;
+        f.n = recs;
+        f.bytes = now;
+        stored_from += now;
+        stored_left -= now;
+      }
+    } else if (state == kFlush && !f.carried) {
+      if (b.byte_pos() > stream_end) { /* bits were taken from behind the end of the stream */
+        bad = true;
+        break;
+      }
+      if (!SIZE_ONLY && f.run != 0) {
+        close_sequence<SIZE_ONLY>(f, 0, 0);
+      }
+      state = kDone;
+    }
+    if (!SIZE_ONLY && (f.n != 0 || f.carried)) {
+      if (!drain<CHECKED>(f, ow, limit, op, err)) {
         return 0;
       }
-      if (in_block) {
-        lzw::in_ensure(ir, b.byte_pos() & ~3u, (b.byte_pos() & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
-      }
-    }
-    if (bad) {
+    } else if (state == kDone) {
       break;
     }
   }
@@ -634,18 +900,8 @@ __device__ __forceinline__ uint32_t decode_chunk(
     err |= lz::kErrInput;
     return 0;
   }
-  if (b.byte_pos() > stream_end) { /* bits were taken from behind the end of the stream */
-    err |= lz::kErrInput;
-    return 0;
-  }
   if (SIZE_ONLY) {
     return (uint32_t)(f.produced + f.run);
-  }
-  if (f.run != 0) {
-    close_sequence<SIZE_ONLY>(f, 0, 0);
-  }
-  if (!drain_all<CHECKED>(f, ow, limit, op, err)) {
-    return 0;
   }
   lzw::out_flush_all(ow, op);
   if (flags & kGzip) {

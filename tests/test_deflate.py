@@ -82,6 +82,26 @@ def test_block_kinds(backend, how):
     check(backend, "Deflate", chunks, [make(c) for c in chunks])
 
 
+def test_many_small_streams(backend):
+    """A few hundred chunks of every size and kind in one batch, all levels and strategies: block boundaries, window
+    boundaries of the speculative decoder and batch cuts fall everywhere."""
+    rng = np.random.RandomState(17)
+    pool = {n: datasets.CLASSES[n](1 << 18, 4) for n in ("text", "table", "float32", "lowcard", "noise", "zeros", "int32")}
+    chunks, comp = [], []
+    for i in range(240 if backend.name == "gpu" else 96):
+        name = list(pool)[i % len(pool)]
+        size = int(rng.randint(1, 20000))
+        at = int(rng.randint(0, (1 << 18) - size))
+        c = pool[name][at: at + size].copy()
+        if i % 5 == 0:  # splice two kinds
+            c[size // 2:] = pool["text"][: size - size // 2]
+        level = int(rng.randint(1, 10))
+        strategy = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_RLE, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY][i % 5 if i % 3 == 0 else 0]
+        chunks.append(c)
+        comp.append(raw_deflate(c, level, strategy, flush_every=int(rng.randint(200, 4000)) if i % 7 == 0 else 0))
+    check(backend, "Deflate", chunks, comp)
+
+
 def test_ragged_and_tiny_chunks(backend):
     rng = np.random.RandomState(3)
     text = datasets.CLASSES["text"](40000, 1)
