@@ -20,11 +20,12 @@ namespace {
 /* One chunk per wave. A wave's LDS (window, stream ring, literal ring, decoding and jump tables:
  * deflate::kLdsPerWave = 11 KiB) allows 14 waves per CU in workgroups of two. */
 constexpr unsigned kDecWaves = 2;
+constexpr unsigned kDecWavesPerSimd = deflate::kLdsPerWave <= 10240 ? 4 : 3;
 constexpr unsigned kEncWaves = 4;
 constexpr uint32_t kMaxOutCap = 1u << 26;
 
 template <bool CHECKED, uint32_t FLAGS>
-__global__ void __launch_bounds__(64 * kDecWaves, 3) deflate_decompress_kernel(
+__global__ void __launch_bounds__(64 * kDecWaves, kDecWavesPerSimd) deflate_decompress_kernel(
     const void* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes,
     const size_t* out_caps,
@@ -64,7 +65,7 @@ __global__ void __launch_bounds__(64 * kDecWaves, 3) deflate_decompress_kernel(
 }
 
 /* Size query of raw DEFLATE: the symbols are decoded and counted (the format carries no length). */
-__global__ void __launch_bounds__(64 * kDecWaves, 3) deflate_size_kernel(
+__global__ void __launch_bounds__(64 * kDecWaves, kDecWavesPerSimd) deflate_size_kernel(
     const void* const* __restrict__ comp_ptrs, const size_t* __restrict__ comp_bytes, size_t* uncompressed_bytes, size_t batch_size)
 {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kDecWaves][deflate::kLdsPerWave];

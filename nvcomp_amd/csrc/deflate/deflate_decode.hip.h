@@ -38,7 +38,10 @@ namespace deflate {
 constexpr uint32_t kMaxBits = 15;
 constexpr uint32_t kLitLenSyms = 288;
 constexpr uint32_t kDistSyms = 32;
-constexpr uint32_t kLutBits = 10;
+#ifndef NVCOMP_DEFLATE_LUT_BITS
+#define NVCOMP_DEFLATE_LUT_BITS 10 /* A/B: 9 frees 1 KiB of LDS per wave (16 instead of 14 waves per CU), more symbols go the slow way */
+#endif
+constexpr uint32_t kLutBits = NVCOMP_DEFLATE_LUT_BITS;
 constexpr uint32_t kDistLutBits = 8;
 constexpr uint32_t kClLutBits = 7; /* the code-length code: at most 7 bits, always decoded by lookup */
 constexpr uint32_t kRunMax = 255;  /* literal bytes per sequence record (8 bits of the record) */
@@ -365,31 +368,64 @@ __device__ __forceinline__ uint64_t bits_at(const lzw::InRing& ir, uint32_t p)
  */
 __device__ __forceinline__ uint32_t decode_at(const Code& ll, const Code& dd, uint64_t w, uint32_t& value, uint32_t& dist)
 {
+  /* straight-line: both lookups are made whatever the first one says, so that the four positions a lane decodes
+   * speculatively have their LDS reads in flight together */
   const uint32_t e = ll.lut[(uint32_t)w & ((1u << kLutBits) - 1u)];
   const uint32_t len = e & 15u, sym = e >> 4;
-  value = sym;
-  dist = 0;
-  if (len == 0 || sym == 256 || sym > 285) {
-    return 0;
+  const bool is_lit = sym < 256;
+  const bool is_len = sym > 256 && sym <= 285;
+  const bool plain = sym < 265 || sym >= 285;
+  const uint32_t k = plain ? 0u : (sym - 261) >> 2;
+  const uint32_t base = sym < 265 ? sym - 254 : sym >= 285 ? 258u : ((4 + ((sym - 261) & 3u)) << k) + 3;
+  const uint32_t mlen = base + ((uint32_t)(w >> len) & ((1u << k) - 1u));
+  const uint32_t used = len + k; /* <= 20 */
+  const uint32_t e2 = dd.lut[(uint32_t)(w >> used) & ((1u << kDistLutBits) - 1u)];
+  const uint32_t len2 = e2 & 15u, dsym = e2 >> 4;
+  const uint32_t k2 = dsym < 4 ? 0u : (dsym >> 1) - 1;
+  const uint32_t dbase = dsym < 4 ? dsym + 1 : ((2 + (dsym & 1u)) << (k2 & 15u)) + 1;
+  const uint32_t used2 = used + len2;
+  const uint32_t far = dbase + ((uint32_t)(w >> used2) & ((1u << (k2 & 15u)) - 1u));
+  const bool pair_ok = is_len && len2 != 0 && dsym <= 29;
+  value = is_lit ? sym : mlen;
+  dist = is_lit ? 0u : far;
+  return len == 0 ? 0u : is_lit ? len : pair_ok ? used2 + k2 : 0u;
+}
+
+/* The same wave-uniformly for the symbol at bit position p, codes longer than the lookups included (canonical walk).
+ * 0: end of block or an illegal symbol -- the symbol-at-a-time decoder deals with those. */
+__device__ __forceinline__ uint32_t uniform_symbol(
+    const lzw::InRing& ir, const Code& ll, const Code& dd, uint32_t p, uint32_t& value, uint32_t& dist)
+{
+  const uint64_t w = wave::uniform64(bits_at(ir, p));
+  const uint32_t e = wave::uniform(ll.lut[(uint32_t)w & ((1u << kLutBits) - 1u)]);
+  uint32_t len = e & 15u, sym = e >> 4;
+  value = 0, dist = 0;
+  if (len == 0) {
+    sym = slow_symbol(ll, (uint32_t)w, len);
   }
   if (sym < 256) {
+    value = sym;
     return len;
+  }
+  if (sym == 256 || sym > 285) {
+    return 0;
   }
   const bool plain = sym < 265 || sym == 285;
   const uint32_t k = plain ? 0u : (sym - 261) >> 2;
   const uint32_t base = sym < 265 ? sym - 254 : sym == 285 ? 258u : ((4 + ((sym - 261) & 3u)) << k) + 3;
-  uint32_t used = len;
-  value = base + ((uint32_t)(w >> used) & ((1u << k) - 1u));
-  used += k;
-  const uint32_t e2 = dd.lut[(uint32_t)(w >> used) & ((1u << kDistLutBits) - 1u)];
-  const uint32_t len2 = e2 & 15u, dsym = e2 >> 4;
-  if (len2 == 0 || dsym > 29) {
+  value = base + ((uint32_t)(w >> len) & ((1u << k) - 1u));
+  uint32_t used = len + k;
+  const uint32_t e2 = wave::uniform(dd.lut[(uint32_t)(w >> used) & ((1u << kDistLutBits) - 1u)]);
+  uint32_t len2 = e2 & 15u, dsym = e2 >> 4;
+  if (len2 == 0) {
+    dsym = slow_symbol(dd, (uint32_t)(w >> used), len2);
+  }
+  if (dsym > 29) {
     return 0;
   }
   used += len2;
   const uint32_t k2 = dsym < 4 ? 0u : (dsym >> 1) - 1;
-  const uint32_t dbase = dsym < 4 ? dsym + 1 : ((2 + (dsym & 1u)) << k2) + 1;
-  dist = dbase + ((uint32_t)(w >> used) & ((1u << k2) - 1u));
+  dist = (dsym < 4 ? dsym + 1 : ((2 + (dsym & 1u)) << k2) + 1) + ((uint32_t)(w >> used) & ((1u << k2) - 1u));
   return used + k2;
 }
 
@@ -450,6 +486,8 @@ __device__ __forceinline__ uint32_t scan_round(
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   uint32_t tokpos = 0; /* lane k: bit position of the round's k-th symbol */
+  bool told = false;   /* ... which was decoded wave-uniformly (a long code): its fields are here */
+  uint32_t told_value = 0, told_dist = 0;
   uint32_t t = 0;
   stuck = false;
   const uint32_t cap = 64 - f.n; /* a symbol makes at most one record */
@@ -476,15 +514,26 @@ __device__ __forceinline__ uint32_t scan_round(
     const uint32_t last = wave::read_lane(pos, count - 1);
     const uint32_t sel = last & 3u;
     const uint32_t v = sel == 0 ? c.nx[0] : sel == 1 ? c.nx[1] : sel == 2 ? c.nx[2] : c.nx[3];
-    const uint32_t d = wave::read_lane(v, last >> 2);
-    if (d == 0) {
-      count -= 1; /* the last one cannot be told: it is not part of the round */
+    uint32_t d = wave::read_lane(v, last >> 2);
+    uint32_t uval = 0, udist = 0;
+    bool resolved = false;
+    if (d == 0) { /* the lookups could not tell: a long code is walked here, the chain goes on */
+      d = uniform_symbol(ir, ll, dd, c.wb + last, uval, udist);
+      resolved = d != 0;
+      if (!resolved) {
+        count -= 1; /* end of block, or illegal: not part of the round */
+      }
     }
     const uint32_t room = cap - t;
     const uint32_t take = count < room ? count : room;
     const uint32_t shifted = t ? wave::shuffle(pos, (lane - t) & 63u) : pos;
     if (lane >= t && lane < t + take) {
       tokpos = c.wb + shifted;
+    }
+    if (resolved && take == count && lane == t + count - 1) {
+      told = true;
+      told_value = uval;
+      told_dist = udist;
     }
     t += take;
     if (take < count) {
@@ -505,6 +554,10 @@ __device__ __forceinline__ uint32_t scan_round(
   const bool mine0 = lane < t;
   if (mine0) {
     (void)decode_at(ll, dd, bits_at(ir, tokpos), value, dist);
+  }
+  if (told) {
+    value = told_value;
+    dist = told_dist;
   }
   const bool is_match0 = mine0 && dist != 0;
   const uint32_t size = mine0 ? (is_match0 ? value : 1u) : 0u;
@@ -783,18 +836,28 @@ __device__ __forceinline__ uint32_t decode_chunk(
         const uint32_t at = b.bit_pos() >> 3;
         lzw::in_ensure(ir, at & ~3u, (at & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
       }
-      bool one_symbol = SIZE_ONLY; /* SIZE_ONLY: the whole block symbol by symbol; else: what the round could not tell */
+      bool one_symbol = SIZE_ONLY; /* SIZE_ONLY: the whole block symbol by symbol; else: what the rounds could not tell */
       if (!SIZE_ONLY) {
-        if (f.run >= kRunClose) {
-          close_sequence<SIZE_ONLY>(f, 0, 0);
-        }
-        if (!f.carried) {
-          const uint32_t q = scan_round(sc, f, ir, ll, dd, b.bit_pos(), one_symbol);
-          b.seek_bit(ir, q);
-          if (b.byte_pos() > stream_end) {
-            bad = true;
+        /* rounds until the batch is nearly full (the executor costs the same for 20 records as for 64), a symbol
+         * cannot be told, or the stream ring has to move on */
+        uint32_t q = b.bit_pos();
+        for (;;) {
+          if (f.run >= kRunClose) {
+            close_sequence<SIZE_ONLY>(f, 0, 0);
+          }
+          if (f.carried || f.n > 40 || f.bytes + f.run > lzw::kBatchMax - 320 || (q >> 3) + 256 > ir.hi + (ir.hi >= ir.vend ? 4096u : 0u)) {
             break;
           }
+          const uint32_t from = q;
+          q = scan_round(sc, f, ir, ll, dd, q, one_symbol);
+          if (one_symbol || q == from || (q >> 3) > stream_end) {
+            break;
+          }
+        }
+        b.seek_bit(ir, q);
+        if (b.byte_pos() > stream_end) {
+          bad = true;
+          break;
         }
       }
       while (one_symbol && !f.carried) {

@@ -74,6 +74,10 @@ def test_examples_on_gpu(built_programs, sample_files):
     assert "all scenarios passed" in run(["examples/bin/high_level_quickstart_example"])
     assert "round-tripped in place" in run(["examples/bin/low_level_quickstart_example"])
     assert "equals zlib's crc32()" in run(["examples/bin/standard_crc_checksum"])
+    for algo in ("1", "2", "gzip"):  # zlib on the CPU -> the DEFLATE / gzip decoder (examples/deflate_cpu_compression.cu,
+        out = run(["examples/bin/deflate_cpu_compression", "-a", algo, "-f", sample_files["table.txt"],  # gzip_gpu_decompression.cu)
+                   sample_files["floats.csv"]])
+        assert "decompression validated" in out
     if os.path.exists(os.path.join(REPO, "examples/bin/lz4_cpu_compression")):
         out = run(["examples/bin/lz4_cpu_compression", "-f", sample_files["table.txt"], sample_files["floats.csv"]])
         assert "decompression validated" in out
@@ -85,6 +89,7 @@ def test_examples_on_gpu(built_programs, sample_files):
 @pytest.mark.parametrize("prog,extra", [("benchmark_lz4_chunked", []), ("benchmark_snappy_chunked", []),
                                          ("benchmark_cascaded_chunked", ["-t", "int"]),
                                          ("benchmark_ans_chunked", []), ("benchmark_bitcomp_chunked", ["-t", "int"]),
+                                         ("benchmark_deflate_chunked", ["-a", "1"]),
                                          ("benchmark_bitcomp_chunked", ["-t", "int", "-a", "1"])])
 def test_chunked_harness_on_gpu(built_programs, sample_files, prog, extra):
     f = sample_files["col.int32"] if "cascaded" in prog or "bitcomp" in prog else sample_files["table.txt"]
