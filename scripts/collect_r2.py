@@ -35,7 +35,7 @@ def main():
     digest = bench.library_source_digest("lz4")
     src, dst = os.path.join(REPO, "gpurun_out", tag), os.path.join(REPO, "profiles")
     lines = {}
-    for name in ("lz4", "snappy", "cascaded", "bitcomp", "ans"):
+    for name in ("lz4", "snappy", "cascaded", "bitcomp", "ans", "deflate"):
         p = os.path.join(src, f"bench_{name}.json")
         if os.path.exists(p) and os.path.getsize(p):
             lines[name] = json.load(open(p))
@@ -44,7 +44,7 @@ def main():
         p = os.path.join(src, name)
         if os.path.exists(p):
             shutil.copy(p, os.path.join(dst, f"{prefix}_{name}"))
-    for sub, out in (("trace", "lz4"), ("trace_snappy", "snappy")):
+    for sub, out in (("trace", "lz4"), ("trace_snappy", "snappy"), ("trace_deflate", "deflate")):
         p = find(src, sub, "*kernel_stats.csv")
         if p:
             shutil.copy(p, os.path.join(dst, f"{prefix}_kernel_stats_{out}.csv"))
@@ -84,6 +84,25 @@ def main():
             "write_bytes_counted": int(write), "algorithmic_bytes": lines["snappy"]["roofline"]["algorithmic_bytes_per_launch"],
             "note": f"as pmc_traffic.json, for snappy_decompress_window_kernel, session {tag}",
         }, open(os.path.join(dst, "pmc_traffic_snappy.json"), "w"), indent=1)
+    dp = {}
+    for name in ("insts", "fetch", "write"):
+        p = find(src, "pmc_deflate_" + name, "*counter_collection.csv")
+        if p:
+            dp.update(counters(p, "deflate_decompress_kernel"))
+    if "deflate" in lines and dp:
+        cfg = lines["deflate"]["config"]
+        ddigest = bench.library_source_digest("deflate")
+        dp["_note"] = (f"per launch of deflate_decompress_kernel<checked, raw>, {cfg['chunks_per_gpu']} chunks x 64 KiB; separate "
+                       "rocprofv3 --pmc passes; FETCH_SIZE / WRITE_SIZE in KB; lib_source_digest " + ddigest)
+        json.dump(dp, open(os.path.join(dst, prefix + "_pmc_deflate.json"), "w"), indent=1)
+        if "FETCH_SIZE" in dp and "WRITE_SIZE" in dp:
+            fetch, write = dp["FETCH_SIZE"] * 1024, dp["WRITE_SIZE"] * 1024
+            json.dump({
+                "algo": "deflate", "dataset": cfg["dataset"], "chunks_per_gpu": cfg["chunks_per_gpu"], "lib_source_digest": ddigest,
+                "hbm_bytes_per_launch": int(fetch + 0.5 * cfg["compressed_bytes_per_gpu"] + write), "fetch_bytes_counted": int(fetch),
+                "write_bytes_counted": int(write), "algorithmic_bytes": lines["deflate"]["roofline"]["algorithmic_bytes_per_launch"],
+                "note": f"as pmc_traffic.json, for deflate_decompress_kernel, session {tag}",
+            }, open(os.path.join(dst, "pmc_traffic_deflate.json"), "w"), indent=1)
     for name in ("pytest_gpu.log", "rc.txt"):
         p = os.path.join(src, name)
         if os.path.exists(p):
