@@ -437,10 +437,7 @@ def run_case(args, ctx):
             "traffic": traffic,
             "traffic_source": traffic_source,
         }
-    if rank == 0 and world == 1 and not args.no_extras and args.algo == "deflate":
-        result["extras"] = {"gpu_compress": "nvcompBatchedDeflateCompressAsync writes stored blocks (ratio 1.0): not timed; "
-                                            "the scope row is the decoder (SURVEY.md 8 f4)"}
-    elif rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras:
         # compress leg on the GPU (ratio + compress GB/s of the metric string); not part of `value`
         from nvcomp_amd.batched import empty_batch
 

@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256) gzip_size_kernel(
   uncompressed_bytes[chunk] = size;
 }
 
-__global__ void __launch_bounds__(64 * kEncWaves) deflate_compress_kernel(
+__global__ void __launch_bounds__(64 * kEncWaves, 4) deflate_compress_kernel(
     const void* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
     size_t max_chunk_bytes,
@@ -115,6 +115,7 @@ __global__ void __launch_bounds__(64 * kEncWaves) deflate_compress_kernel(
     void* const* __restrict__ out_ptrs,
     size_t* out_bytes)
 {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kEncWaves][deflate::kEncLdsPerWave];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
   const size_t chunk = (size_t)blockIdx.x * kEncWaves + w;
   if (chunk >= batch_size) {
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(64 * kEncWaves) deflate_compress_kernel(
   const size_t n64 = wave::uniform64(in_bytes[chunk]);
   /* a chunk larger than the caller declared would overrun the output slot sized from GetMaxOutputChunkSize: it is
    * not compressed, its size reads 0 */
-  const uint32_t produced = n64 > max_chunk_bytes ? 0u : deflate::encode_chunk(src, (uint32_t)n64, dst);
+  const uint32_t produced = n64 > max_chunk_bytes ? 0u : deflate::encode_chunk(src, (uint32_t)n64, dst, lds[w]);
   if (wave::lane_id() == 0) {
     out_bytes[chunk] = produced;
   }
@@ -297,7 +298,7 @@ nvcompStatus_t nvcompBatchedDeflateCompressGetTempSize(
   if (max_uncompressed_chunk_bytes > nvcompDeflateCompressionMaxAllowedChunkSize) {
     return nvcompErrorChunkSizeTooLarge;
   }
-  *temp_bytes = 0;
+  *temp_bytes = 0; /* hash table, input image and bit staging live in LDS */
   return nvcompSuccess;
 }
 

@@ -25,6 +25,11 @@
  *   uint32_t lit_offset(lit_len)                                  where the literal bytes start inside the sequence
  *   uint32_t match(dst, lit, lit_len, offset, match_len)          whole wave, any size; returns bytes written
  *   uint32_t tail(dst, lit, lit_len)                              whole wave: the final literal-only part
+ *   kReach                                                        largest match distance of the format
+ * A format whose sequences do not start at byte boundaries (DEFLATE: deflate/deflate_encode.hip.h) sets kStream and
+ * takes the sequences through a sink of its own instead -- `Sink* sink`, the last argument of encode_chunk():
+ *   void window(sink, src, sel, lit_from, lit_len, match_len, offset, before8, before_ok)   per lane, one step's sequences
+ *   void one(sink, lit, lit_len, offset, match_len)                                          whole wave, one sequence
  */
 #pragma once
 
@@ -235,13 +240,13 @@ struct Probe
 
 /* Candidate from the hash table entry `low` (position mod 65536): the nearest position below pos with these low
  * bits; `ok` = it exists and is within the formats' 65535-byte reach. */
-__device__ __forceinline__ uint32_t table_candidate(uint32_t pos, uint32_t low, bool& ok)
+__device__ __forceinline__ uint32_t table_candidate(uint32_t pos, uint32_t low, bool& ok, uint32_t reach = 65535u)
 {
   uint32_t cand = (pos & ~0xffffu) | low;
   if (cand >= pos) {
     cand -= 0x10000u;
   }
-  ok = cand < pos && pos - cand <= 65535u; /* cand wraps to a huge value when there is none */
+  ok = cand < pos && pos - cand <= reach; /* cand wraps to a huge value when there is none */
   return cand;
 }
 
@@ -270,7 +275,7 @@ __device__ __forceinline__ uint32_t neighbour_repeat(uint32_t word, bool eligibl
  */
 __device__ __forceinline__ Probe probe_fast(
     const uint8_t* __restrict__ src, const uint16_t* table, const Around& me, uint32_t pos, bool eligible, uint32_t match_end,
-    uint32_t stride)
+    uint32_t stride, uint32_t reach = 65535u)
 {
   Probe p;
   p.word = me.fwd[0];
@@ -279,7 +284,7 @@ __device__ __forceinline__ Probe probe_fast(
   bool ok;
   {
     const uint32_t slot = hash4(p.word);
-    p.cand = table_candidate(pos, table[slot], ok);
+    p.cand = table_candidate(pos, table[slot], ok, reach);
 #if NVCOMP_LZM_TAGS
     ok = ok && ((const uint8_t*)(table + kHashSize))[slot] == tag4(p.word);
 #endif
@@ -344,7 +349,8 @@ __device__ __forceinline__ Probe probe_fast(
 
 /* The same probe with nothing assumed about how far a position may read: the last windows of a chunk. */
 __device__ __forceinline__ Probe probe_safe(
-    const uint8_t* __restrict__ src, const uint16_t* table, uint32_t pos, bool eligible, uint32_t match_end, uint32_t stride)
+    const uint8_t* __restrict__ src, const uint16_t* table, uint32_t pos, bool eligible, uint32_t match_end, uint32_t stride,
+    uint32_t reach = 65535u)
 {
   Probe p;
   p.word = 0;
@@ -356,7 +362,7 @@ __device__ __forceinline__ Probe probe_safe(
   if (eligible) {
     p.word = lz::ld_u32(src + pos);
     const uint32_t slot = hash4(p.word);
-    p.cand = table_candidate(pos, table[slot], ok);
+    p.cand = table_candidate(pos, table[slot], ok, reach);
 #if NVCOMP_LZM_TAGS
     ok = ok && ((const uint8_t*)(table + kHashSize))[slot] == tag4(p.word);
 #endif
@@ -400,10 +406,10 @@ __device__ __forceinline__ Probe probe_safe(
  * int"): matches then start at element boundaries only and lie a whole number of elements back, a window covers
  * 64 x STRIDE bytes per step, and the neighbour compares look 1, 2, 4 and 8 ELEMENTS back.
  */
-template <class Emitter, uint32_t STRIDE = 1>
+template <class Emitter, uint32_t STRIDE = 1, class Sink = uint32_t>
 __device__ __forceinline__ uint32_t encode_chunk(
     const uint8_t* __restrict__ src, uint32_t n, uint8_t* dst, uint16_t* table, uint8_t* image, uint32_t last_start,
-    uint32_t match_end, bool any_match)
+    uint32_t match_end, bool any_match, Sink* sink = nullptr)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   for (uint32_t i = lane; i < kTableU16 / 2; i += 64) {
@@ -483,9 +489,9 @@ __device__ __forceinline__ uint32_t encode_chunk(
           load_around(ahead, src, pos + kWin, true);
         }
 #endif
-        pr = probe_fast(src, table, me, pos, eligible, match_end, STRIDE);
+        pr = probe_fast(src, table, me, pos, eligible, match_end, STRIDE, Emitter::kReach);
       } else {
-        pr = probe_safe(src, table, pos, eligible, match_end, STRIDE);
+        pr = probe_safe(src, table, pos, eligible, match_end, STRIDE, Emitter::kReach);
       }
       const uint32_t word = pr.word;
       const uint32_t cand = pr.cand;
@@ -534,7 +540,11 @@ __device__ __forceinline__ uint32_t encode_chunk(
             mcand -= back;
             len0 += back;
           }
-          op += Emitter::match(dst + op, src + anchor, mpos - anchor, mpos - mcand, len0);
+          if constexpr (Emitter::kStream) {
+            Emitter::one(*sink, src + anchor, mpos - anchor, mpos - mcand, len0);
+          } else {
+            op += Emitter::match(dst + op, src + anchor, mpos - anchor, mpos - mcand, len0);
+          }
           const uint32_t next = mpos + len0;
           anchor = next;
           /* the next window starts right behind the match (at the next element boundary): every one of its 64
@@ -582,79 +592,85 @@ __device__ __forceinline__ uint32_t encode_chunk(
         my_len += sel ? back : 0u;
       }
       const uint32_t offset = pos - cand;
-      const uint32_t size = sel ? Emitter::seq_size(lit_len, my_len, offset) : 0;
-      const uint32_t incl = wave::scan_add_inclusive(size);
-      const uint32_t total = wave::read_lane(incl, 63);
-      uint8_t* my_dst = dst + op + incl - size;
-      const bool small = sel && Emitter::is_small(lit_len, my_len);
-      LZM_T(5); /* sizes + scan */
-      if (small) {
-        Emitter::emit_small_header(my_dst, lit_len, offset, my_len);
-      }
-      LZM_T(6); /* headers */
-      /* literal runs of the small sequences. Up to 8 bytes (nearly all of them on text) are the bytes right before
-       * the lane's position, which a fast window holds in registers: no load at all. Longer runs are read back,
-       * four dwords in flight per round (a load-store pair per step costs a memory round trip per step). */
-      {
+      if constexpr (Emitter::kStream) {
         const uint32_t run = sel ? pos - prev_end : 0; /* before the match grew backwards: the run ends at pos */
-        uint8_t* ld = my_dst + Emitter::lit_offset(lit_len);
-        const bool from_regs = small && fast && run <= 8 && pos >= kBackMax;
-        if (from_regs && lit_len != 0) {
-          const uint64_t before = (((uint64_t)me.pre[1] << 32) | me.pre[0]) >> (8 * (8 - run));
-          if (lit_len >= 4) {
-            lz::st_u32(ld, (uint32_t)before);
-            lz::st_u32(ld + lit_len - 4, (uint32_t)(before >> (8 * (lit_len - 4))));
-          } else {
-            ld[0] = (uint8_t)before;
+        Emitter::window(*sink, src, sel, prev_end, lit_len, my_len, offset, ((uint64_t)me.pre[1] << 32) | me.pre[0],
+                        fast && run <= 8 && pos >= kBackMax, run);
+      } else {
+        const uint32_t size = sel ? Emitter::seq_size(lit_len, my_len, offset) : 0;
+        const uint32_t incl = wave::scan_add_inclusive(size);
+        const uint32_t total = wave::read_lane(incl, 63);
+        uint8_t* my_dst = dst + op + incl - size;
+        const bool small = sel && Emitter::is_small(lit_len, my_len);
+        LZM_T(5); /* sizes + scan */
+        if (small) {
+          Emitter::emit_small_header(my_dst, lit_len, offset, my_len);
+        }
+        LZM_T(6); /* headers */
+        /* literal runs of the small sequences. Up to 8 bytes (nearly all of them on text) are the bytes right before
+         * the lane's position, which a fast window holds in registers: no load at all. Longer runs are read back,
+         * four dwords in flight per round (a load-store pair per step costs a memory round trip per step). */
+        {
+          const uint32_t run = sel ? pos - prev_end : 0; /* before the match grew backwards: the run ends at pos */
+          uint8_t* ld = my_dst + Emitter::lit_offset(lit_len);
+          const bool from_regs = small && fast && run <= 8 && pos >= kBackMax;
+          if (from_regs && lit_len != 0) {
+            const uint64_t before = (((uint64_t)me.pre[1] << 32) | me.pre[0]) >> (8 * (8 - run));
+            if (lit_len >= 4) {
+              lz::st_u32(ld, (uint32_t)before);
+              lz::st_u32(ld + lit_len - 4, (uint32_t)(before >> (8 * (lit_len - 4))));
+            } else {
+              ld[0] = (uint8_t)before;
+              if (lit_len > 1) {
+                ld[1] = (uint8_t)(before >> 8);
+              }
+              if (lit_len > 2) {
+                ld[2] = (uint8_t)(before >> 16);
+              }
+            }
+          }
+          const bool from_mem = small && !from_regs && lit_len != 0;
+          const uint8_t* ls = src + prev_end;
+          const bool lit4 = from_mem && lit_len >= 4;
+          for (uint32_t base = 0; wave::ballot(lit4 && lit_len > base) != 0; base += 16) {
+            if (lit4 && lit_len > base) {
+              const uint32_t lastoff = lit_len - 4;
+              uint32_t v[4];
+  #pragma unroll
+              for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t o = base + 4 * i < lastoff ? base + 4 * i : lastoff;
+                v[i] = wave::gload_u32(ls + o);
+              }
+  #pragma unroll
+              for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t o = base + 4 * i < lastoff ? base + 4 * i : lastoff;
+                lz::st_u32(ld + o, v[i]);
+              }
+            }
+          }
+          if (from_mem && lit_len < 4) {
+            ld[0] = ls[0];
             if (lit_len > 1) {
-              ld[1] = (uint8_t)(before >> 8);
+              ld[1] = ls[1];
             }
             if (lit_len > 2) {
-              ld[2] = (uint8_t)(before >> 16);
+              ld[2] = ls[2];
             }
           }
         }
-        const bool from_mem = small && !from_regs && lit_len != 0;
-        const uint8_t* ls = src + prev_end;
-        const bool lit4 = from_mem && lit_len >= 4;
-        for (uint32_t base = 0; wave::ballot(lit4 && lit_len > base) != 0; base += 16) {
-          if (lit4 && lit_len > base) {
-            const uint32_t lastoff = lit_len - 4;
-            uint32_t v[4];
-#pragma unroll
-            for (uint32_t i = 0; i < 4; ++i) {
-              const uint32_t o = base + 4 * i < lastoff ? base + 4 * i : lastoff;
-              v[i] = wave::gload_u32(ls + o);
-            }
-#pragma unroll
-            for (uint32_t i = 0; i < 4; ++i) {
-              const uint32_t o = base + 4 * i < lastoff ? base + 4 * i : lastoff;
-              lz::st_u32(ld + o, v[i]);
-            }
-          }
+        LZM_T(7); /* literals */
+        /* the few sequences a single lane cannot write: long literal run (first of the step,
+         * after match-less windows) or long match (last of the step) */
+        uint64_t big = wave::ballot(sel && !small);
+        while (big) {
+          const uint32_t j = wave::ctz64(big);
+          big &= big - 1;
+          const uint32_t jdst = op + wave::read_lane(incl - size, j);
+          const uint32_t jlit = wave::read_lane(prev_end, j);
+          Emitter::match(dst + jdst, src + jlit, wave::read_lane(lit_len, j), wave::read_lane(offset, j), wave::read_lane(my_len, j));
         }
-        if (from_mem && lit_len < 4) {
-          ld[0] = ls[0];
-          if (lit_len > 1) {
-            ld[1] = ls[1];
-          }
-          if (lit_len > 2) {
-            ld[2] = ls[2];
-          }
-        }
+        op += total;
       }
-      LZM_T(7); /* literals */
-      /* the few sequences a single lane cannot write: long literal run (first of the step,
-       * after match-less windows) or long match (last of the step) */
-      uint64_t big = wave::ballot(sel && !small);
-      while (big) {
-        const uint32_t j = wave::ctz64(big);
-        big &= big - 1;
-        const uint32_t jdst = op + wave::read_lane(incl - size, j);
-        const uint32_t jlit = wave::read_lane(prev_end, j);
-        Emitter::match(dst + jdst, src + jlit, wave::read_lane(lit_len, j), wave::read_lane(offset, j), wave::read_lane(my_len, j));
-      }
-      op += total;
       LZM_T(8); /* cooperative sequences */
       anchor = lit_from;
       /* the next window starts 64 positions on whatever the last match covers of it (so that the data requested
@@ -668,7 +684,11 @@ __device__ __forceinline__ uint32_t encode_chunk(
       }
     }
   }
-  op += Emitter::tail(dst + op, src + anchor, n - anchor);
+  if constexpr (Emitter::kStream) {
+    Emitter::one(*sink, src + anchor, n - anchor, 0, 0);
+  } else {
+    op += Emitter::tail(dst + op, src + anchor, n - anchor);
+  }
   LZM_T(9);
   LZM_PROF_END;
   return op;

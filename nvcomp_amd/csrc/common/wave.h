@@ -272,6 +272,12 @@ __device__ __forceinline__ uint32_t pk_add_sat255(uint32_t a, uint32_t b)
   return __builtin_bit_cast(uint32_t, x);
 }
 
+/* v_bfrev_b32 */
+__device__ __forceinline__ uint32_t bit_reverse(uint32_t v)
+{
+  return __builtin_bitreverse32(v);
+}
+
 /* Byte permute (v_perm_b32): result byte i = byte sel[i] of the 8-byte value hi:lo (0-3 = lo, 4-7 = hi). */
 __device__ __forceinline__ uint32_t perm_bytes(uint32_t hi, uint32_t lo, uint32_t sel)
 {

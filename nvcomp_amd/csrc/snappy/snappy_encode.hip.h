@@ -83,6 +83,8 @@ __device__ __forceinline__ uint32_t emit_copy(uint8_t* dst, uint32_t offset, uin
 
 struct Emitter
 {
+  static constexpr bool kStream = false;   /* sequences start at byte boundaries: lzm writes them where they go */
+  static constexpr uint32_t kReach = 65535; /* 2-byte offsets */
   static __device__ __forceinline__ uint32_t literal_size(uint32_t len)
   {
     if (len == 0) {

@@ -15,7 +15,7 @@ sys.path.insert(0, REPO)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--algo", default="cascaded", choices=["lz4", "snappy", "cascaded", "bitcomp", "ans"])
+    ap.add_argument("--algo", default="cascaded", choices=["lz4", "snappy", "cascaded", "bitcomp", "ans", "deflate"])
     ap.add_argument("--dataset", default="int32")
     ap.add_argument("--mib", type=int, default=256)
     ap.add_argument("--unique-mib", type=int, default=16)
@@ -31,7 +31,7 @@ def main():
 
     lib = nvcomp_amd.load_library()
     dev = nvcomp_amd.TorchDevice("cuda:0")
-    fmt = {"lz4": "LZ4", "snappy": "Snappy", "cascaded": "Cascaded", "bitcomp": "Bitcomp", "ans": "ANS"}[a.algo]
+    fmt = {"lz4": "LZ4", "snappy": "Snappy", "cascaded": "Cascaded", "bitcomp": "Bitcomp", "ans": "ANS", "deflate": "Deflate"}[a.algo]
     opts = tuple(int(x) for x in a.opts.split(",")) if a.algo in ("cascaded", "bitcomp") else None
     codec = nvcomp_amd.BatchedCodec(lib, dev, fmt, opts)
     unique = a.unique_mib << 20

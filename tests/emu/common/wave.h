@@ -197,6 +197,14 @@ inline uint32_t pk_add_sat255(uint32_t a, uint32_t b)
   hi = hi < 255u ? hi : 255u;
   return lo | (hi << 16);
 }
+inline uint32_t bit_reverse(uint32_t v)
+{
+  v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+  v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+  v = ((v >> 4) & 0x0f0f0f0fu) | ((v & 0x0f0f0f0fu) << 4);
+  return __builtin_bswap32(v);
+}
+
 inline uint32_t perm_bytes(uint32_t hi, uint32_t lo, uint32_t sel)
 {
   const uint64_t v = ((uint64_t)hi << 32) | lo;

@@ -320,3 +320,41 @@ def test_compressor_round_trip(backend):
         assert zlib.decompress(cc.tobytes(), -15) == c.tobytes()
     check(backend, "Deflate", chunks, comp)
     assert backend.codec("Deflate").compress([chunks[0]], max_chunk=1000)[0].size == 0  # larger than declared: refused
+
+
+@pytest.mark.parametrize("name", CLASSES)
+def test_compressor_classes(backend, name):
+    """LZ77 + fixed Huffman codes: every class decodes with zlib, compresses at least as well as the byte-oriented LZ
+    formats do, and never expands by more than the stored form's five bytes per block."""
+    size = 4 * 65536 if backend.name == "gpu" else 65536 + 3333
+    data = datasets.CLASSES[name](size, 6)
+    chunks = datasets.split_chunks(data)
+    codec = backend.codec("Deflate")
+    comp = codec.compress(chunks)
+    for cc, c in zip(comp, chunks):
+        assert zlib.decompress(cc.tobytes(), -15) == c.tobytes()
+        assert cc.size <= c.size + 5 * (c.size // 65535 + 1)
+    ratio = data.size / sum(c.size for c in comp)
+    floor = {"text": 1.9, "table": 1.7, "float_csv": 1.5, "float32": 1.5, "int32": 30.0, "lowcard": 1.7, "zeros": 100.0, "noise": 0.999}[name]
+    assert ratio >= floor, ratio
+    check(backend, "Deflate", chunks, comp)
+
+
+def test_compressor_edges(backend):
+    """Chunks shorter than a window, runs far longer than the 258 a match may have (cut into pieces of at least 3),
+    literal runs of thousands of bytes in front of a match, matches at the 32 768 limit of the format."""
+    rng = np.random.RandomState(23)
+    noise = rng.randint(0, 256, 40000, dtype=np.uint8)
+    text = datasets.CLASSES["text"](70000, 2)
+    chunks = [np.frombuffer(b"abcabcabcabcabcabcabcabc", np.uint8), text[:15], text[:16], text[:17], text[:63], text[:64], text[:65],
+              np.full(65536, 0x90, np.uint8), np.full(259 + 3, 7, np.uint8), np.full(258 + 258 + 2, 9, np.uint8),
+              np.concatenate([noise[:30000], text[:2000], noise[:30000]]),           # far match: distance 32 000
+              np.concatenate([noise[:33000], noise[:32000]]),                         # distance 33 000: out of reach
+              np.concatenate([noise[:5000], np.zeros(300, np.uint8), noise[5000:9000]])]
+    codec = backend.codec("Deflate")
+    comp = codec.compress(chunks)
+    for cc, c in zip(comp, chunks):
+        assert zlib.decompress(cc.tobytes(), -15) == c.tobytes()
+        assert cc.size <= c.size + 5 * (c.size // 65535 + 1)
+    assert comp[7].size < 500 and comp[10].size < 40000  # the run; most of the repeat 32 000 back is found
+    check(backend, "Deflate", chunks, comp)
