@@ -17,7 +17,7 @@ int main(int argc, char** argv)
 {
   try {
     if (argc < 2) {
-      std::cerr << "Usage: benchmark_hlif {lz4|snappy|cascaded|bitcomp|ans} -f FILE [-c chunk] [-g gpu] [-n iters] [-t type] [-r -d -b]"
+      std::cerr << "Usage: benchmark_hlif {lz4|snappy|cascaded|bitcomp|ans|deflate} -f FILE [-c chunk] [-g gpu] [-n iters] [-t type] [-r -d -b]"
                 << std::endl;
       return 1;
     }
@@ -70,8 +70,10 @@ int main(int argc, char** argv)
                                        NoComputeNoVerify));
     } else if (format == "ans") {
       manager.reset(new ANSManager(chunk, nvcompBatchedANSOpts_t{}, stream, gpu, NoComputeNoVerify));
+    } else if (format == "deflate") {
+      manager.reset(new DeflateManager(chunk, nvcompBatchedDeflateDefaultOpts, stream, gpu, NoComputeNoVerify));
     } else {
-      throw std::runtime_error("ERROR: unsupported format \"" + format + "\" (this build: lz4, snappy, cascaded, bitcomp, ans)");
+      throw std::runtime_error("ERROR: unsupported format \"" + format + "\" (this build: lz4, snappy, cascaded, bitcomp, ans, deflate)");
     }
     const std::vector<char> data = util::read_file(file);
     const size_t n = data.size();

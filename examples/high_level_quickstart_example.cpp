@@ -216,6 +216,7 @@ int main()
     header_is_authoritative(d_in.p, data);
     multi_buffer_streamed<LZ4Manager>(d_in.p, data, nvcompBatchedLZ4Opts_t{NVCOMP_TYPE_CHAR}, 1 << 16);
     multi_buffer_streamed<SnappyManager>(d_in.p, data, nvcompBatchedSnappyDefaultOpts, 1 << 15);
+    multi_buffer_streamed<DeflateManager>(d_in.p, data, nvcompBatchedDeflateDefaultOpts, 1 << 16);
     multi_buffer_streamed<CascadedManager>(d_in.p, data, nvcompBatchedCascadedDefaultOpts, 1 << 16);
     multi_buffer_streamed<BitcompManager>(d_in.p, data, nvcompBatchedBitcompFormatOpts{0, NVCOMP_TYPE_INT}, 1 << 16);
     multi_buffer_streamed<ANSManager>(d_in.p, data, nvcompBatchedANSOpts_t{}, 1 << 16);

@@ -6,6 +6,7 @@
 #include "nvcomp/ans.hpp"
 #include "nvcomp/bitcomp.hpp"
 #include "nvcomp/cascaded.hpp"
+#include "nvcomp/deflate.hpp"
 #include "nvcomp/lz4.hpp"
 #include "nvcomp/nvcompManager.hpp"
 #include "nvcomp/nvcompManagerFactory.hpp"

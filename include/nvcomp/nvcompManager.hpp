@@ -85,7 +85,7 @@ struct nvcompManagerBase
 class BatchedManager : public nvcompManagerBase
 {
 public:
-  enum Format : uint32_t { kLZ4 = 1, kSnappy = 2, kCascaded = 3, kBitcomp = 4, kANS = 5 };
+  enum Format : uint32_t { kLZ4 = 1, kSnappy = 2, kCascaded = 3, kBitcomp = 4, kANS = 5, kDeflate = 6 };
 
   BatchedManager(Format format, size_t uncomp_chunk_size, const void* format_opts, size_t format_opts_bytes,
                  hipStream_t user_stream, int device_id, ChecksumPolicy checksum_policy);

@@ -313,7 +313,8 @@ struct ManagerImpl
   X(kSnappy, Snappy, nvcompBatchedSnappyOpts_t)            \
   X(kCascaded, Cascaded, nvcompBatchedCascadedOpts_t)      \
   X(kBitcomp, Bitcomp, nvcompBatchedBitcompFormatOpts)     \
-  X(kANS, ANS, nvcompBatchedANSOpts_t)
+  X(kANS, ANS, nvcompBatchedANSOpts_t)                     \
+  X(kDeflate, Deflate, nvcompBatchedDeflateOpts_t)
 
   nvcompStatus_t max_chunk(size_t* out) const
   {

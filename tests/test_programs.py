@@ -106,7 +106,7 @@ def test_chunked_harness_on_gpu(built_programs, sample_files, prog, extra):
 
 @pytest.mark.gpu
 def test_hlif_and_synth_benchmarks_on_gpu(built_programs, sample_files):
-    for fmt in ("lz4", "snappy", "cascaded", "bitcomp", "ans"):
+    for fmt in ("lz4", "snappy", "cascaded", "bitcomp", "ans", "deflate"):
         numeric = fmt in ("cascaded", "bitcomp")
         f = sample_files["col.int32"] if numeric else sample_files["table.txt"]
         out = run(["benchmarks/bin/benchmark_hlif", fmt, "-f", f, "-n", "2"] + (["-t", "int"] if numeric else []))
@@ -127,7 +127,7 @@ def test_allgather_program_oversubscribed(built_programs, sample_files):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("algo", ["lz4", "snappy", "cascaded", "bitcomp", "ans"])
+@pytest.mark.parametrize("algo", ["lz4", "snappy", "cascaded", "bitcomp", "ans", "deflate"])
 def test_bench_contract_on_gpu(algo):
     """bench.py prints exactly one JSON line with the driver's fields plus `roofline` and `cpu_baseline`, measures
     through HIP events on its stream and verifies every decoded byte (small workload: 64 MiB per step)."""
