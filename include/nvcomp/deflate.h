@@ -25,7 +25,8 @@ extern "C" {
  * examples/deflate_cpu_decompression.cu:61 */
 typedef struct
 {
-  int algo; /* compressor effort, 0 (fastest) .. 2; every value produces standard streams */
+  int algo; /* compressor setting 0 .. 2 as in the reference's harness; every value produces standard streams (this
+             * build: one compressor -- greedy LZ77, fixed Huffman codes -- for all three) */
 } nvcompBatchedDeflateOpts_t;
 
 static const nvcompBatchedDeflateOpts_t nvcompBatchedDeflateDefaultOpts = {0};
