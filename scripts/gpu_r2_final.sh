@@ -40,7 +40,7 @@ for algo in lz4 snappy; do for mib in 16 256 1024 4096; do
   u=$(( mib < 64 ? mib : 64 ))
   timeout 400 $B --algo $algo --mib-per-gpu $mib --unique-mib $u --steps 10 --warmup 2 2>> "$OUT/nsweep.err" >> "$OUT/nsweep.jsonl"
 done; done
-for spec in "lz4 silesia_style" "lz4 text" "lz4 int32" "lz4 mortgage_col0_like" "snappy silesia_style" "snappy int32" "cascaded int32" "cascaded example_float_columns" "ans silesia_style"; do
+for spec in "lz4 silesia_style" "lz4 text" "lz4 int32" "lz4 mortgage_col0_like" "snappy silesia_style" "snappy int32" "cascaded int32" "cascaded example_float_columns" "ans silesia_style" "deflate silesia_style" "deflate int32"; do
   set -- $spec
   timeout 200 python scripts/bench_roundtrip.py --algo $1 --dataset $2 --unique-mib 32 --mib 1024 >> "$OUT/roundtrip.jsonl" 2>> "$OUT/roundtrip.err"
 done
