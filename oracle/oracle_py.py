@@ -23,6 +23,7 @@ _PORT = os.path.join(_HERE, "liboracle.so")
 _REF = os.path.join(_HERE, "_ref", "libcpucodecs.so")
 
 LZ4_DEC, SNAPPY_DEC, LZ4_ENC, SNAPPY_ENC, LZ4_ENC_HC = 0, 1, 2, 3, 4
+ZLIB_INFLATE, ZLIB_DEFLATE_1, ZLIB_DEFLATE_9 = 5, 6, 7  # the _ref shim only (zlib: the CPU peer of the DEFLATE path)
 CASCADED_DEC, BITCOMP_DEC, ANS_DEC = 4, 5, 6  # oracle_batch_run only (the port library; 4 means HC in the reference shim)
 
 _u8p = C.POINTER(C.c_uint8)

@@ -8,7 +8,8 @@
  * container's own (/opt/conda: lz4 1.9.3, snappy 1.1.8); nothing from
  * /root/reference is compiled or copied here because the reference ships no
  * codec source (README.md:10) -- its codec path is "unbuildable" and these
- * libraries are the published implementations of the same wire formats.
+ * libraries are the published implementations of the same wire formats. zlib (examples/deflate_cpu_compression.cu:69-104,
+ * examples/deflate_cpu_decompression.cu:128-170: the CPU peer of the DEFLATE path) is bound the same way.
  *
  * TEST INFRASTRUCTURE ONLY: used to pin the oracle sources, to make golden vectors
  * (scripts/make_golden.py), to prepare CPU-compressed inputs for tests and
@@ -17,6 +18,8 @@
 #include <lz4.h>
 #include <lz4hc.h>
 #include <snappy-c.h>
+#include <string.h>
+#include <zlib.h>
 
 #include "batch.h"
 
@@ -79,14 +82,54 @@ int ref_snappy_uncompressed_length(const uint8_t* s, size_t n, size_t* out)
   return snappy_uncompressed_length((const char*)s, n, out) != SNAPPY_OK;
 }
 
-/* codec: 0 lz4 dec, 1 snappy dec, 2 lz4 enc (default), 3 snappy enc, 4 lz4 enc HC level 12 */
+/* raw DEFLATE streams (windowBits -15), as the reference's examples make and read them */
+static int r_zlib_inflate(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out)
+{
+  z_stream zs;
+  memset(&zs, 0, sizeof(zs));
+  *out = 0;
+  if (inflateInit2(&zs, -15) != Z_OK) {
+    return 1;
+  }
+  zs.next_in = (Bytef*)s;
+  zs.avail_in = (uInt)n;
+  zs.next_out = d;
+  zs.avail_out = (uInt)cap;
+  const int r = inflate(&zs, Z_FINISH);
+  *out = r == Z_STREAM_END ? zs.total_out : 0;
+  inflateEnd(&zs);
+  return r != Z_STREAM_END;
+}
+static int zlib_deflate_level(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out, int level)
+{
+  z_stream zs;
+  memset(&zs, 0, sizeof(zs));
+  *out = 0;
+  if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+    return 1;
+  }
+  zs.next_in = (Bytef*)s;
+  zs.avail_in = (uInt)n;
+  zs.next_out = d;
+  zs.avail_out = (uInt)cap;
+  const int r = deflate(&zs, Z_FINISH);
+  *out = r == Z_STREAM_END ? zs.total_out : 0;
+  deflateEnd(&zs);
+  return r != Z_STREAM_END;
+}
+static int r_zlib_deflate1(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out) { return zlib_deflate_level(s, n, d, cap, out, 1); }
+static int r_zlib_deflate9(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out) { return zlib_deflate_level(s, n, d, cap, out, 9); }
+
+/* codec: 0 lz4 dec, 1 snappy dec, 2 lz4 enc (default), 3 snappy enc, 4 lz4 enc HC level 12, 5 zlib inflate (raw),
+ * 6 zlib deflate level 1 (raw), 7 zlib deflate level 9 (raw) */
 double ref_batch_run(
     int codec, int threads, int repeats, size_t n_chunks,
     const uint8_t* const* in_ptrs, const size_t* in_sizes,
     uint8_t* const* out_ptrs, const size_t* out_caps, size_t* out_sizes, int* errors)
 {
-  static const batch_codec_fn table[5] = {r_lz4_dec, r_snappy_dec, r_lz4_enc, r_snappy_enc, r_lz4_enc_hc};
-  if (codec < 0 || codec > 4) {
+  static const batch_codec_fn table[8] = {r_lz4_dec, r_snappy_dec, r_lz4_enc, r_snappy_enc, r_lz4_enc_hc,
+                                          r_zlib_inflate, r_zlib_deflate1, r_zlib_deflate9};
+  if (codec < 0 || codec > 7) {
     return -1.0;
   }
   return batch_run_generic(
