@@ -78,3 +78,42 @@ def test_corrupt_streams_are_contained(backend, lz_path, oracle, fmt):
         # these decoders validate regardless of `device_statuses`; for LZ4/Snappy a NULL status array turns the
         # bounds checks off by contract ("OOB error checking is disabled", doc/lowlevel_c_quickstart.md:140)
         codec.decompress(bad, caps, checked=False, comp_align=align, out_align=align)
+
+
+@pytest.mark.parametrize("fmt", ["Deflate", "Gzip"])
+def test_corrupt_deflate_streams_are_contained(backend, fmt):
+    """The same for DEFLATE / gzip against zlib: what zlib accepts must decode to the same bytes; what it rejects may be
+    rejected or (trailing garbage, incomplete code sets zlib is stricter about) accepted -- never a write past the slot,
+    never a hang."""
+    import zlib
+
+    rng = np.random.RandomState(4242 if fmt == "Deflate" else 2424)
+    n = 160 if backend.name == "gpu" else 48
+    gens = [datasets.text, datasets.int32_column, datasets.lowcard, datasets.table_rows, datasets.float_columns]
+    chunks = [gens[i % 5](int(rng.choice([300, 4096, 20000, 65536])), i) for i in range(n)]
+    wbits = -15 if fmt == "Deflate" else 15 | 16
+    good = []
+    for i, c in enumerate(chunks):
+        o = zlib.compressobj([1, 6, 9][i % 3], zlib.DEFLATED, wbits, 8, [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY][(i // 3) % 3])
+        good.append(np.frombuffer(o.compress(c.tobytes()) + o.flush(), dtype=np.uint8))
+    bad = [damage(rng, g) for g in good]
+    caps = [c.size for c in chunks]
+    codec = backend.codec(fmt)
+    outs, actual, status = codec.decompress(bad, caps)  # canaries checked inside
+    accepted = 0
+    for i, (b, cap) in enumerate(zip(bad, caps)):
+        try:
+            d = zlib.decompressobj(wbits)
+            ref = d.decompress(b.tobytes(), cap + 1)
+            ok = d.eof and len(ref) <= cap
+        except zlib.error:
+            ok = False
+        if status[i] == NvcompStatus.Success:
+            accepted += 1
+            assert actual[i] <= cap
+            if ok:
+                assert actual[i] == len(ref) and outs[i][: len(ref)].tobytes() == ref, f"{fmt} chunk {i}"
+        else:
+            assert actual[i] == 0
+            assert not ok or fmt == "Gzip", f"{fmt} chunk {i}: rejected a stream zlib reads"  # (gzip: we also check ISIZE of cut members)
+    assert 0 < accepted < n
