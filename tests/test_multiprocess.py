@@ -31,6 +31,14 @@ def test_sharded_decompress_two_ranks():
     assert res["config"]["chunks_per_gpu"] == 2
 
 
+def test_sharded_deflate_two_ranks():
+    """The same path for the DEFLATE decoder: the chunks partition across ranks exactly like LZ4's."""
+    res = launch(["--no-cpu-baseline", "--no-extras", "--algo", "deflate"], 29624)
+    assert res["n_gpus"] == 2 and "deflate" in res["metric"]
+    digests = res["config"]["shard_digests"]
+    assert len(digests) == 2 and digests[0] != digests[1]
+
+
 def test_allgather_two_ranks():
     res = launch(["--allgather"], 29622)
     assert res["n_gpus"] == 2 and "all-gather" in res["metric"]
