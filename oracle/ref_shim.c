@@ -82,14 +82,22 @@ int ref_snappy_uncompressed_length(const uint8_t* s, size_t n, size_t* out)
   return snappy_uncompressed_length((const char*)s, n, out) != SNAPPY_OK;
 }
 
-/* raw DEFLATE streams (windowBits -15), as the reference's examples make and read them */
+/* raw DEFLATE streams (windowBits -15), as the reference's examples make and read them. The stream states are kept
+ * per thread and reset per chunk (a fresh deflateInit2 per 64 KiB chunk spends most of its time in malloc when 256
+ * threads do it at once): the figure that favours the CPU. */
 static int r_zlib_inflate(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out)
 {
-  z_stream zs;
-  memset(&zs, 0, sizeof(zs));
+  static __thread z_stream zs;
+  static __thread int ready = 0;
   *out = 0;
-  if (inflateInit2(&zs, -15) != Z_OK) {
-    return 1;
+  if (!ready) {
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, -15) != Z_OK) {
+      return 1;
+    }
+    ready = 1;
+  } else {
+    inflateReset(&zs);
   }
   zs.next_in = (Bytef*)s;
   zs.avail_in = (uInt)n;
@@ -97,24 +105,29 @@ static int r_zlib_inflate(const uint8_t* s, size_t n, uint8_t* d, size_t cap, si
   zs.avail_out = (uInt)cap;
   const int r = inflate(&zs, Z_FINISH);
   *out = r == Z_STREAM_END ? zs.total_out : 0;
-  inflateEnd(&zs);
   return r != Z_STREAM_END;
 }
 static int zlib_deflate_level(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out, int level)
 {
-  z_stream zs;
-  memset(&zs, 0, sizeof(zs));
+  static __thread z_stream zs[10];
+  static __thread int ready[10];
   *out = 0;
-  if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
-    return 1;
+  if (!ready[level]) {
+    memset(&zs[level], 0, sizeof(z_stream));
+    if (deflateInit2(&zs[level], level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+      return 1;
+    }
+    ready[level] = 1;
+  } else {
+    deflateReset(&zs[level]);
   }
-  zs.next_in = (Bytef*)s;
-  zs.avail_in = (uInt)n;
-  zs.next_out = d;
-  zs.avail_out = (uInt)cap;
-  const int r = deflate(&zs, Z_FINISH);
-  *out = r == Z_STREAM_END ? zs.total_out : 0;
-  deflateEnd(&zs);
+  z_stream* z = &zs[level];
+  z->next_in = (Bytef*)s;
+  z->avail_in = (uInt)n;
+  z->next_out = d;
+  z->avail_out = (uInt)cap;
+  const int r = deflate(z, Z_FINISH);
+  *out = r == Z_STREAM_END ? z->total_out : 0;
   return r != Z_STREAM_END;
 }
 static int r_zlib_deflate1(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out) { return zlib_deflate_level(s, n, d, cap, out, 1); }
