@@ -128,12 +128,40 @@ struct Code
   uint16_t* syms; /* symbols in code order */
 };
 
+/* What a lookup entry says besides symbol << 4 | code length, so that the speculative decoder needs no arithmetic on
+ * the symbol: a length symbol (257..285) is stored as 0x8000 | extra bits << 9 | (symbol - 257) << 4 | code length,
+ * a distance symbol as extra bits << 9 | symbol << 4 | code length. */
+enum : uint32_t { kPlainCode, kLitLenCode, kDistCode };
+
+__device__ __forceinline__ uint32_t lut_entry(uint32_t kind, uint32_t sym, uint32_t len)
+{
+  if (kind == kLitLenCode && sym >= 257 && sym <= 285) {
+    const uint32_t ls = sym - 257;
+    const uint32_t k = ls < 8 || ls == 28 ? 0u : (ls - 4) >> 2;
+    return 0x8000u | (k << 9) | (ls << 4) | len;
+  }
+  if (kind == kDistCode) {
+    const uint32_t k = sym < 4 ? 0u : (sym >> 1) - 1; /* 30, 31: illegal symbols, refused where they are met */
+    return ((k & 15u) << 9) | (sym << 4) | len;
+  }
+  return (sym << 4) | len;
+}
+
+/* the symbol an entry stands for */
+__device__ __forceinline__ uint32_t entry_symbol(uint32_t kind, uint32_t e)
+{
+  if (kind == kLitLenCode) {
+    return e & 0x8000u ? 257 + ((e >> 4) & 31u) : (e >> 4) & 0x1ffu;
+  }
+  return kind == kDistCode ? (e >> 4) & 31u : e >> 4;
+}
+
 /*
  * Build the decoding tables of one canonical Huffman code from its code lengths (lens[0, n), n <= 320 -- 0 = unused
  * symbol). Returns false for an over-subscribed set of lengths. An incomplete set is accepted: a bit pattern
  * without a symbol fails when (if) it is met.
  */
-template <uint32_t LUT_BITS>
+template <uint32_t LUT_BITS, uint32_t KIND>
 __device__ __forceinline__ bool build_code(const Code& code, const uint8_t* lens, uint32_t n)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
@@ -188,7 +216,7 @@ __device__ __forceinline__ bool build_code(const Code& code, const uint8_t* lens
     for (uint32_t l = 1; l <= LUT_BITS; ++l) {
       c |= (e >> (l - 1)) & 1u;
       if (entry == 0 && c - first < count[l]) {
-        entry = ((uint32_t)code.syms[index + (c - first)] << 4) | l;
+        entry = lut_entry(KIND, code.syms[index + (c - first)], l);
       }
       index += count[l];
       first = (first + count[l]) << 1;
@@ -220,12 +248,12 @@ __device__ __forceinline__ uint32_t slow_symbol(const Code& code, uint32_t bits,
   return ~0u;
 }
 
-template <uint32_t LUT_BITS>
+template <uint32_t LUT_BITS, uint32_t KIND>
 __device__ __forceinline__ uint32_t next_symbol(const Code& code, Bits& b, bool& bad)
 {
   const uint32_t e = wave::uniform(code.lut[b.peek(LUT_BITS)]);
   uint32_t len = e & 15u;
-  uint32_t sym = e >> 4;
+  uint32_t sym = entry_symbol(KIND, e);
   if (len == 0) {
     sym = slow_symbol(code, (uint32_t)b.buf, len);
     bad = bad || sym == ~0u;
@@ -369,23 +397,24 @@ __device__ __forceinline__ uint64_t bits_at(const lzw::InRing& ir, uint32_t p)
 __device__ __forceinline__ uint32_t decode_at(const Code& ll, const Code& dd, uint64_t w, uint32_t& value, uint32_t& dist)
 {
   /* straight-line: both lookups are made whatever the first one says, so that the four positions a lane decodes
-   * speculatively have their LDS reads in flight together */
+   * speculatively have their LDS reads in flight together; the entries carry the extra-bit counts (lut_entry) */
   const uint32_t e = ll.lut[(uint32_t)w & ((1u << kLutBits) - 1u)];
-  const uint32_t len = e & 15u, sym = e >> 4;
-  const bool is_lit = sym < 256;
-  const bool is_len = sym > 256 && sym <= 285;
-  const bool plain = sym < 265 || sym >= 285;
-  const uint32_t k = plain ? 0u : (sym - 261) >> 2;
-  const uint32_t base = sym < 265 ? sym - 254 : sym >= 285 ? 258u : ((4 + ((sym - 261) & 3u)) << k) + 3;
-  const uint32_t mlen = base + ((uint32_t)(w >> len) & ((1u << k) - 1u));
+  const uint32_t len = e & 15u;
+  const bool is_len = (e & 0x8000u) != 0;
+  const uint32_t sym = (e >> 4) & 0x1ffu; /* literal / 256 / 286+ when !is_len */
+  const bool is_lit = !is_len && sym < 256;
+  const uint32_t k = is_len ? (e >> 9) & 7u : 0u;
   const uint32_t used = len + k; /* <= 20 */
   const uint32_t e2 = dd.lut[(uint32_t)(w >> used) & ((1u << kDistLutBits) - 1u)];
-  const uint32_t len2 = e2 & 15u, dsym = e2 >> 4;
-  const uint32_t k2 = dsym < 4 ? 0u : (dsym >> 1) - 1;
-  const uint32_t dbase = dsym < 4 ? dsym + 1 : ((2 + (dsym & 1u)) << (k2 & 15u)) + 1;
+  const uint32_t len2 = e2 & 15u, dsym = (e2 >> 4) & 31u, k2 = (e2 >> 9) & 15u;
   const uint32_t used2 = used + len2;
-  const uint32_t far = dbase + ((uint32_t)(w >> used2) & ((1u << (k2 & 15u)) - 1u));
   const bool pair_ok = is_len && len2 != 0 && dsym <= 29;
+  /* the fields (dead code where only the length is wanted: the speculative windows) */
+  const uint32_t ls = (e >> 4) & 31u;
+  const uint32_t base = ls < 8 ? ls + 3 : ls == 28 ? 258u : ((4 + (ls & 3u)) << k) + 3;
+  const uint32_t mlen = base + ((uint32_t)(w >> len) & ((1u << k) - 1u));
+  const uint32_t dbase = dsym < 4 ? dsym + 1 : ((2 + (dsym & 1u)) << k2) + 1;
+  const uint32_t far = dbase + ((uint32_t)(w >> used2) & ((1u << k2) - 1u));
   value = is_lit ? sym : mlen;
   dist = is_lit ? 0u : far;
   return len == 0 ? 0u : is_lit ? len : pair_ok ? used2 + k2 : 0u;
@@ -398,7 +427,7 @@ __device__ __forceinline__ uint32_t uniform_symbol(
 {
   const uint64_t w = wave::uniform64(bits_at(ir, p));
   const uint32_t e = wave::uniform(ll.lut[(uint32_t)w & ((1u << kLutBits) - 1u)]);
-  uint32_t len = e & 15u, sym = e >> 4;
+  uint32_t len = e & 15u, sym = entry_symbol(kLitLenCode, e);
   value = 0, dist = 0;
   if (len == 0) {
     sym = slow_symbol(ll, (uint32_t)w, len);
@@ -416,7 +445,7 @@ __device__ __forceinline__ uint32_t uniform_symbol(
   value = base + ((uint32_t)(w >> len) & ((1u << k) - 1u));
   uint32_t used = len + k;
   const uint32_t e2 = wave::uniform(dd.lut[(uint32_t)(w >> used) & ((1u << kDistLutBits) - 1u)]);
-  uint32_t len2 = e2 & 15u, dsym = e2 >> 4;
+  uint32_t len2 = e2 & 15u, dsym = entry_symbol(kDistCode, e2);
   if (len2 == 0) {
     dsym = slow_symbol(dd, (uint32_t)(w >> used), len2);
   }
@@ -771,7 +800,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
               lens[lane] = (uint8_t)mine;
             }
             wave::sync();
-            if (!build_code<kClLutBits>(dd, lens, 19)) {
+            if (!build_code<kClLutBits, kPlainCode>(dd, lens, 19)) {
               bad = true;
               break;
             }
@@ -783,7 +812,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
                 lzw::in_ensure(ir, b.byte_pos() & ~3u, (b.byte_pos() & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
               }
               b.refill(ir);
-              const uint32_t sym = next_symbol<kClLutBits>(dd, b, bad);
+              const uint32_t sym = next_symbol<kClLutBits, kPlainCode>(dd, b, bad);
               uint32_t rep = 1, val = sym;
               if (sym == 16) {
                 rep = 3 + b.take(2);
@@ -822,7 +851,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
               break;
             }
           }
-          if (!build_code<kLutBits>(ll, lens, kLitLenSyms) || !build_code<kDistLutBits>(dd, lens + kLitLenSyms, n_d)) {
+          if (!build_code<kLutBits, kLitLenCode>(ll, lens, kLitLenSyms) || !build_code<kDistLutBits, kDistCode>(dd, lens + kLitLenSyms, n_d)) {
             bad = true;
             break;
           }
@@ -870,7 +899,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
         }
         one_symbol = SIZE_ONLY;
         b.refill(ir);
-        const uint32_t sym = next_symbol<kLutBits>(ll, b, bad);
+        const uint32_t sym = next_symbol<kLutBits, kLitLenCode>(ll, b, bad);
         if (sym < 256) {
           if (f.run == kRunMax) {
             close_sequence<SIZE_ONLY>(f, 0, 0);
@@ -896,7 +925,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
           mlen = ((4 + ((sym - 261) & 3u)) << k) + 3 + b.take(k);
         }
         b.refill(ir);
-        const uint32_t dsym = next_symbol<kDistLutBits>(dd, b, bad);
+        const uint32_t dsym = next_symbol<kDistLutBits, kDistCode>(dd, b, bad);
         if (dsym > 29 || bad) {
           bad = true;
           break;

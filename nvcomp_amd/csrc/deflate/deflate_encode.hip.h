@@ -278,15 +278,23 @@ struct Emitter
     const uint32_t size = mine ? 8 * lit_len + nine + pair_bits : 0u;
     const uint32_t incl = wave::scan_add_inclusive(size);
     uint32_t p = s.bits + incl - size;
-    /* literals, one code word per turn */
-    for (uint32_t i = 0; wave::ballot(mine && i < lit_len) != 0; ++i) {
+    /* literals, three code words (at most 27 bits) per turn and per LDS update */
+    for (uint32_t i = 0; wave::ballot(mine && i < lit_len) != 0; i += 3) {
       if (mine && i < lit_len) {
-        uint32_t n;
-        const uint32_t code = literal_code((uint32_t)lo & 0xffu, n);
-        put(s, p, code, n);
-        p += n;
-        lo = (lo >> 8) | (hi << 56);
-        hi >>= 8;
+        uint32_t word = 0, filled = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 3; ++j) {
+          if (i + j < lit_len) {
+            uint32_t n;
+            const uint32_t code = literal_code((uint32_t)lo & 0xffu, n);
+            word |= code << filled;
+            filled += n;
+            lo = (lo >> 8) | (hi << 56);
+            hi >>= 8;
+          }
+        }
+        put(s, p, word, filled);
+        p += filled;
       }
     }
     if (mine) {
