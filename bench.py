@@ -564,16 +564,19 @@ def deflate_cpu_baseline(oracle, comp, chunks, threads, unique):
 def library_source_digest(algo="lz4"):
     """sha256 over the kernel sources of one codec: PMC traffic recorded for one build of a kernel must not be replayed
     beside the timing of another. LZ4 / Snappy: their own directories + common/ (the shared
-    decoder); the own formats: their own directory."""
+    decoder) + their api/*_api.hip (the kernels' launch shapes); DEFLATE likewise; the own formats: their own directory."""
     import glob
     import hashlib
 
     dirs = ["lz4", "snappy", "common"] if algo in ("lz4", "snappy") else ["deflate", "common"] if algo == "deflate" else [algo]
     h = hashlib.sha256()
-    for d in dirs:
-        for path in sorted(glob.glob(os.path.join(REPO, "nvcomp_amd", "csrc", d, "*.h*"))):
-            h.update(os.path.relpath(path, REPO).encode())
-            h.update(open(path, "rb").read())
+    paths = [p for d in dirs for p in sorted(glob.glob(os.path.join(REPO, "nvcomp_amd", "csrc", d, "*.h*")))]
+    if algo in ("lz4", "snappy", "deflate"):
+        paths += [os.path.join(REPO, "nvcomp_amd", "csrc", "api", f"{a}_api.hip")
+                  for a in (("lz4", "snappy") if algo in ("lz4", "snappy") else ("deflate",))]
+    for path in paths:
+        h.update(os.path.relpath(path, REPO).encode())
+        h.update(open(path, "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -42,8 +42,11 @@ constexpr int snappy_decode_variant()
   return NVCOMP_AMD_SNAPPY_VARIANT;
 }
 
-template <bool CHECKED>
-__global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_WAVES_PER_SIMD) snappy_decompress_window_kernel(
+/* WAVES = chunks (waves) per workgroup: one for batches that fill the card, api/lz4_api.hip has the measurements. */
+constexpr size_t kSingleWaveFromBatch = 8192;
+
+template <bool CHECKED, unsigned WAVES = kDecWaves>
+__global__ void __launch_bounds__(64 * WAVES, NVCOMP_LZW_WAVES_PER_SIMD) snappy_decompress_window_kernel(
     const void* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes,
     const size_t* out_caps,
@@ -52,9 +55,9 @@ __global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_WAVES_PER_SIMD) sna
     void* const* __restrict__ out_ptrs,
     nvcompStatus_t* statuses)
 {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kDecWaves][lzg::kLdsPerWave];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES][lzg::kLdsPerWave];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
-  const size_t chunk = (size_t)blockIdx.x * kDecWaves + w;
+  const size_t chunk = (size_t)blockIdx.x * WAVES + w;
   if (chunk >= batch_size) {
     return;
   }
@@ -306,6 +309,19 @@ nvcompStatus_t nvcompBatchedSnappyDecompressAsync(
     return launch_status();
   }
 #endif
+  if (variant == 0 && batch_size >= kSingleWaveFromBatch) {
+    const dim3 grid1((unsigned)batch_size), block1(64);
+    if (checked) {
+      hipLaunchKernelGGL((snappy_decompress_window_kernel<true, 1>), grid1, block1, 0, stream, device_compressed_ptrs,
+                         device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,
+                         batch_size, device_uncompressed_ptrs, device_statuses);
+    } else {
+      hipLaunchKernelGGL((snappy_decompress_window_kernel<false, 1>), grid1, block1, 0, stream, device_compressed_ptrs,
+                         device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,
+                         batch_size, device_uncompressed_ptrs, device_statuses);
+    }
+    return launch_status();
+  }
   if (variant == 0) {
     if (checked) {
       hipLaunchKernelGGL((snappy_decompress_window_kernel<true>), grid, block, 0, stream, device_compressed_ptrs,

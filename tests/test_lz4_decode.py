@@ -125,6 +125,17 @@ def test_corrupt_streams_do_not_escape(backend, lz_path, oracle):
             assert status[i] != NvcompStatus.Success and actual[i] == 0
 
 
+def test_batch_that_fills_the_card(backend, oracle):
+    """From 8 192 chunks on the window decoder runs in one-wave workgroups (api/lz4_api.hip: kSingleWaveFromBatch): the
+    same kernel body, another launch shape. Small chunks keep the test cheap."""
+    backend.lib.nvcompAmdSetLZIndexMinBatch(1 << 60)  # the single-kernel decoder, whatever the batch size
+    data = datasets.silesia_style(8200 * 384, 3)
+    chunks = datasets.split_chunks(data, 384)
+    assert len(chunks) >= 8192
+    check_roundtrip(backend, oracle, chunks, cpu_compress(oracle, chunks))
+    backend.lib.nvcompAmdSetLZIndexMinBatch(1)
+
+
 def test_get_decompress_size(backend, oracle):
     data = datasets.silesia_style(4 * 65536, 2, chunk=16384)
     chunks = datasets.split_chunks(data, 16384) + [np.zeros(0, np.uint8)]

@@ -37,6 +37,14 @@ def test_decode_classes(backend, lz_path, oracle, name):
     check_decode(backend, oracle, chunks, cpu_compress(oracle, chunks))
 
 
+def test_batch_that_fills_the_card(backend, oracle):
+    """From 8 192 chunks on the window decoder runs in one-wave workgroups (api/snappy_api.hip)."""
+    data = datasets.silesia_style(8200 * 384, 4)
+    chunks = datasets.split_chunks(data, 384)
+    assert len(chunks) >= 8192
+    check_decode(backend, oracle, chunks, cpu_compress(oracle, chunks))
+
+
 def test_reference_synth_workload(backend, lz_path, oracle):
     """benchmark_snappy_synth: 64 KiB chunks of uniform bytes in [0,3], the same device array
     passed as capacity and as actual-size output (benchmarks/benchmark_snappy_synth.cpp:244-245)."""
