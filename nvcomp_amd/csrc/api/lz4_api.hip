@@ -43,9 +43,12 @@ constexpr uint32_t kMaxOutCap = 1u << 26;
 #endif
 
 /* WAVES = chunks (waves) per workgroup. A workgroup's LDS is released when its last wave ends and the chunks of a batch
- * take very different times: one-wave workgroups keep a full card fuller (65 536 chunks: 507 -> 518 GB/s, Snappy 350 ->
- * 372); a batch that does not fill the card spreads better in workgroups of four (4 096 chunks: 282 against 263). */
-constexpr size_t kSingleWaveFromBatch = 8192;
+ * take very different times: one-wave workgroups keep a full card fuller on the mix (65 536 chunks: 507 -> 518 GB/s;
+ * Snappy 350 -> 372) -- but batches of uniformly fast chunks lose 7 % to the four times as many workgroup launches
+ * (int32 column, 16 384 chunks: 639 -> 585; Snappy 608 -> 598), and a batch that does not fill the card spreads
+ * better in workgroups of four (4 096 chunks: 282 against 263). Snappy takes the trade from 8 192 chunks on
+ * (api/snappy_api.hip), LZ4 does not: kSingleWaveFromBatch is out of reach. */
+constexpr size_t kSingleWaveFromBatch = ~(size_t)0;
 
 template <bool CHECKED, int ABLATE = 0, unsigned WAVES = kDecWaves>
 __global__ void __launch_bounds__(64 * WAVES, NVCOMP_LZW_WAVES_PER_SIMD) lz4_decompress_window_kernel(

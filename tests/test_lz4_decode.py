@@ -125,9 +125,9 @@ def test_corrupt_streams_do_not_escape(backend, lz_path, oracle):
             assert status[i] != NvcompStatus.Success and actual[i] == 0
 
 
-def test_batch_that_fills_the_card(backend, oracle):
-    """From 8 192 chunks on the window decoder runs in one-wave workgroups (api/lz4_api.hip: kSingleWaveFromBatch): the
-    same kernel body, another launch shape. Small chunks keep the test cheap."""
+def test_batch_of_many_small_chunks(backend, oracle):
+    """8 200 chunks in one launch (the Snappy decoder changes its launch shape there, api/snappy_api.hip; LZ4 keeps its
+    own: both must decode every chunk)."""
     backend.lib.nvcompAmdSetLZIndexMinBatch(1 << 60)  # the single-kernel decoder, whatever the batch size
     data = datasets.silesia_style(8200 * 384, 3)
     chunks = datasets.split_chunks(data, 384)
