@@ -13,7 +13,7 @@
 #include "common/log.h"
 
 #include "deflate/deflate_decode.hip.h"
-#include "deflate/deflate_encode.hip.h"
+#include "deflate/deflate_encode_dynamic.hip.h"
 
 namespace {
 
@@ -25,7 +25,7 @@ namespace {
 #endif
 constexpr unsigned kDecWaves = NVCOMP_DEFLATE_WAVES_PER_BLOCK;
 constexpr unsigned kDecWavesPerSimd = deflate::kLdsPerWave <= 10240 ? 4 : 3;
-constexpr unsigned kEncWaves = 4;
+constexpr unsigned kEncWaves = 2; /* 10 / 11.3 KiB of LDS per wave: 16 / 14 waves per CU in workgroups of two */
 constexpr uint32_t kMaxOutCap = 1u << 26;
 
 template <bool CHECKED, uint32_t FLAGS>
@@ -107,7 +107,10 @@ __global__ void __launch_bounds__(256) gzip_size_kernel(
   uncompressed_bytes[chunk] = size;
 }
 
-__global__ void __launch_bounds__(64 * kEncWaves, 4) deflate_compress_kernel(
+/* DYNAMIC: per-chunk Huffman codes (nvcompBatchedDeflateOpts_t.algo >= 1: two runs of the match finder and a code
+ * construction per chunk) instead of the fixed code (algo 0). */
+template <bool DYNAMIC>
+__global__ void __launch_bounds__(64 * kEncWaves, DYNAMIC ? 3 : 4) deflate_compress_kernel(
     const void* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
     size_t max_chunk_bytes,
@@ -115,7 +118,7 @@ __global__ void __launch_bounds__(64 * kEncWaves, 4) deflate_compress_kernel(
     void* const* __restrict__ out_ptrs,
     size_t* out_bytes)
 {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kEncWaves][deflate::kEncLdsPerWave];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kEncWaves][DYNAMIC ? deflate::kDynLdsPerWave : deflate::kEncLdsPerWave];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
   const size_t chunk = (size_t)blockIdx.x * kEncWaves + w;
   if (chunk >= batch_size) {
@@ -126,7 +129,9 @@ __global__ void __launch_bounds__(64 * kEncWaves, 4) deflate_compress_kernel(
   const size_t n64 = wave::uniform64(in_bytes[chunk]);
   /* a chunk larger than the caller declared would overrun the output slot sized from GetMaxOutputChunkSize: it is
    * not compressed, its size reads 0 */
-  const uint32_t produced = n64 > max_chunk_bytes ? 0u : deflate::encode_chunk(src, (uint32_t)n64, dst, lds[w]);
+  const uint32_t produced = n64 > max_chunk_bytes ? 0u
+                            : DYNAMIC ? deflate::encode_chunk_dynamic(src, (uint32_t)n64, dst, lds[w])
+                                      : deflate::encode_chunk(src, (uint32_t)n64, dst, lds[w]);
   if (wave::lane_id() == 0) {
     out_bytes[chunk] = produced;
   }
@@ -353,9 +358,14 @@ nvcompStatus_t nvcompBatchedDeflateCompressAsync(
     return nvcompErrorInvalidValue;
   }
   clear_stale_error();
-  hipLaunchKernelGGL(deflate_compress_kernel, dim3((unsigned)((batch_size + kEncWaves - 1) / kEncWaves)), dim3(64 * kEncWaves), 0,
-                     stream, device_uncompressed_ptrs, device_uncompressed_bytes, max_uncompressed_chunk_bytes, batch_size,
-                     device_compressed_ptrs, device_compressed_bytes);
+  const dim3 grid((unsigned)((batch_size + kEncWaves - 1) / kEncWaves)), block(64 * kEncWaves);
+  if (format_opts.algo == 0) {
+    hipLaunchKernelGGL(deflate_compress_kernel<false>, grid, block, 0, stream, device_uncompressed_ptrs, device_uncompressed_bytes,
+                       max_uncompressed_chunk_bytes, batch_size, device_compressed_ptrs, device_compressed_bytes);
+  } else {
+    hipLaunchKernelGGL(deflate_compress_kernel<true>, grid, block, 0, stream, device_uncompressed_ptrs, device_uncompressed_bytes,
+                       max_uncompressed_chunk_bytes, batch_size, device_compressed_ptrs, device_compressed_bytes);
+  }
   return launch_status();
 }
 

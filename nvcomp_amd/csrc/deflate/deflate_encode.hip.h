@@ -145,19 +145,40 @@ __device__ __forceinline__ uint32_t literal_code(uint32_t b, uint32_t& n)
   return rev(b < 144 ? 0x30u + b : 0x190u + (b - 144), n);
 }
 
-/* <length 3..258, distance 1..32768>: the whole pair as one bit string of at most 31 bits */
+/* length 3..258 -> symbol 257..285, its extra-bit count and value */
+__device__ __forceinline__ uint32_t length_symbol(uint32_t mlen, uint32_t& k, uint32_t& extra)
+{
+  const uint32_t m = mlen - 3;
+  k = 0, extra = 0;
+  if (mlen == 258) {
+    return 285;
+  }
+  if (m < 8) {
+    return 257 + m;
+  }
+  k = 29 - (uint32_t)__builtin_clz(m); /* floor(log2 m) - 2 */
+  extra = m & ((1u << k) - 1u);
+  return 261 + 4 * k + ((m >> k) & 3u);
+}
+
+/* distance 1..32768 -> symbol 0..29, its extra-bit count and value */
+__device__ __forceinline__ uint32_t distance_symbol(uint32_t dist, uint32_t& k, uint32_t& extra)
+{
+  const uint32_t d = dist - 1;
+  k = 0, extra = 0;
+  if (d < 4) {
+    return d;
+  }
+  k = 30 - (uint32_t)__builtin_clz(d); /* floor(log2 d) - 1 */
+  extra = d & ((1u << k) - 1u);
+  return 2 * k + 2 + ((d >> k) & 1u);
+}
+
+/* <length 3..258, distance 1..32768> in the fixed code: the whole pair as one bit string of at most 31 bits */
 __device__ __forceinline__ uint32_t match_code(uint32_t mlen, uint32_t dist, uint32_t& n)
 {
-  /* length symbol 257..285 and its extra bits */
-  const uint32_t m = mlen - 3;
-  uint32_t k = 0, sym = 257 + m, extra = 0;
-  if (mlen == 258) {
-    sym = 285;
-  } else if (m >= 8) {
-    k = 29 - (uint32_t)__builtin_clz(m); /* floor(log2 m) - 2 */
-    sym = 261 + 4 * k + ((m >> k) & 3u);
-    extra = m & ((1u << k) - 1u);
-  }
+  uint32_t k, extra;
+  const uint32_t sym = length_symbol(mlen, k, extra);
   uint32_t bits, used;
   if (sym < 280) { /* 256..279: 7 bits, 0000000.. */
     bits = rev(sym - 256, 7);
@@ -168,15 +189,9 @@ __device__ __forceinline__ uint32_t match_code(uint32_t mlen, uint32_t dist, uin
   }
   bits |= extra << used;
   used += k;
-  /* distance symbol 0..29 (5 bits) and its extra bits */
-  const uint32_t d = dist - 1;
-  uint32_t k2 = 0, dsym = d, dextra = 0;
-  if (d >= 4) {
-    k2 = 30 - (uint32_t)__builtin_clz(d); /* floor(log2 d) - 1 */
-    dsym = 2 * k2 + 2 + ((d >> k2) & 1u);
-    dextra = d & ((1u << k2) - 1u);
-  }
-  bits |= rev(dsym, 5) << used;
+  uint32_t k2, dextra;
+  const uint32_t dsym = distance_symbol(dist, k2, dextra);
+  bits |= rev(dsym, 5) << used; /* distances: 5 bits each */
   used += 5;
   bits |= dextra << used;
   n = used + k2;

@@ -32,7 +32,7 @@ def main():
     lib = nvcomp_amd.load_library()
     dev = nvcomp_amd.TorchDevice("cuda:0")
     fmt = {"lz4": "LZ4", "snappy": "Snappy", "cascaded": "Cascaded", "bitcomp": "Bitcomp", "ans": "ANS", "deflate": "Deflate"}[a.algo]
-    opts = tuple(int(x) for x in a.opts.split(",")) if a.algo in ("cascaded", "bitcomp") else None
+    opts = tuple(int(x) for x in a.opts.split(",")) if a.algo in ("cascaded", "bitcomp") else (int(a.opts),) if a.algo == "deflate" and a.opts.isdigit() else None
     codec = nvcomp_amd.BatchedCodec(lib, dev, fmt, opts)
     unique = a.unique_mib << 20
     gen = getattr(datasets, a.dataset) if hasattr(datasets, a.dataset) else datasets.CLASSES[a.dataset]

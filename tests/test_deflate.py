@@ -322,25 +322,30 @@ def test_compressor_round_trip(backend):
     assert backend.codec("Deflate").compress([chunks[0]], max_chunk=1000)[0].size == 0  # larger than declared: refused
 
 
+@pytest.mark.parametrize("algo", [0, 1, 2])
 @pytest.mark.parametrize("name", CLASSES)
-def test_compressor_classes(backend, name):
-    """LZ77 + fixed Huffman codes: every class decodes with zlib, compresses at least as well as the byte-oriented LZ
-    formats do, and never expands by more than the stored form's five bytes per block."""
+def test_compressor_classes(backend, name, algo):
+    """algo 0: LZ77 + the fixed Huffman code; algo 1, 2: per-chunk (dynamic) codes. Every class decodes with zlib,
+    compresses at least as well as the byte-oriented LZ formats do (dynamic codes: about what zlib level 1 reaches),
+    and never expands by more than the stored form's five bytes per block."""
     size = 4 * 65536 if backend.name == "gpu" else 65536 + 3333
     data = datasets.CLASSES[name](size, 6)
     chunks = datasets.split_chunks(data)
-    codec = backend.codec("Deflate")
+    codec = backend.codec("Deflate", (algo,))
     comp = codec.compress(chunks)
     for cc, c in zip(comp, chunks):
         assert zlib.decompress(cc.tobytes(), -15) == c.tobytes()
         assert cc.size <= c.size + 5 * (c.size // 65535 + 1)
     ratio = data.size / sum(c.size for c in comp)
     floor = {"text": 1.9, "table": 1.7, "float_csv": 1.5, "float32": 1.5, "int32": 30.0, "lowcard": 1.7, "zeros": 100.0, "noise": 0.999}[name]
+    if algo:
+        floor = {"text": 2.5, "table": 2.2, "float_csv": 2.2, "float32": 2.0, "int32": 40.0, "lowcard": 2.8, "zeros": 200.0, "noise": 0.999}[name]
     assert ratio >= floor, ratio
     check(backend, "Deflate", chunks, comp)
 
 
-def test_compressor_edges(backend):
+@pytest.mark.parametrize("algo", [0, 1])
+def test_compressor_edges(backend, algo):
     """Chunks shorter than a window, runs far longer than the 258 a match may have (cut into pieces of at least 3),
     literal runs of thousands of bytes in front of a match, matches at the 32 768 limit of the format."""
     rng = np.random.RandomState(23)
@@ -350,11 +355,36 @@ def test_compressor_edges(backend):
               np.full(65536, 0x90, np.uint8), np.full(259 + 3, 7, np.uint8), np.full(258 + 258 + 2, 9, np.uint8),
               np.concatenate([noise[:30000], text[:2000], noise[:30000]]),           # far match: distance 32 000
               np.concatenate([noise[:33000], noise[:32000]]),                         # distance 33 000: out of reach
-              np.concatenate([noise[:5000], np.zeros(300, np.uint8), noise[5000:9000]])]
-    codec = backend.codec("Deflate")
+              np.concatenate([noise[:5000], np.zeros(300, np.uint8), noise[5000:9000]]),
+              np.frombuffer(bytes(range(256)) * 8, np.uint8),                          # every literal once per 256: flat counts
+              np.concatenate([np.full(60000, 65, np.uint8), rng.randint(0, 256, 5536, dtype=np.uint8)]),  # one symbol dominates
+              text[:1023], text[:1024], text[:1025]]                                   # around the dynamic coder's size threshold
+    codec = backend.codec("Deflate", (algo,))
     comp = codec.compress(chunks)
     for cc, c in zip(comp, chunks):
         assert zlib.decompress(cc.tobytes(), -15) == c.tobytes()
         assert cc.size <= c.size + 5 * (c.size // 65535 + 1)
     assert comp[7].size < 500 and comp[10].size < 40000  # the run; most of the repeat 32 000 back is found
+    check(backend, "Deflate", chunks, comp)
+
+
+def test_dynamic_codes_on_skewed_alphabets(backend):
+    """Code construction under stress: byte distributions from flat to Fibonacci-steep (code lengths that want more than
+    15 bits and must be repaired), few and many distinct symbols, with and without matches. zlib must read every block."""
+    rng = np.random.RandomState(99)
+    chunks = []
+    for i in range(40 if backend.name == "gpu" else 16):
+        n = int(rng.choice([1500, 5000, 20000, 65536]))
+        k = int(rng.choice([2, 3, 17, 64, 200, 256]))
+        steep = float(rng.choice([0.0, 0.3, 0.62, 1.0, 2.0]))  # p(symbol j) ~ exp(-steep * j): 0.62 ~ golden ratio decay
+        p = np.exp(-steep * np.arange(k))
+        c = rng.choice(k, size=n, p=p / p.sum()).astype(np.uint8)
+        if i % 3 == 0:
+            c[n // 2:] = c[: n - n // 2]  # long-distance repeats on top
+        chunks.append(c)
+    codec = backend.codec("Deflate", (1,))
+    comp = codec.compress(chunks)
+    for cc, c in zip(comp, chunks):
+        assert zlib.decompress(cc.tobytes(), -15) == c.tobytes()
+        assert cc.size <= c.size + 5 * (c.size // 65535 + 1)
     check(backend, "Deflate", chunks, comp)
