@@ -474,6 +474,20 @@ def run_case(args, ctx):
                 "algorithmic_bytes_per_launch": int(comp_alg), "kernel_ms": round(comp_ms, 4), "traffic": None,
             },
         }
+        if args.algo == "deflate":
+            # algo 0 above: the fixed Huffman code; algo 1: per-chunk codes (two runs of the match finder + code construction)
+            dyn = nvcomp_amd.BatchedCodec(lib, dev, fmt, (1,))
+            dyn.compress_async(src, dst, CHUNK, ctemp, ctb)
+            rt.barrier_sync()
+            d0, d1 = rt.event(), rt.event()
+            d0.record()
+            for _ in range(3):
+                dyn.compress_async(src, dst, CHUNK, ctemp, ctb)
+            d1.record()
+            rt.barrier_sync()
+            dsz = dev.download(dst.sizes).view(np.uint64)[:k]
+            result["extras"]["gpu_compress_dynamic_codes"] = {
+                "GBps": round(raw_k / (d0.elapsed_time(d1) / 3 * 1e-3) / 1e9, 3), "ratio": round(raw_k / int(dsz.sum()), 4)}
         del dst, ctemp
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # The reference's CPU path (liblz4 / snappy decoders) on this box's host cores over a

@@ -25,8 +25,9 @@ extern "C" {
  * examples/deflate_cpu_decompression.cu:61 */
 typedef struct
 {
-  int algo; /* compressor setting 0 .. 2 as in the reference's harness; every value produces standard streams (this
-             * build: one compressor -- greedy LZ77, fixed Huffman codes -- for all three) */
+  int algo; /* compressor setting 0 .. 2 as in the reference's harness; every value produces standard streams. This
+             * build: greedy LZ77 throughout; 0 = the fixed Huffman code (fastest), 1 and 2 = per-chunk Huffman codes
+             * (two runs of the match finder and a code construction per chunk: better ratio, less than half the speed) */
 } nvcompBatchedDeflateOpts_t;
 
 static const nvcompBatchedDeflateOpts_t nvcompBatchedDeflateDefaultOpts = {0};

@@ -14,8 +14,9 @@
  *     area (ds_or_b32) that is flushed to the chunk's output in whole dwords after every step;
  *   - a chunk the fixed code would expand (9 bits per literal, no matches: random bytes) is written as STORED blocks
  *     instead.
- * nvcompBatchedDeflateOpts_t.algo 0, 1 and 2 all select this compressor for now (every value must produce standard
- * streams; the reference's values select CPU-library-like effort levels, benchmarks/benchmark_deflate_chunked.cu:43).
+ * This is nvcompBatchedDeflateOpts_t.algo 0; algo 1 and 2 write per-chunk Huffman codes
+ * (deflate_encode_dynamic.hip.h). The reference's values select CPU-library-like effort levels
+ * (benchmarks/benchmark_deflate_chunked.cu:43); every value must produce standard streams.
  */
 #pragma once
 
