@@ -42,3 +42,22 @@ def test_own_format_golden(backend, oracle, rec):
     assert np.array_equal(made, stream), "compressed bytes differ from the committed golden stream"
     outs, actual, status = codec.decompress([stream], [rec["bytes"]], comp_align=8, out_align=8)
     assert status[0] == 0 and actual[0] == rec["bytes"] and np.array_equal(outs[0], chunk)
+
+
+DEFLATE = json.load(open(os.path.join(GOLDEN, "deflate_manifest.json")))
+
+
+@pytest.mark.parametrize("fmt", ["Deflate", "Gzip"])
+def test_deflate_golden(backend, fmt):
+    """DEFLATE / gzip streams committed by scripts/make_golden_deflate.py: zlib's output for the reference's fixture
+    chunks, written the way examples/deflate_cpu_compression.cu and gzip_gpu_decompression.cu write them."""
+    recs = [s for s in DEFLATE["streams"] if s["format"] == fmt]
+    comp = [np.fromfile(os.path.join(GOLDEN, r["file"]), dtype=np.uint8) for r in recs]
+    for c, r in zip(comp, recs):
+        assert hashlib.sha256(c.tobytes()).hexdigest() == r["stream_sha256"]
+    codec = backend.codec(fmt)
+    outs, actual, status = codec.decompress(comp, [r["bytes"] for r in recs])
+    assert (status == 0).all() and actual.tolist() == [r["bytes"] for r in recs]
+    for o, r in zip(outs, recs):
+        assert hashlib.sha256(o.tobytes()).hexdigest() == r["sha256"]
+    assert codec.get_decompress_size(comp).tolist() == [r["bytes"] for r in recs]
