@@ -88,7 +88,7 @@ def test_many_small_streams(backend):
     rng = np.random.RandomState(17)
     pool = {n: datasets.CLASSES[n](1 << 18, 4) for n in ("text", "table", "float32", "lowcard", "noise", "zeros", "int32")}
     chunks, comp = [], []
-    for i in range(240 if backend.name == "gpu" else 96):
+    for i in range(240 if backend.name == "gpu" else 40):
         name = list(pool)[i % len(pool)]
         size = int(rng.randint(1, 20000))
         at = int(rng.randint(0, (1 << 18) - size))
@@ -373,7 +373,7 @@ def test_dynamic_codes_on_skewed_alphabets(backend):
     15 bits and must be repaired), few and many distinct symbols, with and without matches. zlib must read every block."""
     rng = np.random.RandomState(99)
     chunks = []
-    for i in range(40 if backend.name == "gpu" else 16):
+    for i in range(40 if backend.name == "gpu" else 10):
         n = int(rng.choice([1500, 5000, 20000, 65536]))
         k = int(rng.choice([2, 3, 17, 64, 200, 256]))
         steep = float(rng.choice([0.0, 0.3, 0.62, 1.0, 2.0]))  # p(symbol j) ~ exp(-steep * j): 0.62 ~ golden ratio decay

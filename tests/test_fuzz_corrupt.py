@@ -88,7 +88,7 @@ def test_corrupt_deflate_streams_are_contained(backend, fmt):
     import zlib
 
     rng = np.random.RandomState(4242 if fmt == "Deflate" else 2424)
-    n = 160 if backend.name == "gpu" else 48
+    n = 160 if backend.name == "gpu" else 30
     gens = [datasets.text, datasets.int32_column, datasets.lowcard, datasets.table_rows, datasets.float_columns]
     chunks = [gens[i % 5](int(rng.choice([300, 4096, 20000, 65536])), i) for i in range(n)]
     wbits = -15 if fmt == "Deflate" else 15 | 16

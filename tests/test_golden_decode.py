@@ -52,6 +52,8 @@ def test_deflate_golden(backend, fmt):
     """DEFLATE / gzip streams committed by scripts/make_golden_deflate.py: zlib's output for the reference's fixture
     chunks, written the way examples/deflate_cpu_compression.cu and gzip_gpu_decompression.cu write them."""
     recs = [s for s in DEFLATE["streams"] if s["format"] == fmt]
+    if backend.name != "gpu":
+        recs = recs[: len(recs) // 2]  # every kind of the first file's chunks: the emulator decodes ~50 KB/s
     comp = [np.fromfile(os.path.join(GOLDEN, r["file"]), dtype=np.uint8) for r in recs]
     for c, r in zip(comp, recs):
         assert hashlib.sha256(c.tobytes()).hexdigest() == r["stream_sha256"]
@@ -60,4 +62,5 @@ def test_deflate_golden(backend, fmt):
     assert (status == 0).all() and actual.tolist() == [r["bytes"] for r in recs]
     for o, r in zip(outs, recs):
         assert hashlib.sha256(o.tobytes()).hexdigest() == r["sha256"]
-    assert codec.get_decompress_size(comp).tolist() == [r["bytes"] for r in recs]
+    few = slice(0, None if backend.name == "gpu" else 4)  # the size query decodes symbol by symbol: slow under emulation
+    assert codec.get_decompress_size(comp[few]).tolist() == [r["bytes"] for r in recs[few]]

@@ -39,6 +39,8 @@ def test_decode_classes(backend, lz_path, oracle, name):
 
 def test_batch_that_fills_the_card(backend, oracle):
     """From 8 192 chunks on the window decoder runs in one-wave workgroups (api/snappy_api.hip)."""
+    if backend.name != "gpu":
+        pytest.skip("a launch shape of the GPU: 8 200 workgroups take the emulator half a minute")
     data = datasets.silesia_style(8200 * 384, 4)
     chunks = datasets.split_chunks(data, 384)
     assert len(chunks) >= 8192
