@@ -62,11 +62,6 @@ def parse_args():
     p.add_argument("--no-extras", action="store_true", help="skip the GPU compress leg (ratio / compress GB/s)")
     p.add_argument("--allgather", action="store_true", help="benchmark_allgather.cpp path (N >= 2)")
     p.add_argument("--no-verify", action="store_true", help="(profiling of ablated kernels only) skip output checks")
-    p.add_argument("--lz-index-min-batch", type=int, default=None,
-                   help="include/nvcomp/amd_ext.h: smallest batch that takes the two-kernel (token index) LZ decode path; "
-                        "0 = always, a huge value = never (the single-kernel chase decoder)")
-    p.add_argument("--lz-pair-max-batch", type=int, default=None,
-                   help="include/nvcomp/amd_ext.h: largest batch the LZ4 decoder runs with two waves per chunk; 0 = never")
     p.add_argument("--dry-run-emu", action="store_true",
                    help="CPU-only self-test of this script's plumbing against tests/emu (prints value=null)")
     return p.parse_args()
@@ -222,8 +217,7 @@ def setup_runtime(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one process per GPU (or none: bench.py launches itself)")
     import nvcomp_amd
     from nvcomp_amd import datasets
     from nvcomp_amd.batched import DeviceBatch
@@ -275,10 +269,6 @@ def run_case(args, ctx):
     if own_format:
         opts = tuple(int(x) for x in args.opts.split(",")) if args.opts else OWN_FORMAT_OPTS[args.algo]
     codec = nvcomp_amd.BatchedCodec(lib, dev, fmt, opts)
-    if args.lz_index_min_batch is not None:
-        lib.nvcompAmdSetLZIndexMinBatch(args.lz_index_min_batch)
-    if args.lz_pair_max_batch is not None:
-        lib.nvcompAmdSetLZPairMaxBatch(args.lz_pair_max_batch)
     threads = len(os.sched_getaffinity(0))
 
     # ---- build the batch (untimed) ----
@@ -708,9 +698,7 @@ def run_allgather_case(args, ctx):
     recv = {r: rt.as_tensor(dev.empty(cap_bytes)) for r in remote}
     all_sizes_flat = torch.zeros(world * n, dtype=torch.int64, device=sizes.device)
     all_sizes = all_sizes_flat.view(world, n)
-    offs_all = torch.zeros(world, n, dtype=torch.int64, device=sizes.device)
     ptrs_all = torch.zeros(world, n, dtype=torch.int64, device=sizes.device)
-    totals = torch.zeros(world, dtype=torch.int64, device=sizes.device)
     actual = rt.as_tensor(dev.upload(np.zeros(max(m, 1), dtype=np.uint64).view(np.uint8))).view(torch.int64)
     statuses = rt.as_tensor(dev.upload(np.full(max(m, 1), -1, dtype=np.int32).view(np.uint8))).view(torch.int32)
     dtemps = {r: (dev.empty(dtb) if dtb else None) for r in remote}
@@ -720,6 +708,15 @@ def run_allgather_case(args, ctx):
         out_batches[r] = DeviceBatch(out, dev_u64(optrs), dev_u64(np.full(n, CHUNK)), None, None, n)
     side = rt.side_streams(len(remote))
     moved = [0]
+    # The exchange runs in SLICES of the chunk range: slice j of every shard travels in ONE grouped send/recv
+    # (ncclGroupStart .. ncclSend/ncclRecv to and from every peer .. ncclGroupEnd: every xGMI link of the rank carries its
+    # own peer's bytes at once, no ring, no root) and is decoded, peer by peer on the peers' streams, while slice j+1 is on
+    # the wire (the reference waits for the whole exchange, benchmark_allgather.cpp:370).
+    n_slices = max(1, min(4, n // 4096)) if not args.unique_kib else min(2, n)
+    cuts = [n * j // n_slices for j in range(n_slices + 1)]
+    cut_index = torch.tensor(cuts, dtype=torch.int64, device=sizes.device)
+    cut_offs = torch.zeros(world, n_slices + 1, dtype=torch.int64, device=sizes.device)  # byte offset of every cut, per rank
+    offs_ext = torch.zeros(world, n + 1, dtype=torch.int64, device=sizes.device)  # exclusive prefix sums + the total
 
     def step():
         rc = codec.compress_async(src, dst, CHUNK, ctemp, ctb)
@@ -729,27 +726,28 @@ def run_allgather_case(args, ctx):
                                            dev.ptr(my_offsets), dev.stream())
         assert rc == 0, rc
         dist.all_gather_into_tensor(all_sizes_flat, sizes)
-        torch.sum(all_sizes, dim=1, out=totals)
-        host_totals = totals.tolist()  # THE host sync of a step: the sizes, like the reference's sync_all_streams (:370)
-        moved[0] = int(sum(host_totals))
-        torch.cumsum(all_sizes, dim=1, out=offs_all)
-        offs_all.sub_(all_sizes)
-        # the payloads travel rank by rank (the actual compressed bytes, not the bound the reference ships) ...
-        works = {}
-        for r in range(world):
-            buf = packed if r == rank else recv[r]
-            works[r] = dist.broadcast(buf[: host_totals[r]], src=r, async_op=True)
-        # ... and every peer's shard is decoded on its own stream as soon as IT has landed, while the next ones are
-        # still on the wire (the reference waits for all of them, benchmark_allgather.cpp:370)
-        for j, r in enumerate(remote):
-            with rt.on_stream(side[j]):
-                works[r].wait()
-                torch.add(offs_all[r], ptr(recv[r]), out=ptrs_all[r])
-                batch = DeviceBatch(recv[r], ptrs_all[r], all_sizes[r], None, None, n)
-                rc = codec.decompress_async(batch, out_batches[r], actual[j * n: (j + 1) * n], statuses[j * n: (j + 1) * n],
-                                            dtemps[r], dtb)
-                assert rc == 0, rc
-        works[rank].wait()
+        torch.cumsum(all_sizes, dim=1, out=offs_ext[:, 1:])
+        torch.index_select(offs_ext, 1, cut_index, out=cut_offs)
+        host_cuts = cut_offs.tolist()  # THE host sync of a step: byte counts, like the reference's sync_all_streams (:370)
+        moved[0] = int(sum(row[-1] for row in host_cuts))
+        for j in range(n_slices):
+            c0, c1 = cuts[j], cuts[j + 1]
+            ops = []
+            for r in remote:  # the ACTUAL compressed bytes travel, not the bound the reference ships
+                ops.append(dist.P2POp(dist.irecv, recv[r][host_cuts[r][j]: host_cuts[r][j + 1]], r))
+                ops.append(dist.P2POp(dist.isend, packed[host_cuts[rank][j]: host_cuts[rank][j + 1]], r))
+            works = dist.batch_isend_irecv(ops) if ops else []
+            for k, r in enumerate(remote):
+                with rt.on_stream(side[k]):
+                    for w in works:
+                        w.wait()
+                    torch.add(offs_ext[r, c0:c1], ptr(recv[r]), out=ptrs_all[r, c0:c1])
+                    batch = DeviceBatch(recv[r], ptrs_all[r, c0:c1], all_sizes[r, c0:c1], None, None, c1 - c0)
+                    ob = out_batches[r]
+                    oslice = DeviceBatch(out, ob.ptrs[8 * c0: 8 * c1], ob.sizes[8 * c0: 8 * c1], None, None, c1 - c0)
+                    rc = codec.decompress_async(batch, oslice, actual[k * n + c0: k * n + c1],
+                                                statuses[k * n + c0: k * n + c1], dtemps[r], dtb)
+                    assert rc == 0, rc
         out[rank * shard_bytes: (rank + 1) * shard_bytes].copy_(raw)  # own shard: plain copy (benchmark_allgather.cpp:386-393)
         rt.join_streams(side)
 
@@ -817,8 +815,26 @@ def rider(args, ctx, algo, **overrides):
         return {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` alone (no launcher, no WORLD_SIZE): become `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` -- one process per GPU,
+    rank 0 prints the one JSON line. The reference's multi-GPU program is one command too
+    (benchmarks/benchmark_allgather.cpp:594-644, -g N)."""
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     if args.mib_per_gpu is None:
         args.mib_per_gpu = 4096
     if args.dataset is None:

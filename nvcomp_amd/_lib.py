@@ -123,19 +123,14 @@ def declare(lib: C.CDLL, formats=FORMATS) -> C.CDLL:
             getattr(lib, "nvcompBatchedGzip" + name).restype = C.c_int
     if hasattr(lib, "nvcompAmdBatchedPackAsync"):  # include/nvcomp/amd_ext.h
         lib.nvcompAmdBatchedPackAsync.argtypes = [vp, vp, sz, vp, sz, vp, vp]
-    if hasattr(lib, "nvcompAmdSetLZPairMaxBatch"):  # include/nvcomp/amd_ext.h
-        lib.nvcompAmdSetLZPairMaxBatch.argtypes = [sz]
-        lib.nvcompAmdSetLZPairMaxBatch.restype = sz
-    if hasattr(lib, "nvcompAmdSetLZIndexMinBatch"):  # include/nvcomp/amd_ext.h
-        lib.nvcompAmdSetLZIndexMinBatch.argtypes = [sz]
-        lib.nvcompAmdSetLZIndexMinBatch.restype = sz
     return lib
 
 
 def load_library(path: str = LIB_PATH) -> C.CDLL:
     """Load the HIP library. Raises if it has not been built: there is no fallback.
     NVCOMP_AMD_LIB selects an alternative build of the same HIP library (A/B tuning builds)."""
-    path = os.environ.get("NVCOMP_AMD_LIB", path)
+    if path == LIB_PATH:
+        path = os.environ.get("NVCOMP_AMD_LIB", path)
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

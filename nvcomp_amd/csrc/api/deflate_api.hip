@@ -28,7 +28,10 @@ constexpr unsigned kDecWavesPerSimd = deflate::kLdsPerWave <= 10240 ? 4 : 3;
 constexpr unsigned kEncWaves = 2; /* 10 / 11.3 KiB of LDS per wave: 16 / 14 waves per CU in workgroups of two */
 constexpr uint32_t kMaxOutCap = 1u << 26;
 
-template <bool CHECKED, uint32_t FLAGS>
+/* The bounds and match-offset checks always run: DEFLATE / gzip streams come from outside (CPU producers, files), and a
+ * corrupt one must never write outside its output slot or read in front of it -- whether or not the caller asked for
+ * statuses (they cost two ballots per batch of 64 records). Only the status WRITE depends on `statuses`. */
+template <uint32_t FLAGS>
 __global__ void __launch_bounds__(64 * kDecWaves, kDecWavesPerSimd) deflate_decompress_kernel(
     const void* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes,
@@ -56,13 +59,13 @@ __global__ void __launch_bounds__(64 * kDecWaves, kDecWavesPerSimd) deflate_deco
   if (in_len64 > (1u << 28)) {
     err = lz::kErrInput;
   } else {
-    produced = deflate::decode_chunk<CHECKED, false>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds[w], FLAGS, err);
+    produced = deflate::decode_chunk<true, false>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds[w], FLAGS, err);
   }
   if (wave::lane_id() == 0) {
     if (actual_bytes != nullptr) {
       actual_bytes[chunk] = err ? 0 : produced;
     }
-    if (CHECKED) {
+    if (statuses != nullptr) {
       statuses[chunk] = err ? nvcompErrorCannotDecompress : nvcompSuccess;
     }
   }
@@ -178,15 +181,9 @@ nvcompStatus_t decompress_async(
   clear_stale_error();
   const dim3 grid((unsigned)((batch_size + kDecWaves - 1) / kDecWaves));
   const dim3 block(64 * kDecWaves);
-  if (device_statuses != nullptr) {
-    hipLaunchKernelGGL((deflate_decompress_kernel<true, FLAGS>), grid, block, 0, stream, device_compressed_ptrs,
-                       device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes, batch_size,
-                       device_uncompressed_ptrs, device_statuses);
-  } else {
-    hipLaunchKernelGGL((deflate_decompress_kernel<false, FLAGS>), grid, block, 0, stream, device_compressed_ptrs,
-                       device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes, batch_size,
-                       device_uncompressed_ptrs, device_statuses);
-  }
+  hipLaunchKernelGGL((deflate_decompress_kernel<FLAGS>), grid, block, 0, stream, device_compressed_ptrs,
+                     device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes, batch_size,
+                     device_uncompressed_ptrs, device_statuses);
   return launch_status();
 }
 

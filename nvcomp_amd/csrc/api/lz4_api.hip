@@ -13,18 +13,14 @@
 
 #include "nvcomp/amd_ext.h"
 
-#include "common/tuning.h"
-
+#include "common/lz_launch.hip.h"
 #include "lz4/lz4_decode.hip.h"
 #include "lz4/lz4_decode_window.hip.h"
 #include "lz4/lz4_encode.hip.h"
-#include "lz4/lz4_index.hip.h"
 
 namespace {
 
 constexpr unsigned kWavesPerBlock = 4; /* 256-thread workgroups, one chunk per wave */
-/* The decoders' workgroup size is a tuning parameter of its own: a workgroup's LDS is released when its LAST wave ends, and
- * chunks of a mixed batch take very different times. */
 #ifndef NVCOMP_LZ_DEC_WAVES_PER_BLOCK
 #define NVCOMP_LZ_DEC_WAVES_PER_BLOCK 4
 #endif
@@ -32,48 +28,22 @@ constexpr unsigned kDecWaves = NVCOMP_LZ_DEC_WAVES_PER_BLOCK;
 #ifndef NVCOMP_LZM_WAVES_PER_BLOCK
 #define NVCOMP_LZM_WAVES_PER_BLOCK 4
 #endif
-constexpr unsigned kEncWaves = NVCOMP_LZM_WAVES_PER_BLOCK; /* the compressors' workgroup size, same reasoning */
-constexpr uint32_t kMaxOutCap = 1u << 26;
+constexpr unsigned kEncWaves = NVCOMP_LZM_WAVES_PER_BLOCK; /* the compressors' workgroup size */
+using lzl::kMaxOutCap;
 
-/* A/B and ablation kernels exist in measurement builds only (scripts/build_variants.sh passes
- * -DNVCOMP_AMD_LZ4_VARIANT=1 direct | 2 serial | 11 / 12 chase-only / chase+parse ablations, the last two with
- * wrong output by construction); the shipped library has exactly one decoder and no run-time switch. */
-#ifndef NVCOMP_AMD_LZ4_VARIANT
-#define NVCOMP_AMD_LZ4_VARIANT 0
+/* Profiling builds only (wrong output by construction): 1 = stop after the token chase, 2 = after the parse. */
+#ifndef NVCOMP_LZ4W_ABLATE
+#define NVCOMP_LZ4W_ABLATE 0
 #endif
 
-/* WAVES = chunks (waves) per workgroup. A workgroup's LDS is released when its last wave ends and the chunks of a batch
- * take very different times: one-wave workgroups keep a full card fuller on the mix (65 536 chunks: 507 -> 518 GB/s;
- * Snappy 350 -> 372) -- but batches of uniformly fast chunks lose 7 % to the four times as many workgroup launches
- * (int32 column, 16 384 chunks: 639 -> 585; Snappy 608 -> 598), and a batch that does not fill the card spreads
- * better in workgroups of four (4 096 chunks: 282 against 263). Snappy takes the trade from 8 192 chunks on
- * (api/snappy_api.hip), LZ4 does not: kSingleWaveFromBatch is out of reach. */
-constexpr size_t kSingleWaveFromBatch = ~(size_t)0;
-
-template <bool CHECKED, int ABLATE = 0, unsigned WAVES = kDecWaves>
-__global__ void __launch_bounds__(64 * WAVES, NVCOMP_LZW_WAVES_PER_SIMD) lz4_decompress_window_kernel(
-    const void* const* __restrict__ comp_ptrs,
-    const size_t* __restrict__ comp_bytes,
-    const size_t* out_caps,
-    size_t* actual_bytes,
-    size_t batch_size,
-    void* const* __restrict__ out_ptrs,
-    nvcompStatus_t* statuses,
-    const uint32_t* __restrict__ index_counts /* non-null: only the chunks the indexer left out (lzi::kNotIndexed) */)
+/* Decode chunk `chunk` of the batch with the calling wave and report its size and status. */
+template <bool CHECKED>
+__device__ __forceinline__ void decode_one(const lzl::Batch& b, size_t chunk, uint8_t* lds)
 {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES][lzg::kLdsPerWave];
-  const uint32_t w = wave::uniform(threadIdx.x >> 6);
-  const size_t chunk = (size_t)blockIdx.x * WAVES + w;
-  if (chunk >= batch_size) {
-    return;
-  }
-  if (index_counts != nullptr && wave::uniform(index_counts[chunk]) != lzi::kNotIndexed) {
-    return;
-  }
-  const uint8_t* in = wave::uniform_ptr((const uint8_t*)comp_ptrs[chunk]);
-  uint8_t* out = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
-  const size_t in_len64 = wave::uniform64(comp_bytes[chunk]);
-  size_t cap64 = wave::uniform64(out_caps[chunk]);
+  const uint8_t* in = wave::uniform_ptr((const uint8_t*)b.comp_ptrs[chunk]);
+  uint8_t* out = wave::uniform_ptr((uint8_t*)b.out_ptrs[chunk]);
+  const size_t in_len64 = wave::uniform64(b.comp_bytes[chunk]);
+  size_t cap64 = wave::uniform64(b.out_caps[chunk]);
   if (cap64 > kMaxOutCap) {
     cap64 = kMaxOutCap;
   }
@@ -82,50 +52,60 @@ __global__ void __launch_bounds__(64 * WAVES, NVCOMP_LZW_WAVES_PER_SIMD) lz4_dec
   if (in_len64 > 0xffffffffull - 64) {
     err = lz::kErrInput;
   } else {
-#ifdef NVCOMP_LZW_PROF
-    lzw::prof_begin();
-#endif
-    produced = lz4w::decode_chunk<CHECKED, ABLATE>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds[w], err);
-#ifdef NVCOMP_LZW_PROF
-    lzw::prof_end();
-#endif
+    produced = lz4w::decode_chunk<CHECKED, NVCOMP_LZ4W_ABLATE>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err);
   }
   if (wave::lane_id() == 0) {
-    if (actual_bytes != nullptr) {
-      actual_bytes[chunk] = err ? 0 : produced;
+    if (b.actual_bytes != nullptr) {
+      b.actual_bytes[chunk] = err ? 0 : produced;
     }
     if (CHECKED) {
-      statuses[chunk] = err ? nvcompErrorCannotDecompress : nvcompSuccess;
+      b.statuses[chunk] = err ? nvcompErrorCannotDecompress : nvcompSuccess;
     }
   }
 }
 
-#if !NVCOMP_LZ_GATHER
+/* One wave per chunk at a time; with a ticket counter the waves are persistent (common/lz_launch.hip.h). */
+template <bool CHECKED>
+__global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_WAVES_PER_SIMD) lz4_decompress_window_kernel(
+    const lzl::Batch b, uint32_t* ticket)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kDecWaves][lzw::kLdsPerWave];
+  const uint32_t w = wave::uniform(threadIdx.x >> 6);
+  const size_t first_dynamic = (size_t)gridDim.x * kDecWaves;
+  size_t chunk = (size_t)blockIdx.x * kDecWaves + w;
+#ifdef NVCOMP_LZW_PROF
+  lzw::prof_begin();
+#endif
+  while (chunk < b.batch_size) {
+    decode_one<CHECKED>(b, chunk, lds[w]);
+    if (ticket == nullptr) {
+      break;
+    }
+    chunk = lzl::next_chunk(ticket, first_dynamic);
+  }
+#ifdef NVCOMP_LZW_PROF
+  lzw::prof_end();
+#endif
+}
+
 /* Small batches: two waves per chunk, a producer (chase + parse) and a consumer (execute), lz4w::pair. */
 template <bool CHECKED>
-__global__ void __launch_bounds__(128, 4) lz4_decompress_pair_kernel(
-    const void* const* __restrict__ comp_ptrs,
-    const size_t* __restrict__ comp_bytes,
-    const size_t* out_caps,
-    size_t* actual_bytes,
-    size_t batch_size,
-    void* const* __restrict__ out_ptrs,
-    nvcompStatus_t* statuses)
+__global__ void __launch_bounds__(128, 4) lz4_decompress_pair_kernel(const lzl::Batch b)
 {
   __shared__ __attribute__((aligned(16))) uint8_t lds[lz4w::pair::kLdsPerChunk];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
   const size_t chunk = blockIdx.x;
-  if (chunk >= batch_size) {
+  if (chunk >= b.batch_size) {
     return;
   }
   if (threadIdx.x < 4) {
     ((uint32_t*)(lds + lz4w::pair::kLdsPerChunk - lz4w::pair::kCtrlBytes))[threadIdx.x] = 0; /* both slots empty, no abort */
   }
   __syncthreads();
-  const uint8_t* in = wave::uniform_ptr((const uint8_t*)comp_ptrs[chunk]);
-  uint8_t* out = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
-  const size_t in_len64 = wave::uniform64(comp_bytes[chunk]);
-  size_t cap64 = wave::uniform64(out_caps[chunk]);
+  const uint8_t* in = wave::uniform_ptr((const uint8_t*)b.comp_ptrs[chunk]);
+  uint8_t* out = wave::uniform_ptr((uint8_t*)b.out_ptrs[chunk]);
+  const size_t in_len64 = wave::uniform64(b.comp_bytes[chunk]);
+  size_t cap64 = wave::uniform64(b.out_caps[chunk]);
   if (cap64 > kMaxOutCap) {
     cap64 = kMaxOutCap;
   }
@@ -143,100 +123,11 @@ __global__ void __launch_bounds__(128, 4) lz4_decompress_pair_kernel(
     produced = lz4w::pair::consume<CHECKED>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err);
   }
   if (wave::lane_id() == 0) {
-    if (actual_bytes != nullptr) {
-      actual_bytes[chunk] = err ? 0 : produced;
+    if (b.actual_bytes != nullptr) {
+      b.actual_bytes[chunk] = err ? 0 : produced;
     }
     if (CHECKED) {
-      statuses[chunk] = err ? nvcompErrorCannotDecompress : nvcompSuccess;
-    }
-  }
-}
-#endif
-
-/* Token indexer: one LANE per chunk, 64 chunks per single-wave workgroup (common/lz_index.hip.h). */
-__global__ void __launch_bounds__(64) lz4_index_kernel(
-    const void* const* __restrict__ comp_ptrs, const size_t* __restrict__ comp_bytes, size_t batch_size, lzi::Layout lay)
-{
-  __shared__ __attribute__((aligned(16))) uint32_t lds[lzi::kLdsDwords];
-  lzi::index_chunks<lz4i::Format>(comp_ptrs, comp_bytes, batch_size, lay, lds);
-}
-
-/* The window decoder fed from the token index: no chase tables in LDS, one wave per chunk. */
-template <bool CHECKED>
-__global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_INDEXED_WAVES_PER_SIMD) lz4_decompress_indexed_kernel(
-    const void* const* __restrict__ comp_ptrs,
-    const size_t* __restrict__ comp_bytes,
-    const size_t* out_caps,
-    size_t* actual_bytes,
-    size_t batch_size,
-    void* const* __restrict__ out_ptrs,
-    nvcompStatus_t* statuses,
-    lzi::Layout lay)
-{
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kDecWaves][lzg::kLdsPerWaveIndexed];
-  const uint32_t w = wave::uniform(threadIdx.x >> 6);
-  const size_t chunk = (size_t)blockIdx.x * kDecWaves + w;
-  if (chunk >= batch_size) {
-    return;
-  }
-  const uint32_t n_tok = wave::uniform(lay.counts[chunk]);
-  if (n_tok == lzi::kNotIndexed) {
-    return; /* the chase decoder takes this chunk */
-  }
-  const uint8_t* in = wave::uniform_ptr((const uint8_t*)comp_ptrs[chunk]);
-  uint8_t* out = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
-  const uint32_t in_len = (uint32_t)wave::uniform64(comp_bytes[chunk]); /* <= lzi::kMaxInput */
-  size_t cap64 = wave::uniform64(out_caps[chunk]);
-  if (cap64 > kMaxOutCap) {
-    cap64 = kMaxOutCap;
-  }
-  uint32_t err = lz::kErrNone;
-  const uint32_t produced = lz4w::decode_chunk_indexed<CHECKED>(
-      in, in_len, out, (uint32_t)cap64, lds[w], lay.table + chunk * (size_t)lay.stride, n_tok, err);
-  if (wave::lane_id() == 0) {
-    if (actual_bytes != nullptr) {
-      actual_bytes[chunk] = err ? 0 : produced;
-    }
-    if (CHECKED) {
-      statuses[chunk] = err ? nvcompErrorCannotDecompress : nvcompSuccess;
-    }
-  }
-}
-
-template <bool CHECKED, bool LANE_PARALLEL>
-__global__ void __launch_bounds__(64 * kDecWaves) lz4_decompress_kernel(
-    const void* const* __restrict__ comp_ptrs,
-    const size_t* __restrict__ comp_bytes,
-    const size_t* out_caps,
-    size_t* actual_bytes,
-    size_t batch_size,
-    void* const* __restrict__ out_ptrs,
-    nvcompStatus_t* statuses)
-{
-  const size_t chunk = (size_t)blockIdx.x * kDecWaves + wave::uniform(threadIdx.x >> 6);
-  if (chunk >= batch_size) {
-    return;
-  }
-  const uint8_t* in = wave::uniform_ptr((const uint8_t*)comp_ptrs[chunk]);
-  uint8_t* out = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
-  const size_t in_len64 = wave::uniform64(comp_bytes[chunk]);
-  size_t cap64 = wave::uniform64(out_caps[chunk]);
-  if (cap64 > kMaxOutCap) {
-    cap64 = kMaxOutCap;
-  }
-  uint32_t err = lz::kErrNone;
-  uint32_t produced = 0;
-  if (in_len64 > 0xffffffffull - 8) {
-    err = lz::kErrInput;
-  } else {
-    produced = lz4::decode_chunk<CHECKED, LANE_PARALLEL, false>(in, (uint32_t)in_len64, out, (uint32_t)cap64, err);
-  }
-  if (wave::lane_id() == 0) {
-    if (actual_bytes != nullptr) {
-      actual_bytes[chunk] = err ? 0 : produced;
-    }
-    if (CHECKED) {
-      statuses[chunk] = err ? nvcompErrorCannotDecompress : nvcompSuccess;
+      b.statuses[chunk] = err ? nvcompErrorCannotDecompress : nvcompSuccess;
     }
   }
 }
@@ -331,11 +222,10 @@ nvcompStatus_t nvcompBatchedLZ4DecompressGetTempSize(
   if (temp_bytes == nullptr) {
     return nvcompErrorInvalidValue;
   }
-  /* only the opt-in two-kernel path (include/nvcomp/amd_ext.h) wants scratch: the token index, u32 count + one u16 per
-   * possible token of every chunk (common/lz_index.hip.h) */
-  *temp_bytes = num_chunks == 0 || num_chunks < nvcomp_amd_tuning::lz_index_min_batch
-                    ? 0
-                    : lzi::temp_bytes_for(num_chunks, lz4_bound(max_uncompressed_chunk_bytes));
+  /* the persistent waves' ticket counter (common/lz_launch.hip.h); batches small enough for the two-waves-per-chunk path
+   * need nothing */
+  (void)max_uncompressed_chunk_bytes;
+  *temp_bytes = num_chunks > lzl::kPairMaxBatch ? lzl::kTicketBytes : 0;
   return nvcompSuccess;
 }
 
@@ -368,72 +258,39 @@ nvcompStatus_t nvcompBatchedLZ4DecompressAsync(
     return nvcompErrorInvalidValue;
   }
   clear_stale_error();
-  const dim3 grid((unsigned)((batch_size + kDecWaves - 1) / kDecWaves));
-  const dim3 block(64 * kDecWaves);
   const bool checked = device_statuses != nullptr;
-#define NVCOMP_LZ4_ARGS                                                                                        \
-  device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes, \
-      batch_size, device_uncompressed_ptrs, device_statuses
-#if NVCOMP_AMD_LZ4_VARIANT == 0 && !NVCOMP_LZ_GATHER
+  const lzl::Batch b = {device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
+                        device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, (int*)device_statuses};
   /* Small batches cannot fill the card with one wave per chunk: two waves per chunk (producer / consumer). */
-  if (batch_size <= nvcomp_amd_tuning::lz_pair_max_batch) {
+  if (batch_size <= lzl::kPairMaxBatch) {
     const dim3 pgrid((unsigned)batch_size), pblock(128);
     if (checked) {
-      hipLaunchKernelGGL((lz4_decompress_pair_kernel<true>), pgrid, pblock, 0, stream, NVCOMP_LZ4_ARGS);
+      hipLaunchKernelGGL((lz4_decompress_pair_kernel<true>), pgrid, pblock, 0, stream, b);
     } else {
-      hipLaunchKernelGGL((lz4_decompress_pair_kernel<false>), pgrid, pblock, 0, stream, NVCOMP_LZ4_ARGS);
+      hipLaunchKernelGGL((lz4_decompress_pair_kernel<false>), pgrid, pblock, 0, stream, b);
     }
     return launch_status();
   }
-#endif
-#if NVCOMP_AMD_LZ4_VARIANT == 0
-  /* Two-kernel path when the caller's temp buffer holds the token index and the batch is large enough to fill
-   * the indexer's lanes (one lane per chunk; below the threshold the chase decoder's latency is lower). */
-  const lzi::Layout lay = batch_size >= nvcomp_amd_tuning::lz_index_min_batch
-                              ? lzi::carve(device_temp_ptr, temp_bytes, batch_size)
-                              : lzi::Layout{nullptr, nullptr, 0};
-  const uint32_t* only = nullptr;
-  if (lay.stride != 0) {
-    hipLaunchKernelGGL(lz4_index_kernel, dim3((unsigned)((batch_size + 63) / 64)), dim3(64), 0, stream,
-                       device_compressed_ptrs, device_compressed_bytes, batch_size, lay);
-    if (checked) {
-      hipLaunchKernelGGL((lz4_decompress_indexed_kernel<true>), grid, block, 0, stream, NVCOMP_LZ4_ARGS, lay);
-    } else {
-      hipLaunchKernelGGL((lz4_decompress_indexed_kernel<false>), grid, block, 0, stream, NVCOMP_LZ4_ARGS, lay);
+  /* Persistent waves when the caller's temp buffer holds the ticket counter: as many workgroups as stay resident. */
+  unsigned groups = (unsigned)((batch_size + kDecWaves - 1) / kDecWaves);
+  uint32_t* ticket = nullptr;
+#if NVCOMP_LZ_PERSISTENT
+  if (device_temp_ptr != nullptr && temp_bytes >= sizeof(uint32_t) && ((uintptr_t)device_temp_ptr & 3u) == 0) {
+    static const unsigned resident[2] = {
+        lzl::resident_workgroups(lz4_decompress_window_kernel<false>, 64 * kDecWaves),
+        lzl::resident_workgroups(lz4_decompress_window_kernel<true>, 64 * kDecWaves)};
+    const unsigned fit = resident[checked ? 1 : 0];
+    if (fit != 0 && fit < groups && hipMemsetAsync(device_temp_ptr, 0, sizeof(uint32_t), stream) == hipSuccess) {
+      ticket = (uint32_t*)device_temp_ptr;
+      groups = fit;
     }
-    only = lay.counts; /* chunks the index leaves out (> 65535 bytes, row overflow) fall to the chase decoder */
-  }
-  if (batch_size >= kSingleWaveFromBatch) {
-    const dim3 grid1((unsigned)batch_size), block1(64);
-    if (checked) {
-      hipLaunchKernelGGL((lz4_decompress_window_kernel<true, 0, 1>), grid1, block1, 0, stream, NVCOMP_LZ4_ARGS, only);
-    } else {
-      hipLaunchKernelGGL((lz4_decompress_window_kernel<false, 0, 1>), grid1, block1, 0, stream, NVCOMP_LZ4_ARGS, only);
-    }
-  } else if (checked) {
-    hipLaunchKernelGGL((lz4_decompress_window_kernel<true>), grid, block, 0, stream, NVCOMP_LZ4_ARGS, only);
-  } else {
-    hipLaunchKernelGGL((lz4_decompress_window_kernel<false>), grid, block, 0, stream, NVCOMP_LZ4_ARGS, only);
-  }
-#elif NVCOMP_AMD_LZ4_VARIANT == 11
-  hipLaunchKernelGGL((lz4_decompress_window_kernel<false, 1>), grid, block, 0, stream, NVCOMP_LZ4_ARGS, nullptr);
-#elif NVCOMP_AMD_LZ4_VARIANT == 12
-  hipLaunchKernelGGL((lz4_decompress_window_kernel<false, 2>), grid, block, 0, stream, NVCOMP_LZ4_ARGS, nullptr);
-#elif NVCOMP_AMD_LZ4_VARIANT == 3 /* the round-1 decoder: chase inside the decode kernel, whatever the batch size */
-  if (checked) {
-    hipLaunchKernelGGL((lz4_decompress_window_kernel<true>), grid, block, 0, stream, NVCOMP_LZ4_ARGS, nullptr);
-  } else {
-    hipLaunchKernelGGL((lz4_decompress_window_kernel<false>), grid, block, 0, stream, NVCOMP_LZ4_ARGS, nullptr);
-  }
-#else
-  if (checked) {
-    hipLaunchKernelGGL((lz4_decompress_kernel<true, NVCOMP_AMD_LZ4_VARIANT == 1>), grid, block, 0, stream, NVCOMP_LZ4_ARGS);
-  } else {
-    hipLaunchKernelGGL((lz4_decompress_kernel<false, NVCOMP_AMD_LZ4_VARIANT == 1>), grid, block, 0, stream, NVCOMP_LZ4_ARGS);
   }
 #endif
-#undef NVCOMP_LZ4_ARGS
-  (void)temp_bytes;
+  if (checked) {
+    hipLaunchKernelGGL((lz4_decompress_window_kernel<true>), dim3(groups), dim3(64 * kDecWaves), 0, stream, b, ticket);
+  } else {
+    hipLaunchKernelGGL((lz4_decompress_window_kernel<false>), dim3(groups), dim3(64 * kDecWaves), 0, stream, b, ticket);
+  }
   return launch_status();
 }
 

@@ -11,16 +11,14 @@
 
 #include "common/log.h"
 
+#include "common/lz_launch.hip.h"
 #include "snappy/snappy_decode.hip.h"
-#include "common/tuning.h"
 #include "snappy/snappy_decode_window.hip.h"
 #include "snappy/snappy_encode.hip.h"
 
 namespace {
 
 constexpr unsigned kWavesPerBlock = 4; /* 256-thread workgroups, one chunk per wave */
-/* The decoders' workgroup size is a tuning parameter of its own: a workgroup's LDS is released when its LAST wave ends, and
- * chunks of a mixed batch take very different times. */
 #ifndef NVCOMP_LZ_DEC_WAVES_PER_BLOCK
 #define NVCOMP_LZ_DEC_WAVES_PER_BLOCK 4
 #endif
@@ -28,44 +26,17 @@ constexpr unsigned kDecWaves = NVCOMP_LZ_DEC_WAVES_PER_BLOCK;
 #ifndef NVCOMP_LZM_WAVES_PER_BLOCK
 #define NVCOMP_LZM_WAVES_PER_BLOCK 4
 #endif
-constexpr unsigned kEncWaves = NVCOMP_LZM_WAVES_PER_BLOCK; /* the compressors' workgroup size, same reasoning */
-constexpr uint32_t kMaxOutCap = 1u << 26;
+constexpr unsigned kEncWaves = NVCOMP_LZM_WAVES_PER_BLOCK; /* the compressors' workgroup size */
+using lzl::kMaxOutCap;
 
-/* A/B kernels exist in measurement builds only (scripts/build_variants.sh passes -DNVCOMP_AMD_SNAPPY_VARIANT=1 direct:
- * sequence-parallel straight to HBM (snappy_decode.hip.h) | 2 serial: one sequence per step, the ablation baseline);
- * the shipped library has exactly one decoder and no run-time switch. */
-#ifndef NVCOMP_AMD_SNAPPY_VARIANT
-#define NVCOMP_AMD_SNAPPY_VARIANT 0
-#endif
-constexpr int snappy_decode_variant()
+/* Decode chunk `chunk` of the batch with the calling wave and report its size and status. */
+template <bool CHECKED>
+__device__ __forceinline__ void decode_one(const lzl::Batch& b, size_t chunk, uint8_t* lds)
 {
-  return NVCOMP_AMD_SNAPPY_VARIANT;
-}
-
-/* WAVES = chunks (waves) per workgroup: one for batches that fill the card (mix, 65 536 chunks: 350 -> 370 GB/s; int32
- * column, 16 384 chunks: 608 -> 598); api/lz4_api.hip has the whole table. */
-constexpr size_t kSingleWaveFromBatch = 8192;
-
-template <bool CHECKED, unsigned WAVES = kDecWaves>
-__global__ void __launch_bounds__(64 * WAVES, NVCOMP_LZW_WAVES_PER_SIMD) snappy_decompress_window_kernel(
-    const void* const* __restrict__ comp_ptrs,
-    const size_t* __restrict__ comp_bytes,
-    const size_t* out_caps,
-    size_t* actual_bytes,
-    size_t batch_size,
-    void* const* __restrict__ out_ptrs,
-    nvcompStatus_t* statuses)
-{
-  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES][lzg::kLdsPerWave];
-  const uint32_t w = wave::uniform(threadIdx.x >> 6);
-  const size_t chunk = (size_t)blockIdx.x * WAVES + w;
-  if (chunk >= batch_size) {
-    return;
-  }
-  const uint8_t* in = wave::uniform_ptr((const uint8_t*)comp_ptrs[chunk]);
-  uint8_t* out = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
-  const size_t in_len64 = wave::uniform64(comp_bytes[chunk]);
-  size_t cap64 = wave::uniform64(out_caps[chunk]);
+  const uint8_t* in = wave::uniform_ptr((const uint8_t*)b.comp_ptrs[chunk]);
+  uint8_t* out = wave::uniform_ptr((uint8_t*)b.out_ptrs[chunk]);
+  const size_t in_len64 = wave::uniform64(b.comp_bytes[chunk]);
+  size_t cap64 = wave::uniform64(b.out_caps[chunk]);
   if (cap64 > kMaxOutCap) {
     cap64 = kMaxOutCap;
   }
@@ -74,44 +45,54 @@ __global__ void __launch_bounds__(64 * WAVES, NVCOMP_LZW_WAVES_PER_SIMD) snappy_
   if (in_len64 > 0xffffffffull - 64) {
     err = lz::kErrInput;
   } else {
-    produced = snappyw::decode_chunk<CHECKED>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds[w], err);
+    produced = snappyw::decode_chunk<CHECKED>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err);
   }
   if (wave::lane_id() == 0) {
-    if (actual_bytes != nullptr) {
-      actual_bytes[chunk] = err ? 0 : produced;
+    if (b.actual_bytes != nullptr) {
+      b.actual_bytes[chunk] = err ? 0 : produced;
     }
     if (CHECKED) {
-      statuses[chunk] = err ? nvcompErrorCannotDecompress : nvcompSuccess;
+      b.statuses[chunk] = err ? nvcompErrorCannotDecompress : nvcompSuccess;
     }
   }
 }
 
-#if !NVCOMP_LZ_GATHER
+/* One wave per chunk at a time; with a ticket counter the waves are persistent (common/lz_launch.hip.h). */
+template <bool CHECKED>
+__global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_WAVES_PER_SIMD) snappy_decompress_window_kernel(
+    const lzl::Batch b, uint32_t* ticket)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kDecWaves][lzw::kLdsPerWave];
+  const uint32_t w = wave::uniform(threadIdx.x >> 6);
+  const size_t first_dynamic = (size_t)gridDim.x * kDecWaves;
+  size_t chunk = (size_t)blockIdx.x * kDecWaves + w;
+  while (chunk < b.batch_size) {
+    decode_one<CHECKED>(b, chunk, lds[w]);
+    if (ticket == nullptr) {
+      break;
+    }
+    chunk = lzl::next_chunk(ticket, first_dynamic);
+  }
+}
+
 /* Small batches: two waves per chunk, a producer (chase + parse) and a consumer (execute), snappyw::pair. */
 template <bool CHECKED>
-__global__ void __launch_bounds__(128, 4) snappy_decompress_pair_kernel(
-    const void* const* __restrict__ comp_ptrs,
-    const size_t* __restrict__ comp_bytes,
-    const size_t* out_caps,
-    size_t* actual_bytes,
-    size_t batch_size,
-    void* const* __restrict__ out_ptrs,
-    nvcompStatus_t* statuses)
+__global__ void __launch_bounds__(128, 4) snappy_decompress_pair_kernel(const lzl::Batch b)
 {
   __shared__ __attribute__((aligned(16))) uint8_t lds[lzw::pair::kLdsPerChunk];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
   const size_t chunk = blockIdx.x;
-  if (chunk >= batch_size) {
+  if (chunk >= b.batch_size) {
     return;
   }
   if (threadIdx.x < 4) {
     ((uint32_t*)(lds + lzw::pair::kLdsPerChunk - lzw::pair::kCtrlBytes))[threadIdx.x] = 0; /* both slots empty, no abort */
   }
   __syncthreads();
-  const uint8_t* in = wave::uniform_ptr((const uint8_t*)comp_ptrs[chunk]);
-  uint8_t* out = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
-  const size_t in_len64 = wave::uniform64(comp_bytes[chunk]);
-  size_t cap64 = wave::uniform64(out_caps[chunk]);
+  const uint8_t* in = wave::uniform_ptr((const uint8_t*)b.comp_ptrs[chunk]);
+  uint8_t* out = wave::uniform_ptr((uint8_t*)b.out_ptrs[chunk]);
+  const size_t in_len64 = wave::uniform64(b.comp_bytes[chunk]);
+  size_t cap64 = wave::uniform64(b.out_caps[chunk]);
   if (cap64 > kMaxOutCap) {
     cap64 = kMaxOutCap;
   }
@@ -128,50 +109,11 @@ __global__ void __launch_bounds__(128, 4) snappy_decompress_pair_kernel(
     produced = snappyw::pair::consume<CHECKED>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err);
   }
   if (wave::lane_id() == 0) {
-    if (actual_bytes != nullptr) {
-      actual_bytes[chunk] = err ? 0 : produced;
+    if (b.actual_bytes != nullptr) {
+      b.actual_bytes[chunk] = err ? 0 : produced;
     }
     if (CHECKED) {
-      statuses[chunk] = err ? nvcompErrorCannotDecompress : nvcompSuccess;
-    }
-  }
-}
-#endif
-
-template <bool CHECKED, bool LANE_PARALLEL>
-__global__ void __launch_bounds__(64 * kDecWaves) snappy_decompress_kernel(
-    const void* const* __restrict__ comp_ptrs,
-    const size_t* __restrict__ comp_bytes,
-    const size_t* out_caps,
-    size_t* actual_bytes,
-    size_t batch_size,
-    void* const* __restrict__ out_ptrs,
-    nvcompStatus_t* statuses)
-{
-  const size_t chunk = (size_t)blockIdx.x * kDecWaves + wave::uniform(threadIdx.x >> 6);
-  if (chunk >= batch_size) {
-    return;
-  }
-  const uint8_t* in = wave::uniform_ptr((const uint8_t*)comp_ptrs[chunk]);
-  uint8_t* out = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
-  const size_t in_len64 = wave::uniform64(comp_bytes[chunk]);
-  size_t cap64 = wave::uniform64(out_caps[chunk]);
-  if (cap64 > kMaxOutCap) {
-    cap64 = kMaxOutCap;
-  }
-  uint32_t err = lz::kErrNone;
-  uint32_t produced = 0;
-  if (in_len64 > 0xffffffffull - 8) {
-    err = lz::kErrInput;
-  } else {
-    produced = snappy::decode_chunk<CHECKED, LANE_PARALLEL>(in, (uint32_t)in_len64, out, (uint32_t)cap64, err);
-  }
-  if (wave::lane_id() == 0) {
-    if (actual_bytes != nullptr) {
-      actual_bytes[chunk] = err ? 0 : produced;
-    }
-    if (CHECKED) {
-      statuses[chunk] = err ? nvcompErrorCannotDecompress : nvcompSuccess;
+      b.statuses[chunk] = err ? nvcompErrorCannotDecompress : nvcompSuccess;
     }
   }
 }
@@ -252,12 +194,13 @@ bool snappy_opts_ok(nvcompBatchedSnappyOpts_t opts)
 extern "C" {
 
 nvcompStatus_t nvcompBatchedSnappyDecompressGetTempSize(
-    size_t /*num_chunks*/, size_t /*max_uncompressed_chunk_bytes*/, size_t* temp_bytes)
+    size_t num_chunks, size_t /*max_uncompressed_chunk_bytes*/, size_t* temp_bytes)
 {
   if (temp_bytes == nullptr) {
     return nvcompErrorInvalidValue;
   }
-  *temp_bytes = 0; /* the decoder keeps all state in registers */
+  /* the persistent waves' ticket counter (common/lz_launch.hip.h); the decoder itself keeps all state in registers and LDS */
+  *temp_bytes = num_chunks > lzl::kPairMaxBatch ? lzl::kTicketBytes : 0;
   return nvcompSuccess;
 }
 
@@ -273,14 +216,15 @@ nvcompStatus_t nvcompBatchedSnappyDecompressAsync(
     const size_t* device_uncompressed_bytes,
     size_t* device_actual_uncompressed_bytes,
     size_t batch_size,
-    void* const /*device_temp_ptr*/,
-    size_t /*temp_bytes*/,
+    void* const device_temp_ptr,
+    size_t temp_bytes,
     void* const* device_uncompressed_ptrs,
     nvcompStatus_t* device_statuses,
     hipStream_t stream)
 {
-  nvlog::call(3, "nvcompBatchedSnappyDecompressAsync(batch_size=%zu, statuses=%s, actual_sizes=%s, stream=%p)", batch_size,
-              device_statuses ? "yes" : "null", device_actual_uncompressed_bytes ? "yes" : "null", (void*)stream);
+  nvlog::call(3, "nvcompBatchedSnappyDecompressAsync(batch_size=%zu, statuses=%s, actual_sizes=%s, temp_bytes=%zu, stream=%p)",
+              batch_size, device_statuses ? "yes" : "null", device_actual_uncompressed_bytes ? "yes" : "null", temp_bytes,
+              (void*)stream);
   if (batch_size == 0) {
     return nvcompSuccess;
   }
@@ -289,70 +233,39 @@ nvcompStatus_t nvcompBatchedSnappyDecompressAsync(
     return nvcompErrorInvalidValue;
   }
   clear_stale_error();
-  const dim3 grid((unsigned)((batch_size + kDecWaves - 1) / kDecWaves));
-  const dim3 block(64 * kDecWaves);
   const bool checked = device_statuses != nullptr;
-  const int variant = snappy_decode_variant();
-  const bool serial = variant == 2;
-#if !NVCOMP_LZ_GATHER
-  /* Small batches cannot fill the card with one wave per chunk: two waves per chunk (include/nvcomp/amd_ext.h). */
-  if (variant == 0 && batch_size <= nvcomp_amd_tuning::lz_pair_max_batch) {
+  const lzl::Batch b = {device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
+                        device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, (int*)device_statuses};
+  /* Small batches cannot fill the card with one wave per chunk: two waves per chunk (producer / consumer). */
+  if (batch_size <= lzl::kPairMaxBatch) {
     const dim3 pgrid((unsigned)batch_size), pblock(128);
     if (checked) {
-      hipLaunchKernelGGL((snappy_decompress_pair_kernel<true>), pgrid, pblock, 0, stream, device_compressed_ptrs,
-                         device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,
-                         batch_size, device_uncompressed_ptrs, device_statuses);
+      hipLaunchKernelGGL((snappy_decompress_pair_kernel<true>), pgrid, pblock, 0, stream, b);
     } else {
-      hipLaunchKernelGGL((snappy_decompress_pair_kernel<false>), pgrid, pblock, 0, stream, device_compressed_ptrs,
-                         device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,
-                         batch_size, device_uncompressed_ptrs, device_statuses);
+      hipLaunchKernelGGL((snappy_decompress_pair_kernel<false>), pgrid, pblock, 0, stream, b);
     }
     return launch_status();
+  }
+  /* Persistent waves when the caller's temp buffer holds the ticket counter: as many workgroups as stay resident. */
+  unsigned groups = (unsigned)((batch_size + kDecWaves - 1) / kDecWaves);
+  uint32_t* ticket = nullptr;
+#if NVCOMP_LZ_PERSISTENT
+  if (device_temp_ptr != nullptr && temp_bytes >= sizeof(uint32_t) && ((uintptr_t)device_temp_ptr & 3u) == 0) {
+    static const unsigned resident[2] = {
+        lzl::resident_workgroups(snappy_decompress_window_kernel<false>, 64 * kDecWaves),
+        lzl::resident_workgroups(snappy_decompress_window_kernel<true>, 64 * kDecWaves)};
+    const unsigned fit = resident[checked ? 1 : 0];
+    if (fit != 0 && fit < groups && hipMemsetAsync(device_temp_ptr, 0, sizeof(uint32_t), stream) == hipSuccess) {
+      ticket = (uint32_t*)device_temp_ptr;
+      groups = fit;
+    }
   }
 #endif
-  if (variant == 0 && batch_size >= kSingleWaveFromBatch) {
-    const dim3 grid1((unsigned)batch_size), block1(64);
-    if (checked) {
-      hipLaunchKernelGGL((snappy_decompress_window_kernel<true, 1>), grid1, block1, 0, stream, device_compressed_ptrs,
-                         device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,
-                         batch_size, device_uncompressed_ptrs, device_statuses);
-    } else {
-      hipLaunchKernelGGL((snappy_decompress_window_kernel<false, 1>), grid1, block1, 0, stream, device_compressed_ptrs,
-                         device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,
-                         batch_size, device_uncompressed_ptrs, device_statuses);
-    }
-    return launch_status();
-  }
-  if (variant == 0) {
-    if (checked) {
-      hipLaunchKernelGGL((snappy_decompress_window_kernel<true>), grid, block, 0, stream, device_compressed_ptrs,
-                         device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,
-                         batch_size, device_uncompressed_ptrs, device_statuses);
-    } else {
-      hipLaunchKernelGGL((snappy_decompress_window_kernel<false>), grid, block, 0, stream, device_compressed_ptrs,
-                         device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,
-                         batch_size, device_uncompressed_ptrs, device_statuses);
-    }
-    return launch_status();
-  }
-#define NVCOMP_SNAPPY_LAUNCH(C, P)                                                                               \
-  hipLaunchKernelGGL((snappy_decompress_kernel<C, P>), grid, block, 0, stream, device_compressed_ptrs,           \
-                     device_compressed_bytes, device_uncompressed_bytes, device_actual_uncompressed_bytes,   \
-                     batch_size, device_uncompressed_ptrs, device_statuses)
   if (checked) {
-    if (serial) {
-      NVCOMP_SNAPPY_LAUNCH(true, false);
-    } else {
-      NVCOMP_SNAPPY_LAUNCH(true, true);
-    }
+    hipLaunchKernelGGL((snappy_decompress_window_kernel<true>), dim3(groups), dim3(64 * kDecWaves), 0, stream, b, ticket);
   } else {
-    if (serial) {
-      NVCOMP_SNAPPY_LAUNCH(false, false);
-    } else {
-      NVCOMP_SNAPPY_LAUNCH(false, true);
-    }
+    hipLaunchKernelGGL((snappy_decompress_window_kernel<false>), dim3(groups), dim3(64 * kDecWaves), 0, stream, b, ticket);
   }
-#undef NVCOMP_SNAPPY_LAUNCH
   return launch_status();
 }
 

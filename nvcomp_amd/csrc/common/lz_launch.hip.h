@@ -1,0 +1,74 @@
+/*
+ * common/lz_launch.hip.h -- how the batched LZ decoders (LZ4, Snappy) put a batch on the card.
+ *
+ * PERSISTENT WAVES. One wavefront decodes one chunk at a time, but a launch has only as many workgroups as the
+ * card keeps resident; a wave that finishes its chunk takes the next one from a ticket counter in the caller's temp
+ * buffer. Chunks of one batch take very different times (the mix: 5x), and with one chunk per wave and four waves per
+ * workgroup a workgroup's LDS and wave slots stay allocated until its SLOWEST chunk ends; one-wave workgroups fix that
+ * and pay four times as many workgroup launches instead (measured in round 2: +2 % on the mix, -7 % on uniformly fast
+ * chunks). Persistent waves have neither cost. The counter is cleared by a 4-byte hipMemsetAsync on the caller's
+ * stream in front of the kernel; without a temp buffer (a caller that passes NULL) the launch falls back to one
+ * wave per chunk, statically.
+ *
+ * PATH BY BATCH SIZE. Batches of at most kPairMaxBatch chunks cannot fill the card with one wave per chunk and run
+ * two waves per chunk (producer / consumer, lz4_decode_window.hip.h: pair). The threshold is a compile-time
+ * constant: the library has no run-time tuning state (tests force either path with an A/B build of this file's macro).
+ */
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common/wave.h"
+
+#ifndef NVCOMP_LZ_PAIR_MAX_BATCH
+#define NVCOMP_LZ_PAIR_MAX_BATCH 3072 /* profiles/r02_pair_decode.json: two waves per chunk win up to ~3 000 chunks */
+#endif
+#ifndef NVCOMP_LZ_PERSISTENT
+#define NVCOMP_LZ_PERSISTENT 1 /* A/B: 0 = one wave per chunk, static mapping (round 2) */
+#endif
+
+namespace lzl {
+
+constexpr size_t kPairMaxBatch = (size_t)(NVCOMP_LZ_PAIR_MAX_BATCH);
+constexpr uint32_t kMaxOutCap = 1u << 26;
+constexpr size_t kTicketBytes = 16; /* what the temp-size queries ask for: one u32 counter, padded */
+
+/* The caller's arrays of one nvcompBatched<Fmt>DecompressAsync call. */
+struct Batch
+{
+  const void* const* comp_ptrs;
+  const size_t* comp_bytes;
+  const size_t* out_caps;
+  size_t* actual_bytes;
+  size_t batch_size;
+  void* const* out_ptrs;
+  int* statuses; /* nvcompStatus_t* */
+};
+
+/* The wave's next chunk: `first_dynamic` + a ticket (lane 0 draws it, the wave shares it). */
+__device__ __forceinline__ size_t next_chunk(uint32_t* ticket, size_t first_dynamic)
+{
+  uint32_t t = 0;
+  if (wave::lane_id() == 0) {
+    t = atomicAdd(ticket, 1u);
+  }
+  return first_dynamic + wave::uniform(wave::read_lane(t, 0));
+}
+
+/* Workgroups of `kernel` (block threads, static LDS) the current device keeps resident at once; 0 when the runtime
+ * cannot tell (the launch is then static). Asked once per kernel and device. */
+template <class Kernel>
+inline unsigned resident_workgroups(Kernel kernel, unsigned block_threads)
+{
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess
+      || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess
+      || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)block_threads, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return cus > 0 && per_cu > 0 ? (unsigned)cus * (unsigned)per_cu : 0u;
+}
+
+} // namespace lzl

@@ -26,13 +26,6 @@
 
 namespace lzw {
 
-/* Which batch executor the decoders use (A/B builds of scripts/build_variants.sh): 0 = execute_window_batch below, the
- * lane-per-sequence copies (default: 455 GB/s on the headline); 1 = the byte-gather executor of common/lz_gather.hip.h
- * (331 GB/s: more vector instructions per batch and 4-5 waves/SIMD). Both produce the same bytes. */
-#ifndef NVCOMP_LZ_GATHER
-#define NVCOMP_LZ_GATHER 0
-#endif
-
 /* Tunables (overridable with -D for the A/B builds of scripts/build_variants.sh). */
 /* Defaults from the MI355X sweeps of profiles/r01_window_variants.json, r01_pchase_variants.json and
  * r01_occupancy_variants.json: a small window at 6-7 waves/SIMD beats a large one -- the decoder is
@@ -87,11 +80,6 @@ constexpr uint32_t kChaseWin = 256;                 /* stream positions one chas
 constexpr uint32_t kChaseLevels = 6;                /* jump tables for 1, 2, 4, 8, 16, 32 tokens ahead */
 constexpr uint32_t kChaseLds = NVCOMP_LZW_PCHASE ? kChaseLevels * kChaseWin : 0;
 constexpr uint32_t kLdsPerWave = kOutLds + kInLds + kChaseLds;
-/* the decoder fed from the token index (common/lz_index.hip.h) builds no jump tables: 4 144 B per wave = 8 waves/SIMD */
-constexpr uint32_t kLdsPerWaveIndexed = kOutLds + kInLds;
-#ifndef NVCOMP_LZW_INDEXED_WAVES_PER_SIMD
-#define NVCOMP_LZW_INDEXED_WAVES_PER_SIMD 8
-#endif
 
 constexpr uint32_t kLitShort = 32;   /* lane-parallel literal runs: up to 8 dwords */
 constexpr uint32_t kMatchShort = 32; /* lane-parallel matches:      up to 8 dwords */
@@ -374,7 +362,6 @@ struct OutWindow
   uint32_t wbase;    /* output position of window index `align` (multiple of 16) */
   uint32_t valid_lo; /* positions >= valid_lo (and < op) are present in the window */
   uint32_t flushed;  /* positions < flushed are in HBM; valid_lo <= flushed <= op, op - flushed < 16 between batches */
-  uint8_t* scratch;  /* LDS, lzg::kScratch bytes: the gather executor's staging area and tables (common/lz_gather.hip.h) */
 };
 
 __device__ __forceinline__ void out_init(OutWindow& w, uint8_t* out, uint8_t* lds)
@@ -385,7 +372,6 @@ __device__ __forceinline__ void out_init(OutWindow& w, uint8_t* out, uint8_t* ld
   w.wbase = 0;
   w.valid_lo = 0;
   w.flushed = 0;
-  w.scratch = nullptr;
 }
 
 __device__ __forceinline__ uint8_t* out_at(const OutWindow& w, uint32_t pos)
@@ -465,6 +451,14 @@ __device__ __forceinline__ void out_flush(OutWindow& w, uint32_t op_end)
     if (!(NVCOMP_LZW_ABLATE_EXEC & 1)) out_flush_range(w, w.flushed, a_to - w.align);
     w.flushed = a_to - w.align;
   }
+}
+
+/* After a sequence was streamed HBM -> HBM behind the window's back (the callers' `big` path): restart the window at op. */
+__device__ __forceinline__ void restart_window(OutWindow& w, uint32_t op)
+{
+  w.wbase = op & ~15u;
+  w.valid_lo = op;
+  w.flushed = op;
 }
 
 /* Everything up to op_end, tail bytes included (end of the chunk, or before HBM-to-HBM copies). */

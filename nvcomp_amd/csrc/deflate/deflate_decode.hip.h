@@ -31,7 +31,7 @@
  */
 #pragma once
 
-#include "common/lz_gather.hip.h"
+#include "common/lz_window.hip.h"
 
 namespace deflate {
 

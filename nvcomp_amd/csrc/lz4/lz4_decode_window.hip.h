@@ -12,7 +12,7 @@
  */
 #pragma once
 
-#include "common/lz_gather.hip.h"
+#include "common/lz_window.hip.h"
 
 namespace lz4w {
 
@@ -325,7 +325,6 @@ __device__ __forceinline__ uint32_t decode_chunk(
   lzw::OutWindow ow;
   lzw::in_init(ir, in, in_len, lds + lzw::kOutLds);
   lzw::out_init(ow, out, lds);
-  lzg::attach_scratch(ow, lds + lzw::kOutLds + lzw::kInLds + lzw::kChaseLds);
 #if NVCOMP_LZW_PCHASE
   lzw::Chase c;
   lzw::chase_init(c, ir.vbeg, lds + lzw::kOutLds + lzw::kInLds);
@@ -396,7 +395,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
       }
     }
     bool big;
-    uint32_t take = lzg::execute_batch<CHECKED>(ir, ow, out_cap, op, count, s, err, big);
+    uint32_t take = lzw::execute_window_batch<CHECKED>(ir, ow, out_cap, op, count, s, err, big);
     if (CHECKED && err) {
       return 0;
     }
@@ -421,7 +420,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
         lz::wave_match_copy(out + op + llen, moff, mlen);
       }
       op += llen + mlen;
-      lzg::restart_window(ow, op);
+      lzw::restart_window(ow, op);
       take = 1;
     }
     /* drop the executed sequences, keep the rest for the next round */
@@ -571,7 +570,7 @@ __device__ __forceinline__ uint32_t consume(
       lzw::in_ensure(ir, oldest, (newest & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
     }
     bool big;
-    uint32_t take = lzg::execute_batch<CHECKED>(ir, ow, out_cap, op, count, s, err, big);
+    uint32_t take = lzw::execute_window_batch<CHECKED>(ir, ow, out_cap, op, count, s, err, big);
     if (CHECKED && err) {
       if (lane == 0) {
         wave::lds_store_release(sh.abort, 1u);
@@ -602,7 +601,7 @@ __device__ __forceinline__ uint32_t consume(
         lz::wave_match_copy(out + op + llen, moff, mlen);
       }
       op += llen + mlen;
-      lzg::restart_window(ow, op);
+      lzw::restart_window(ow, op);
       take = 1;
     }
     if (take < count) {
@@ -619,90 +618,5 @@ __device__ __forceinline__ uint32_t consume(
 }
 
 } // namespace pair
-
-/*
- * The same decoder fed from the token index (common/lz_index.hip.h, lz4_index.hip.h): `toks` holds the virtual
- * positions of the chunk's n_tok tokens, found beforehand by the lane-per-chunk indexer, so a batch of 64
- * sequences starts with one coalesced load instead of the jump-table chase. The positions of the next 128
- * tokens are kept in two registers per lane (tw0: index wbase + lane, tw1: wbase + 64 + lane), the refill of
- * tw1 being issued a whole batch before its first use. Parsing and validation are unchanged, so a corrupt
- * stream is reported exactly as by decode_chunk.
- */
-template <bool CHECKED>
-__device__ __forceinline__ uint32_t decode_chunk_indexed(
-    const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_cap, uint8_t* lds,
-    const uint16_t* __restrict__ toks, uint32_t n_tok, uint32_t& err)
-{
-  const uint32_t lane = (uint32_t)wave::lane_id();
-  err = lz::kErrNone;
-  if (in_len == 0) {
-    return 0;
-  }
-  lzw::InRing ir;
-  lzw::OutWindow ow;
-  lzw::in_init(ir, in, in_len, lds + lzw::kOutLds);
-  lzw::out_init(ow, out, lds);
-  lzg::attach_scratch(ow, lds + lzw::kOutLds + lzw::kInLds);
-  uint32_t op = 0;
-  uint32_t done = 0;  /* sequences executed */
-  uint32_t wbase = 0; /* token index of tw0 lane 0 */
-  uint32_t tw0 = lane < n_tok ? wave::gload_u16(toks + lane) : 0u;
-  uint32_t tw1 = 64 + lane < n_tok ? wave::gload_u16(toks + 64 + lane) : 0u;
-  while (done < n_tok) {
-    const uint32_t left = n_tok - done;
-    const uint32_t count = left < 64 ? left : 64u;
-    const uint32_t idx = done - wbase + lane; /* < 128 */
-    const uint32_t from0 = wave::shuffle(tw0, idx & 63u);
-    const uint32_t from1 = wave::shuffle(tw1, idx & 63u);
-    const uint32_t seqpos = idx < 64 ? from0 : from1;
-    const uint32_t oldest = wave::read_lane(seqpos, 0);
-    const uint32_t newest = wave::read_lane(seqpos, count - 1);
-    lzw::in_ensure(ir, oldest, (newest & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
-    lz::Seq s;
-    bool bad;
-    parse(ir, seqpos, lane < count, s, bad);
-    if (wave::ballot(bad)) {
-      err |= lz::kErrInput;
-      return 0;
-    }
-    bool big;
-    uint32_t take = lzg::execute_batch<CHECKED>(ir, ow, out_cap, op, count, s, err, big);
-    if (CHECKED && err) {
-      return 0;
-    }
-    if (big) {
-      /* sequence 0 alone exceeds a batch: stream it HBM -> HBM and restart the window after it */
-      const uint32_t lsrc = wave::read_lane(s.lit_src, 0);
-      const uint32_t llen = wave::read_lane(s.lit_len, 0);
-      const uint32_t moff = wave::read_lane(s.match_off, 0);
-      const uint32_t mlen = wave::read_lane(s.match_len, 0);
-      if (CHECKED) {
-        const uint64_t end = (uint64_t)op + llen + mlen;
-        if (end > out_cap || (mlen != 0 && (moff == 0 || moff > op + llen))) {
-          err |= end > out_cap ? lz::kErrOutput : lz::kErrOffset;
-          return 0;
-        }
-      }
-      lzw::out_flush_all(ow, op);
-      wave::sync();
-      lz::wave_copy(out + op, ir.base + lsrc, llen);
-      wave::sync();
-      if (mlen) {
-        lz::wave_match_copy(out + op + llen, moff, mlen);
-      }
-      op += llen + mlen;
-      lzg::restart_window(ow, op);
-      take = 1;
-    }
-    done += take;
-    if (done - wbase >= 64) {
-      wbase += 64;
-      tw0 = tw1;
-      tw1 = wbase + 64 + lane < n_tok ? wave::gload_u16(toks + wbase + 64 + lane) : 0u;
-    }
-  }
-  lzw::out_flush_all(ow, op);
-  return op;
-}
 
 } // namespace lz4w

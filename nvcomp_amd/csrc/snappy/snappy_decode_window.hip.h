@@ -12,15 +12,15 @@
  * its elements are half as long as LZ4's sequences, so a batch of 64 fills a smaller window; 1472 bytes leave 5 104 B of
  * LDS per wave = 8 waves/SIMD, which this decoder (unlike LZ4's, which loses more to the spills of a 64-VGPR budget) turns
  * into +4.5 %. */
-#if !defined(NVCOMP_LZW_OUTWIN) && !(defined(NVCOMP_LZ_GATHER) && NVCOMP_LZ_GATHER)
+#if !defined(NVCOMP_LZW_OUTWIN)
 #define NVCOMP_LZW_OUTWIN 1472
 #define NVCOMP_LZW_BATCHMAX 736
 #define NVCOMP_LZW_KEEP 544
 #endif
-#if !defined(NVCOMP_LZW_WAVES_PER_SIMD) && !(defined(NVCOMP_LZ_GATHER) && NVCOMP_LZ_GATHER)
+#if !defined(NVCOMP_LZW_WAVES_PER_SIMD)
 #define NVCOMP_LZW_WAVES_PER_SIMD 7 /* 8 = a 64-VGPR budget: 12 spilled VGPRs since the parsed sequences stay in registers; 7: 339 vs 322 GB/s */
 #endif
-#include "common/lz_gather.hip.h"
+#include "common/lz_window.hip.h"
 
 namespace snappyw {
 
@@ -383,7 +383,6 @@ __device__ __forceinline__ uint32_t decode_chunk(
   lzw::OutWindow ow;
   lzw::in_init(ir, in, in_len, lds + lzw::kOutLds);
   lzw::out_init(ow, out, lds);
-  lzg::attach_scratch(ow, lds + lzw::kOutLds + lzw::kInLds + lzw::kChaseLds);
   lzw::in_ensure(ir, ir.vbeg, ir.vbeg + lzw::kInBlock);
   uint32_t q, total;
   if (!read_preamble(ir, q, total)) {
@@ -442,7 +441,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
     }
     const uint64_t train = merge_trains(s, count);
     bool big;
-    uint32_t take = lzg::execute_batch<CHECKED>(ir, ow, limit, op, count, s, err, big);
+    uint32_t take = lzw::execute_window_batch<CHECKED>(ir, ow, limit, op, count, s, err, big);
     if (CHECKED && err) {
       return 0;
     }
@@ -466,7 +465,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
         lz::wave_match_copy(out + op + llen, moff, mlen);
       }
       op += llen + mlen;
-      lzg::restart_window(ow, op);
+      lzw::restart_window(ow, op);
       take = 1 + wave::ctz64(~(train >> 1)); /* sequence 0 and the empty sequences of its train */
     }
     if (take < count) {
@@ -622,7 +621,7 @@ __device__ __forceinline__ uint32_t consume(
       }
     }
     bool big;
-    uint32_t take = lzg::execute_batch<CHECKED>(ir, ow, limit, op, count, s, err, big);
+    uint32_t take = lzw::execute_window_batch<CHECKED>(ir, ow, limit, op, count, s, err, big);
     if (CHECKED && err) {
       if (lane == 0) {
         wave::lds_store_release(sh.abort, 1u);
@@ -652,7 +651,7 @@ __device__ __forceinline__ uint32_t consume(
         lz::wave_match_copy(out + op + llen, moff, mlen);
       }
       op += llen + mlen;
-      lzg::restart_window(ow, op);
+      lzw::restart_window(ow, op);
       /* sequence 0 and the empty sequences (the followers of its copy train) right behind it */
       const uint64_t empty = wave::ballot(lane < count && s.lit_len + s.match_len == 0);
       take = 1 + wave::ctz64(~(empty >> 1));

@@ -70,18 +70,30 @@ def emu_library():
     return _emu_lib
 
 
-_emu_gather_lib = None
+_emu_path_libs = {}
 
 
-def emu_gather_library():
-    """The same emulation build with the LZ decoders' alternative (byte-gather) batch executor compiled in."""
-    global _emu_gather_lib
-    if _emu_gather_lib is None:
+def emu_path_library(path):
+    """The emulation build with one LZ decode path forced whatever the batch size ("chase": one persistent wave per
+    chunk, "pair": two waves per chunk). The product picks by batch size (common/lz_launch.hip.h); these are A/B builds
+    of the same sources with another compile-time threshold."""
+    if path not in _emu_path_libs:
         from nvcomp_amd import _lib
 
-        emu_dir = _make_emu("gather")
-        _emu_gather_lib = _lib.declare(C.CDLL(os.path.join(emu_dir, "libnvcomp_emu_gather.so")))
-    return _emu_gather_lib
+        emu_dir = _make_emu(path)
+        _emu_path_libs[path] = _lib.declare(C.CDLL(os.path.join(emu_dir, f"libnvcomp_emu_{path}.so")))
+    return _emu_path_libs[path]
+
+
+_gpu_path_libs = {}
+
+
+def gpu_path_library(path):
+    if path not in _gpu_path_libs:
+        import nvcomp_amd
+
+        _gpu_path_libs[path] = nvcomp_amd.load_library(os.path.join(REPO, "nvcomp_amd", "lib", "alt", f"libnvcomp_{path}.so"))
+    return _gpu_path_libs[path]
 
 
 class Backend:
@@ -100,11 +112,6 @@ def emu():
 
 
 @pytest.fixture(scope="session")
-def emu_gather():
-    return Backend("emu", emu_gather_library(), HostDevice())
-
-
-@pytest.fixture(scope="session")
 def gpu():
     import nvcomp_amd
 
@@ -113,24 +120,19 @@ def gpu():
 
 @pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
 def backend(request):
-    """Every test through this fixture runs the LZ4 decoder on its two-kernel path (token index + indexed decoder:
-    opt-in in the library, include/nvcomp/amd_ext.h). Tests of the LZ decoders additionally ask for `lz_path` to see
-    the single-kernel chase decoder (the default for large batches) and the two-waves-per-chunk decoder (the default
-    for small ones) too."""
+    """The library exactly as shipped: the LZ decoders pick their path by batch size (two waves per chunk for small
+    batches, persistent waves above). Tests of the LZ decoders additionally ask for `lz_path`, which swaps in the A/B
+    builds that force either path whatever the batch size."""
     b = request.getfixturevalue(request.param)
-    b.lib.nvcompAmdSetLZPairMaxBatch(0)
-    b.lib.nvcompAmdSetLZIndexMinBatch(1)
-    return b
+    return Backend(b.name, b.lib, b.dev)
 
 
-@pytest.fixture(params=["indexed", "chase", "pair"])
+@pytest.fixture(params=["default", "chase", "pair"])
 def lz_path(request, backend):
-    """All decode paths of nvcompBatchedLZ4DecompressAsync, whatever the batch size."""
-    backend.lib.nvcompAmdSetLZPairMaxBatch((1 << 60) if request.param == "pair" else 0)
-    backend.lib.nvcompAmdSetLZIndexMinBatch(1 if request.param == "indexed" else 1 << 60)
-    yield request.param
-    backend.lib.nvcompAmdSetLZPairMaxBatch(0)
-    backend.lib.nvcompAmdSetLZIndexMinBatch(1)
+    """All decode paths of nvcompBatched{LZ4,Snappy}DecompressAsync, whatever the batch size."""
+    if request.param != "default":
+        backend.lib = (emu_path_library if backend.name == "emu" else gpu_path_library)(request.param)
+    return request.param
 
 
 @pytest.fixture(scope="session")

@@ -62,6 +62,11 @@ inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSucc
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+/* a "card" of one CU that keeps two workgroups resident: launches sized by residency (persistent waves,
+ * common/lz_launch.hip.h) draw almost all their chunks from the ticket counter, which is what the tests want to see */
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1 };
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 1; return hipSuccess; }
+template <class K> inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 2; return hipSuccess; }
 
 namespace emu {
 

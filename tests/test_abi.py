@@ -119,6 +119,21 @@ def test_no_runtime_kernel_switches():
     assert b"NVCOMP_AMD_LZ4_DECODE" not in blob and b"NVCOMP_AMD_SNAPPY_DECODE" not in blob
 
 
+def test_no_process_wide_tuning_state():
+    """a drop-in library has no setters. Which kernel a batch takes depends on the arguments of the call
+    alone (compile-time thresholds, common/lz_launch.hip.h), and the temp-size queries are pure functions of theirs."""
+    import re
+    import subprocess
+
+    so = os.path.join(REPO, "nvcomp_amd", "lib", "libnvcomp.so")
+    if not os.path.exists(so):
+        pytest.skip("library not built")
+    syms = subprocess.run(["nm", "-D", "--defined-only", so], check=True, capture_output=True, text=True).stdout
+    assert not re.findall(r"nvcompAmdSet\w*", syms), "the library must export no nvcompAmdSet* knobs"
+    hdr = open(os.path.join(REPO, "include", "nvcomp", "amd_ext.h")).read()
+    assert "nvcompAmdSet" not in hdr
+
+
 def test_cmake_package_exports_nvcomp_target(tmp_path):
     """find_package(nvcomp 3.0.3 REQUIRED) + nvcomp::nvcomp, as the reference's callers write it
     (CMakeLists.txt:18, cmake/nvcomp-config.cmake.in:25-26, benchmarks/CMakeLists.txt:28): a consumer configures, builds

@@ -117,3 +117,10 @@ def test_corrupt_deflate_streams_are_contained(backend, fmt):
             assert actual[i] == 0
             assert not ok or fmt == "Gzip", f"{fmt} chunk {i}: rejected a stream zlib reads"  # (gzip: we also check ISIZE of cut members)
     assert 0 < accepted < n
+    # device_statuses == NULL must not turn the bounds / match-offset checks off (these streams come from outside;
+    # only the status write is optional): same canaries, same sizes, same bytes where the stream was accepted
+    outs2, actual2, status2 = codec.decompress(bad, caps, checked=False)
+    assert status2 is None and actual2.tolist() == actual.tolist()
+    for i in range(n):
+        if status[i] == NvcompStatus.Success:
+            assert np.array_equal(outs2[i][: actual[i]], outs[i][: actual[i]])

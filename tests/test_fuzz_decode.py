@@ -55,25 +55,3 @@ def test_fuzz_structures(backend, lz_path, oracle, fmt, seed):
         rc, ref = dec(cc, c.size)
         assert rc == 0 and np.array_equal(ref, c)
         assert np.array_equal(o, c), f"chunk {i} (size {c.size}) differs at {int(np.argmax(o != c))}"
-
-
-@pytest.mark.parametrize("fmt", ["LZ4", "Snappy"])
-def test_gather_executor_variant(emu_gather, oracle, fmt):
-    """The alternative batch executor (common/lz_gather.hip.h, -DNVCOMP_LZ_GATHER=1: every lane gathers 16 output
-    bytes) is an A/B build, not the default; it must still produce the same bytes on the same structures."""
-    from nvcomp_amd import datasets
-
-    rng = np.random.RandomState(4242 + (fmt == "LZ4"))
-    sizes = [100, 5000, 65536, 70001]
-    chunks = [synth(rng, s) for s in sizes] + [datasets.text(30000, 3), datasets.table_rows(65536, 4)]
-    if fmt == "LZ4":
-        enc = (lambda c: oracle.ref_lz4_compress(c, 9)) if oracle.have_ref() else oracle.lz4_compress
-    else:
-        enc = oracle.ref_snappy_compress if oracle.have_ref() else oracle.snappy_compress
-    comp = [enc(c) for c in chunks]
-    emu_gather.lib.nvcompAmdSetLZIndexMinBatch(1 << 60)
-    outs, actual, status = emu_gather.codec(fmt).decompress(comp, [c.size for c in chunks], base_misalign=5)
-    assert (status == NvcompStatus.Success).all(), status
-    assert actual.tolist() == [c.size for c in chunks]
-    for i, (o, c) in enumerate(zip(outs, chunks)):
-        assert np.array_equal(o, c), f"chunk {i} differs at {int(np.argmax(o != c))}"

@@ -126,16 +126,14 @@ def test_corrupt_streams_do_not_escape(backend, lz_path, oracle):
 
 
 def test_batch_of_many_small_chunks(backend, oracle):
-    """8 200 chunks in one launch (the Snappy decoder changes its launch shape there, api/snappy_api.hip; LZ4 keeps its
-    own: both must decode every chunk)."""
+    """8 200 chunks in one launch: above the two-waves-per-chunk threshold, i.e. the persistent-wave launch as shipped
+    (common/lz_launch.hip.h): every chunk must be decoded exactly once."""
     if backend.name != "gpu":
         pytest.skip("8 200 workgroup launches take the emulator half a minute and exercise nothing the smaller batches do not")
-    backend.lib.nvcompAmdSetLZIndexMinBatch(1 << 60)  # the single-kernel decoder, whatever the batch size
     data = datasets.silesia_style(8200 * 384, 3)
     chunks = datasets.split_chunks(data, 384)
     assert len(chunks) >= 8192
     check_roundtrip(backend, oracle, chunks, cpu_compress(oracle, chunks))
-    backend.lib.nvcompAmdSetLZIndexMinBatch(1)
 
 
 def test_get_decompress_size(backend, oracle):
