@@ -509,7 +509,7 @@ def run_case(args, ctx):
                          "libsnappy RawUncompress" if use_ref else "oracle/ C port"),
         }
         # the CPU peer of the compress leg: the fast compressor of the same library on the same
-        # sample. libdeflate, which north_star also names, is not in this image (no header, no library): not timed.
+        # sample. (libdeflate, which north_star also names, is the CPU peer of the DEFLATE rider: extras.deflate.cpu_baseline.)
         enc = oracle.LZ4_ENC if args.algo == "lz4" else oracle.SNAPPY_ENC
         bound = (CHUNK + CHUNK // 255 + 16) if args.algo == "lz4" else (32 + CHUNK + CHUNK // 6)
         s_raw = chunks * reps
@@ -520,14 +520,16 @@ def run_case(args, ctx):
                 "ratio": round(unique * reps / max(1, sum(int(o.size) for o in couts)), 4),
                 "kind": "reference" if use_ref else "port",
                 "sample": ("liblz4 LZ4_compress_default" if args.algo == "lz4" else "libsnappy RawCompress") if use_ref
-                          else "oracle/ C port", "libdeflate": "not in this image: not timed"}
+                          else "oracle/ C port"}
     return finish(result, args, world, rt, data)
 
 
 def deflate_cpu_baseline(oracle, comp, chunks, threads, unique):
-    """zlib inflate (the reference's CPU peer, examples/deflate_cpu_decompression.cu:128-170) over the unique set repeated
-    until every thread has a few dozen chunks, one thread per core through the oracle/_ref shim (best of 3); the
-    compress peer: zlib level 1 on the same chunks. Without the shim: Python threads (zlib releases the GIL)."""
+    """The CPU peers of the DEFLATE path on this box's host cores, one C thread per core through the oracle/_ref shim, over
+    the unique set repeated until every thread has a few dozen chunks (best of 3): libdeflate_deflate_decompress -- the
+    peer BASELINE.json's north_star names and the reference's algo 0 (examples/deflate_cpu_compression.cu:60-67,
+    deflate_cpu_decompression.cu) -- is `value`; zlib inflate (algo 1/2, examples/deflate_cpu_decompression.cu:128-170)
+    rides beside it; the compress peers: libdeflate level 6 (as the reference calls it) and zlib level 1."""
     import zlib
 
     reps = max(1, min(16, (32 * threads) // max(1, len(comp))))
@@ -539,12 +541,26 @@ def deflate_cpu_baseline(oracle, comp, chunks, threads, unique):
         csecs, couts, cerrs = oracle.batch_run(oracle.ZLIB_DEFLATE_1, chunks * reps, [c + c // 8 + 64 for c in s_caps],
                                                threads=threads, repeats=1, use_ref=True)
         assert cerrs == 0
-        return {"value": round(total / secs / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "reference",
-                "sample": f"{total >> 20} MiB ({len(s_comp)} chunks) of the same workload, best of 3, zlib {zlib.ZLIB_VERSION} inflate "
-                          "(raw streams), one thread per core",
-                "compress": {"value": round(total / csecs / 1e9, 3), "unit": "GB/s", "cores": threads,
-                             "ratio": round(total / max(1, sum(int(o.size) for o in couts)), 4), "kind": "reference",
-                             "sample": "zlib deflate level 1"}}
+        sample = f"{total >> 20} MiB ({len(s_comp)} chunks) of the same workload, best of 3, one thread per core"
+        zl = {"value": round(total / secs / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "reference",
+              "sample": f"{sample}, zlib {zlib.ZLIB_VERSION} inflate (raw streams)",
+              "compress": {"value": round(total / csecs / 1e9, 3), "unit": "GB/s", "cores": threads,
+                           "ratio": round(total / max(1, sum(int(o.size) for o in couts)), 4), "kind": "reference",
+                           "sample": "zlib deflate level 1"}}
+        if not oracle.have_libdeflate():
+            return zl
+        lsecs, louts, lerrs = oracle.batch_run(oracle.LIBDEFLATE_DEC, s_comp, s_caps, threads=threads, repeats=3, use_ref=True)
+        assert lerrs == 0 and all(o.size == c for o, c in zip(louts, s_caps))
+        assert all(np.array_equal(o, c) for o, c in zip(louts[: len(chunks): 53], chunks[::53]))
+        esecs, eouts, eerrs = oracle.batch_run(oracle.LIBDEFLATE_ENC_6, chunks * reps, [c + c // 8 + 64 for c in s_caps],
+                                               threads=threads, repeats=2, use_ref=True)
+        assert eerrs == 0
+        return {"value": round(total / lsecs / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "reference",
+                "sample": f"{sample}, libdeflate_deflate_decompress (raw streams)",
+                "compress": {"value": round(total / esecs / 1e9, 3), "unit": "GB/s", "cores": threads,
+                             "ratio": round(total / max(1, sum(int(o.size) for o in eouts)), 4), "kind": "reference",
+                             "sample": "libdeflate_deflate_compress level 6 (examples/deflate_cpu_compression.cu:62)"},
+                "zlib": zl}
     from multiprocessing.pool import ThreadPool
 
     blobs = [c.tobytes() for c in comp] * reps
@@ -804,13 +820,17 @@ def rider(args, ctx, algo, **overrides):
 
     sargs = copy.copy(args)
     sargs.algo, sargs.no_extras, sargs.no_cpu_baseline, sargs.steps, sargs.warmup = algo, True, True, 5, 1
+    sargs.opts = ""
     for key, val in overrides.items():
         setattr(sargs, key, val)
     try:
         r = run_case(sargs, ctx)
-        return {"value": r["value"], "unit": "GB/s", "ms_per_step": r["ms_per_step"], "roofline": r["roofline"],
+        line = {"value": r["value"], "unit": "GB/s", "ms_per_step": r["ms_per_step"], "roofline": r["roofline"],
                 "ratio": r["config"]["ratio"], "producer": r["config"]["producer"], "verified": r["config"]["verified"],
-                "chunks_per_gpu": r["config"]["chunks_per_gpu"]}
+                "chunks_per_gpu": r["config"]["chunks_per_gpu"], "dataset": r["config"]["dataset"]}
+        if "cpu_baseline" in r:
+            line["cpu_baseline"] = r["cpu_baseline"]
+        return line
     except Exception as e:  # noqa: BLE001 -- reported, not raised: see the docstring
         return {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
 
@@ -849,7 +869,17 @@ def main():
         # north_star bars BOTH LZ decoders: the Snappy line of the same workload rides along (5 timed launches); so
         # does the DEFLATE decoder's, on a quarter of the workload
         result.setdefault("extras", {})["snappy"] = rider(args, ctx, "snappy")
-        result["extras"]["deflate"] = rider(args, ctx, "deflate", mib_per_gpu=min(args.mib_per_gpu, 1024), unique_mib=min(args.unique_mib, 32))
+        # ... with its CPU peers timed beside it: libdeflate (the one north_star names) and zlib
+        result["extras"]["deflate"] = rider(args, ctx, "deflate", mib_per_gpu=min(args.mib_per_gpu, 1024),
+                                            unique_mib=min(args.unique_mib, 32), no_cpu_baseline=args.no_cpu_baseline)
+        # BASELINE.json configs[3]: Cascaded {4096, int, 2 RLE, 1 delta, bit-packing} on the reference's own float columns
+        # (benchmarks/benchmark_cascaded_chunked.cu:35-36)
+        result["extras"]["cascaded"] = rider(args, ctx, "cascaded", dataset="example_float_columns",
+                                             mib_per_gpu=min(args.mib_per_gpu, 1024), unique_mib=min(args.unique_mib, 32))
+        # the one shape the reference publishes a number for (doc/Benchmarks.md:88-95: LZ4 on Mortgage 2009Q2 column 0,
+        # ratio 38.9, A100 decompress 320.7 GB/s): long matches and runs -- the data that CAN approach the roofline
+        result["extras"]["lz4_mortgage_like"] = rider(args, ctx, "lz4", dataset="mortgage_col0_like",
+                                                      mib_per_gpu=min(args.mib_per_gpu, 1024), unique_mib=min(args.unique_mib, 64))
     if args.dry_run_emu and args.allgather:
         result["value"] = None
         result["data"] = "DRY RUN on the CPU emulation of the kernels: not a measurement"

@@ -3,12 +3,13 @@
  * nvcompBatchedDeflateDecompressAsync (raw DEFLATE streams) or nvcompBatchedGzipDecompressAsync (gzip members),
  * byte-compare. The format pins of the reference: examples/deflate_cpu_compression.cu:58-104 (algo 1: compress2 with
  * the zlib wrapper cut off; algo 2: deflateInit2(9, windowBits -15)) and examples/gzip_gpu_decompression.cu:57-81
- * (deflateInit2(9, windowBits 15 | 16)). libdeflate (the reference's algo 0) is not in this image.
- * Usage: deflate_cpu_compression [-a 1|2|gzip] -f FILE [FILE...]
+ * (deflateInit2(9, windowBits 15 | 16)); algo 0 is libdeflate at level 6 (:60-67), the reference's default.
+ * Usage: deflate_cpu_compression [-a 0|1|2|gzip] -f FILE [FILE...]
  */
 #include <cstring>
 #include <iomanip>
 
+#include <libdeflate.h>
 #include <zlib.h>
 
 #include "nvcomp/deflate.h"
@@ -47,8 +48,8 @@ int main(int argc, char** argv)
         algo = argv[++i];
       }
     }
-    if (files.empty() || (algo != "1" && algo != "2" && algo != "gzip")) {
-      throw std::runtime_error("Usage: deflate_cpu_compression [-a 1|2|gzip] -f FILE [FILE...]");
+    if (files.empty() || (algo != "0" && algo != "1" && algo != "2" && algo != "gzip")) {
+      throw std::runtime_error("Usage: deflate_cpu_compression [-a 0|1|2|gzip] -f FILE [FILE...]");
     }
     const bool gz = algo == "gzip";
     const size_t chunk = 1 << 16;
@@ -58,7 +59,19 @@ int main(int argc, char** argv)
     std::vector<std::vector<char>> comp(n);
     for (size_t i = 0; i < n; ++i) {
       total += chunks[i].size();
-      if (algo == "1") { /* compress2, then the 2-byte header and the 4-byte Adler-32 are dropped */
+      if (algo == "0") { /* libdeflate, level 6 (examples/deflate_cpu_compression.cu:60-67) */
+        libdeflate_compressor* c = libdeflate_alloc_compressor(6);
+        if (c == nullptr) {
+          throw std::runtime_error("libdeflate_alloc_compressor failed");
+        }
+        comp[i].resize(libdeflate_deflate_compress_bound(c, chunks[i].size()));
+        const size_t len = libdeflate_deflate_compress(c, chunks[i].data(), chunks[i].size(), comp[i].data(), comp[i].size());
+        libdeflate_free_compressor(c);
+        if (len == 0) {
+          throw std::runtime_error("libdeflate_deflate_compress failed to compress chunk " + std::to_string(i) + ".");
+        }
+        comp[i].resize(len);
+      } else if (algo == "1") { /* compress2, then the 2-byte header and the 4-byte Adler-32 are dropped */
         uLongf len = compressBound((uLong)chunks[i].size());
         std::vector<char> z(len);
         if (compress2((Bytef*)z.data(), &len, (const Bytef*)chunks[i].data(), (uLong)chunks[i].size(), 9) != Z_OK) {

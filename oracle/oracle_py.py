@@ -24,6 +24,7 @@ _REF = os.path.join(_HERE, "_ref", "libcpucodecs.so")
 
 LZ4_DEC, SNAPPY_DEC, LZ4_ENC, SNAPPY_ENC, LZ4_ENC_HC = 0, 1, 2, 3, 4
 ZLIB_INFLATE, ZLIB_DEFLATE_1, ZLIB_DEFLATE_9 = 5, 6, 7  # the _ref shim only (zlib: the CPU peer of the DEFLATE path)
+LIBDEFLATE_DEC, LIBDEFLATE_ENC_6 = 8, 9  # the _ref shim only (libdeflate: the reference's algo 0 of the same examples)
 CASCADED_DEC, BITCOMP_DEC, ANS_DEC = 4, 5, 6  # oracle_batch_run only (the port library; 4 means HC in the reference shim)
 
 _u8p = C.POINTER(C.c_uint8)
@@ -33,7 +34,8 @@ _szp = C.POINTER(C.c_size_t)
 def build(force: bool = False) -> None:
     """Compile the oracle with gcc (seconds). The _ref shim is built only where
     the container's liblz4/snappy development files exist."""
-    if force or not os.path.exists(_PORT) or (not os.path.exists(_REF) and os.path.exists("/opt/conda/include/lz4.h")):
+    stale = os.path.exists(_REF) and os.path.getmtime(_REF) < os.path.getmtime(os.path.join(_HERE, "ref_shim.c"))
+    if force or stale or not os.path.exists(_PORT) or (not os.path.exists(_REF) and os.path.exists("/opt/conda/include/lz4.h")):
         subprocess.run(["make", "-C", _HERE, "all"], check=True, stdout=subprocess.DEVNULL)
 
 
@@ -107,6 +109,11 @@ class _Lib:
             r.ref_snappy_bound.restype = C.c_size_t
             r.ref_snappy_bound.argtypes = [C.c_size_t]
             r.ref_lz4_version.restype = C.c_int
+            if hasattr(r, "ref_libdeflate_decompress"):
+                for name in ("ref_libdeflate_decompress", "ref_libdeflate_compress"):
+                    f = getattr(r, name)
+                    f.restype = C.c_int
+                    f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _szp]
             r.ref_batch_run.restype = C.c_double
             r.ref_batch_run.argtypes = p.oracle_batch_run.argtypes
 
@@ -271,6 +278,29 @@ def ref_snappy_compress(raw) -> np.ndarray:
     rc = r.ref_snappy_compress(_ptr(src), src.size, _ptr(dst), cap, C.byref(out))
     assert rc == 0
     return dst[: out.value].copy()
+
+
+def have_libdeflate() -> bool:
+    return have_ref() and hasattr(lib().ref, "ref_libdeflate_decompress")
+
+
+def ref_libdeflate_compress(buf) -> np.ndarray:
+    """libdeflate_deflate_compress at level 6: what examples/deflate_cpu_compression.cu:60-67 (algo 0) writes."""
+    src = _as_u8(buf)
+    cap = src.size + src.size // 8 + 64
+    dst = np.empty(cap, dtype=np.uint8)
+    out = C.c_size_t(0)
+    rc = lib().ref.ref_libdeflate_compress(_ptr(src), src.size, _ptr(dst), cap, C.byref(out))
+    assert rc == 0
+    return dst[: out.value].copy()
+
+
+def ref_libdeflate_decompress(buf, cap: int):
+    src = _as_u8(buf)
+    dst = np.empty(max(cap, 1), dtype=np.uint8)
+    out = C.c_size_t(0)
+    rc = lib().ref.ref_libdeflate_decompress(_ptr(src), src.size, _ptr(dst), cap, C.byref(out))
+    return rc, dst[: out.value].copy()
 
 
 # ------------------------------------------------------------------- batches

@@ -9,12 +9,16 @@
  * /root/reference is compiled or copied here because the reference ships no
  * codec source (README.md:10) -- its codec path is "unbuildable" and these
  * libraries are the published implementations of the same wire formats. zlib (examples/deflate_cpu_compression.cu:69-104,
- * examples/deflate_cpu_decompression.cu:128-170: the CPU peer of the DEFLATE path) is bound the same way.
+ * examples/deflate_cpu_decompression.cu:128-170: the CPU peer of the DEFLATE path) is bound the same way, and so is
+ * libdeflate (/opt/conda: 1.8), the reference's algo 0 of the same examples (deflate_cpu_compression.cu:60-67:
+ * libdeflate_alloc_compressor(6), libdeflate_deflate_compress; deflate_cpu_decompression.cu: libdeflate_deflate_decompress)
+ * and the CPU peer BASELINE.json's north_star names beside liblz4.
  *
  * TEST INFRASTRUCTURE ONLY: used to pin the oracle sources, to make golden vectors
  * (scripts/make_golden.py), to prepare CPU-compressed inputs for tests and
  * bench.py, and as bench.py's cpu_baseline ("reference" kind).
  */
+#include <libdeflate.h>
 #include <lz4.h>
 #include <lz4hc.h>
 #include <snappy-c.h>
@@ -133,16 +137,45 @@ static int zlib_deflate_level(const uint8_t* s, size_t n, uint8_t* d, size_t cap
 static int r_zlib_deflate1(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out) { return zlib_deflate_level(s, n, d, cap, out, 1); }
 static int r_zlib_deflate9(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out) { return zlib_deflate_level(s, n, d, cap, out, 9); }
 
+/* libdeflate, raw DEFLATE streams; one compressor / decompressor per thread, kept (the reference's example allocates one
+ * per chunk: the figure that favours the CPU again) */
+static int r_libdeflate_dec(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out)
+{
+  static __thread struct libdeflate_decompressor* dec = NULL;
+  *out = 0;
+  if (dec == NULL && (dec = libdeflate_alloc_decompressor()) == NULL) {
+    return 1;
+  }
+  size_t got = 0;
+  const enum libdeflate_result r = libdeflate_deflate_decompress(dec, s, n, d, cap, &got);
+  *out = r == LIBDEFLATE_SUCCESS ? got : 0;
+  return r != LIBDEFLATE_SUCCESS;
+}
+static int r_libdeflate_enc6(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out)
+{
+  static __thread struct libdeflate_compressor* enc = NULL;
+  *out = 0;
+  if (enc == NULL && (enc = libdeflate_alloc_compressor(6)) == NULL) { /* level 6: deflate_cpu_compression.cu:62 */
+    return 1;
+  }
+  const size_t got = libdeflate_deflate_compress(enc, s, n, d, cap);
+  *out = got;
+  return got == 0 && n != 0;
+}
+int ref_libdeflate_decompress(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out) { return r_libdeflate_dec(s, n, d, cap, out); }
+int ref_libdeflate_compress(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out) { return r_libdeflate_enc6(s, n, d, cap, out); }
+size_t ref_libdeflate_bound(size_t n) { return libdeflate_deflate_compress_bound(NULL, n); }
+
 /* codec: 0 lz4 dec, 1 snappy dec, 2 lz4 enc (default), 3 snappy enc, 4 lz4 enc HC level 12, 5 zlib inflate (raw),
- * 6 zlib deflate level 1 (raw), 7 zlib deflate level 9 (raw) */
+ * 6 zlib deflate level 1 (raw), 7 zlib deflate level 9 (raw), 8 libdeflate decompress (raw), 9 libdeflate compress level 6 */
 double ref_batch_run(
     int codec, int threads, int repeats, size_t n_chunks,
     const uint8_t* const* in_ptrs, const size_t* in_sizes,
     uint8_t* const* out_ptrs, const size_t* out_caps, size_t* out_sizes, int* errors)
 {
-  static const batch_codec_fn table[8] = {r_lz4_dec, r_snappy_dec, r_lz4_enc, r_snappy_enc, r_lz4_enc_hc,
-                                          r_zlib_inflate, r_zlib_deflate1, r_zlib_deflate9};
-  if (codec < 0 || codec > 7) {
+  static const batch_codec_fn table[10] = {r_lz4_dec, r_snappy_dec, r_lz4_enc, r_snappy_enc, r_lz4_enc_hc,
+                                           r_zlib_inflate, r_zlib_deflate1, r_zlib_deflate9, r_libdeflate_dec, r_libdeflate_enc6};
+  if (codec < 0 || codec > 9) {
     return -1.0;
   }
   return batch_run_generic(

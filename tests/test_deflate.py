@@ -56,6 +56,24 @@ def check(backend, fmt, chunks, comp, **kw):
 CLASSES = ["text", "table", "float_csv", "float32", "int32", "lowcard", "zeros", "noise"]
 
 
+def test_libdeflate_streams(backend, oracle):
+    """The reference's DEFAULT CPU producer (examples/deflate_cpu_compression.cu:60-67, algo 0: libdeflate_alloc_compressor(6),
+    libdeflate_deflate_compress) through the container's libdeflate (oracle/_ref shim): its block splitting and code
+    construction differ from zlib's; every stream must decode to the original bytes, and libdeflate must read them back
+    too (the checker of the checker)."""
+    if not oracle.have_libdeflate():
+        pytest.skip("libdeflate is not in this container")
+    size = 65536 + 4321 if backend.name == "emu" else 3 * 65536 + 4321
+    chunks = []
+    for name in CLASSES:
+        chunks += datasets.split_chunks(datasets.CLASSES[name](size, 7))
+    comp = [oracle.ref_libdeflate_compress(c) for c in chunks]
+    for c, cc in zip(chunks[::5], comp[::5]):
+        rc, back = oracle.ref_libdeflate_decompress(cc, c.size)
+        assert rc == 0 and np.array_equal(back, c)
+    check(backend, "Deflate", chunks, comp)
+
+
 @pytest.mark.parametrize("name", CLASSES)
 def test_decode_classes(backend, name):
     size = 3 * 65536 + 4321 if backend.name == "gpu" else 65536 + 4321

@@ -76,7 +76,7 @@ def test_examples_on_gpu(built_programs, sample_files):
     assert "equals zlib's crc32()" in run(["examples/bin/standard_crc_checksum"])
     out = run(["examples/bin/nvcomp_storage", os.path.join(os.path.dirname(sample_files["table.txt"]), "storage.bin"), "30000000"])
     assert "PASSED: Uncompressed data is identical to the input" in out  # examples/nvcomp_gds.cu's round trip through a file
-    for algo in ("1", "2", "gzip"):  # zlib on the CPU -> the DEFLATE / gzip decoder (examples/deflate_cpu_compression.cu,
+    for algo in ("0", "1", "2", "gzip"):  # libdeflate (0) / zlib on the CPU -> the DEFLATE / gzip decoder (examples/deflate_cpu_compression.cu,
         out = run(["examples/bin/deflate_cpu_compression", "-a", algo, "-f", sample_files["table.txt"],  # gzip_gpu_decompression.cu)
                    sample_files["floats.csv"]])
         assert "decompression validated" in out
