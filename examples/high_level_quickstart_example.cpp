@@ -137,7 +137,8 @@ void multi_buffer_streamed(const uint8_t* d_in, const std::vector<uint8_t>& host
 
 } // namespace
 
-/* A manager decompresses what a manager of another chunk size wrote (the header carries the chunk size), refuses a
+/* A manager decompresses what a manager of another chunk size and other format options wrote (the header carries the
+ * chunk size, the decoders are driven by the stream alone), refuses a
  * buffer whose header does not add up, and a CascadedManager refuses a buffer that is not a whole number of elements
  * instead of dropping its tail. */
 void header_is_authoritative(const uint8_t* d_in, const std::vector<uint8_t>& host)
@@ -146,7 +147,8 @@ void header_is_authoritative(const uint8_t* d_in, const std::vector<uint8_t>& ho
   HIP_CHECK(hipStreamCreate(&stream));
   {
     nvcompBatchedLZ4Opts_t opts{NVCOMP_TYPE_CHAR};
-    LZ4Manager writer{1 << 15, opts, stream, 0, NoComputeNoVerify};
+    /* the writer declares 4-byte elements, the reader below does not: the options are the compressor's business */
+    LZ4Manager writer{1 << 15, nvcompBatchedLZ4Opts_t{NVCOMP_TYPE_INT}, stream, 0, NoComputeNoVerify};
     CompressionConfig cc = writer.configure_compression(host.size());
     DeviceBuf comp(cc.max_compressed_buffer_size);
     writer.compress(d_in, comp.p, cc);

@@ -60,7 +60,13 @@ nvcompStatus_t nvcompBatchedDeflateCompressGetMaxOutputChunkSize(
     size_t* max_compressed_bytes);
 
 /* reference call site: examples/deflate_cpu_decompression.cu:93-103 ; the output must be accepted by
- * libdeflate_deflate_decompress / zlib inflate (examples/deflate_cpu_decompression.cu:128-170) */
+ * libdeflate_deflate_decompress / zlib inflate (examples/deflate_cpu_decompression.cu:128-170)
+ *
+ * A chunk LARGER than max_uncompressed_chunk_bytes would not fit the output slot sized from
+ * ...CompressGetMaxOutputChunkSize(max_uncompressed_chunk_bytes): it is not compressed and its entry of
+ * device_compressed_bytes reads 0. The call still returns nvcompSuccess (it is asynchronous and has no per-chunk status
+ * array to write to): a caller that cannot vouch for its chunk sizes checks for 0; the nvcomp::*Manager layer does and
+ * reports nvcompErrorInvalidValue through the compression status. */
 nvcompStatus_t nvcompBatchedDeflateCompressAsync(
     const void* const* device_uncompressed_ptrs,
     const size_t* device_uncompressed_bytes,

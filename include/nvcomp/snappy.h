@@ -63,7 +63,14 @@ nvcompStatus_t nvcompBatchedSnappyCompressGetMaxOutputChunkSize(
     size_t* max_compressed_bytes);
 
 /* reference call site: benchmarks/benchmark_template_chunked.cuh:441-451 ;
- * doc/lowlevel_c_quickstart.md:53-63 ; benchmarks/benchmark_snappy_synth.cpp:163-173 */
+ * doc/lowlevel_c_quickstart.md:53-63 ; benchmarks/benchmark_snappy_synth.cpp:163-173
+ *
+ * A chunk LARGER than max_uncompressed_chunk_bytes would not fit the output slot sized from
+ * ...CompressGetMaxOutputChunkSize(max_uncompressed_chunk_bytes): it is not compressed and its entry of
+ * device_compressed_bytes reads 0 (no other chunk has a compressed size of 0 unless it was empty itself). The call
+ * still returns nvcompSuccess -- it is asynchronous and has no per-chunk status array to write to -- so a caller
+ * that cannot vouch for its chunk sizes checks for 0; the nvcomp::*Manager layer does and reports
+ * nvcompErrorInvalidValue through the compression status. */
 nvcompStatus_t nvcompBatchedSnappyCompressAsync(
     const void* const* device_uncompressed_ptrs,
     const size_t* device_uncompressed_bytes,

@@ -34,11 +34,13 @@ __host__ __device__ inline size_t stored_size(size_t n)
   return n + 5 * (n / kStoredMax + 1);
 }
 
-/* Worst case of the fixed code: 9 bits per byte + block header + end of block, rounded up; the stored form is
- * smaller, and is what such a chunk ends up as -- but the attempt is written into the same slot first. */
+/* Worst case of an ATTEMPT, which is written into the slot before the stored form is chosen instead: 9 bits per byte
+ * (the fixed code; a per-chunk Huffman code built over counts that start at one costs at most one bit per symbol more
+ * than the 8-bit code) + block header + end of block + the per-chunk code's own header (316 code lengths of 7 bits and
+ * the 19 of the code-length code: under 300 bytes), rounded up. */
 __host__ __device__ inline size_t max_compressed_size(size_t n)
 {
-  const size_t fixed = n + n / 8 + 16;
+  const size_t fixed = n + n / 8 + 16 + 320;
   return fixed > stored_size(n) ? fixed : stored_size(n);
 }
 

@@ -510,9 +510,9 @@ DecompressionConfig BatchedManager::configure_decompression(const uint8_t* comp_
       || (uint64_t)h.num_chunks != (h.uncompressed_size + h.chunk_size - 1) / h.chunk_size) {
     throw std::runtime_error("nvcomp: inconsistent container header (chunk size / chunk count / uncompressed size)");
   }
-  if (memcmp(h.opts, impl_->opts, sizeof(h.opts)) != 0) {
-    throw std::runtime_error("nvcomp: compressed buffer was written with different format options");
-  }
+  /* The writer's format OPTIONS (h.opts) need not match this manager's: every decoder of the library is driven by the
+   * stream alone -- LZ4 / Snappy / Deflate / ANS have no decode-side options, the Bitcomp and Cascaded chunk headers name
+   * their own type and scheme -- so a manager decompresses any buffer of its format. */
   DecompressionConfig d;
   d.decomp_data_size = h.uncompressed_size;
   d.num_chunks = h.num_chunks;
