@@ -30,13 +30,13 @@ constexpr unsigned kEncWaves = NVCOMP_LZM_WAVES_PER_BLOCK; /* the compressors' w
 using lzl::kMaxOutCap;
 
 /* Decode chunk `chunk` of the batch with the calling wave and report its size and status. */
-template <bool CHECKED>
-__device__ __forceinline__ void decode_one(const lzl::Batch& b, size_t chunk, uint8_t* lds)
+template <bool CHECKED, class BatchPtr>
+__device__ __forceinline__ void decode_one(BatchPtr b, size_t chunk, uint8_t* lds)
 {
-  const uint8_t* in = wave::uniform_ptr((const uint8_t*)b.comp_ptrs[chunk]);
-  uint8_t* out = wave::uniform_ptr((uint8_t*)b.out_ptrs[chunk]);
-  const size_t in_len64 = wave::uniform64(b.comp_bytes[chunk]);
-  size_t cap64 = wave::uniform64(b.out_caps[chunk]);
+  const uint8_t* in = wave::uniform_ptr((const uint8_t*)b->comp_ptrs[chunk]);
+  uint8_t* out = wave::uniform_ptr((uint8_t*)b->out_ptrs[chunk]);
+  const size_t in_len64 = wave::uniform64(b->comp_bytes[chunk]);
+  size_t cap64 = wave::uniform64(b->out_caps[chunk]);
   if (cap64 > kMaxOutCap) {
     cap64 = kMaxOutCap;
   }
@@ -48,30 +48,36 @@ __device__ __forceinline__ void decode_one(const lzl::Batch& b, size_t chunk, ui
     produced = snappyw::decode_chunk<CHECKED>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err);
   }
   if (wave::lane_id() == 0) {
-    if (b.actual_bytes != nullptr) {
-      b.actual_bytes[chunk] = err ? 0 : produced;
+    size_t* actual_bytes = b->actual_bytes;
+    if (actual_bytes != nullptr) {
+      actual_bytes[chunk] = err ? 0 : produced;
     }
     if (CHECKED) {
-      b.statuses[chunk] = err ? nvcompErrorCannotDecompress : nvcompSuccess;
+      b->statuses[chunk] = err ? nvcompErrorCannotDecompress : nvcompSuccess;
     }
   }
 }
 
 /* One wave per chunk at a time; with a ticket counter the waves are persistent (common/lz_launch.hip.h). */
 template <bool CHECKED>
-__global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_WAVES_PER_SIMD) snappy_decompress_window_kernel(
-    const lzl::Batch b, uint32_t* ticket)
+__global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_WAVES_PER_SIMD) snappy_decompress_window_kernel(const lzl::Launch launch)
 {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kDecWaves][lzw::kLdsPerWave];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
-  const size_t first_dynamic = (size_t)gridDim.x * kDecWaves;
   size_t chunk = (size_t)blockIdx.x * kDecWaves + w;
-  while (chunk < b.batch_size) {
-    decode_one<CHECKED>(b, chunk, lds[w]);
+  for (;;) {
+    /* the arguments are read where they are used, not held in scalar registers across the decode (wave::kernel_args) */
+    const auto* a = wave::kernel_args(launch);
+    if (chunk >= a->b.batch_size) {
+      break;
+    }
+    decode_one<CHECKED>(&a->b, chunk, lds[w]);
+    a = wave::kernel_args(launch);
+    uint32_t* ticket = a->ticket;
     if (ticket == nullptr) {
       break;
     }
-    chunk = lzl::next_chunk(ticket, first_dynamic);
+    chunk = lzl::next_chunk(ticket, a->first_dynamic);
   }
 }
 
@@ -261,10 +267,11 @@ nvcompStatus_t nvcompBatchedSnappyDecompressAsync(
     }
   }
 #endif
+  const lzl::Launch launch = {b, ticket, (size_t)groups * kDecWaves};
   if (checked) {
-    hipLaunchKernelGGL((snappy_decompress_window_kernel<true>), dim3(groups), dim3(64 * kDecWaves), 0, stream, b, ticket);
+    hipLaunchKernelGGL((snappy_decompress_window_kernel<true>), dim3(groups), dim3(64 * kDecWaves), 0, stream, launch);
   } else {
-    hipLaunchKernelGGL((snappy_decompress_window_kernel<false>), dim3(groups), dim3(64 * kDecWaves), 0, stream, b, ticket);
+    hipLaunchKernelGGL((snappy_decompress_window_kernel<false>), dim3(groups), dim3(64 * kDecWaves), 0, stream, launch);
   }
   return launch_status();
 }

@@ -46,6 +46,15 @@ struct Batch
   int* statuses; /* nvcompStatus_t* */
 };
 
+/* The single parameter of the persistent kernels: the batch, the ticket counter (NULL: one chunk per wave, statically) and
+ * the first chunk index handed out by ticket (= waves of the launch). Read through wave::kernel_args where needed. */
+struct Launch
+{
+  Batch b;
+  uint32_t* ticket;
+  size_t first_dynamic;
+};
+
 /* The wave's next chunk: `first_dynamic` + a ticket (lane 0 draws it, the wave shares it). */
 __device__ __forceinline__ size_t next_chunk(uint32_t* ticket, size_t first_dynamic)
 {

@@ -44,6 +44,9 @@ namespace lzw {
 #ifndef NVCOMP_LZW_INRING
 #define NVCOMP_LZW_INRING 2048
 #endif
+#ifndef NVCOMP_LZW_FLUSH_ALIGN
+#define NVCOMP_LZW_FLUSH_ALIGN 16 /* a batch's flush ends on this address boundary (16 | 32 | 64 | 128); the rest waits in the window */
+#endif
 #ifndef NVCOMP_LZW_WAVES_PER_SIMD
 #define NVCOMP_LZW_WAVES_PER_SIMD 7
 #endif
@@ -53,6 +56,7 @@ constexpr uint32_t kBatchMax = NVCOMP_LZW_BATCHMAX; /* most output bytes one bat
 constexpr uint32_t kKeep = NVCOMP_LZW_KEEP;         /* history kept when the window slides */
 constexpr uint32_t kInRing = NVCOMP_LZW_INRING;     /* bytes of compressed-stream ring per wave */
 constexpr uint32_t kInBlock = 1024;  /* ring refill granule: 64 lanes x 16 bytes */
+constexpr uint32_t kFlushAlign = NVCOMP_LZW_FLUSH_ALIGN;
 constexpr uint32_t kOutLds = kOutWin + 32;
 constexpr uint32_t kInLds = kInRing + 16; /* first 16 bytes mirrored after the end */
 /* Profiling builds only (wrong output by construction): bit mask of execute stages to leave out.
@@ -63,14 +67,15 @@ constexpr uint32_t kInLds = kInRing + 16; /* first 16 bytes mirrored after the e
 #ifndef NVCOMP_LZW_FAR_ALIGNED
 #define NVCOMP_LZW_FAR_ALIGNED 1 /* far-match data enters the window with aligned LDS accesses only */
 #endif
-#ifndef NVCOMP_LZW_PCHASE
-#define NVCOMP_LZW_PCHASE 1 /* 1: jump-table token chase (below); 0: the serial v_readlane walk */
-#endif
 /* A/B build: short literal runs written from the registers the parser read them into (lz::Seq::lit_lo / lit_hi) instead
  * of being read from the stream ring again. Measured on MI355X: the two more live registers per lane cost more in
  * spills at the 72-VGPR budget of 7 waves/SIMD than the saved LDS round trip returns (449 vs 502 GB/s). Off. */
 #ifndef NVCOMP_LZW_LIT_REGS
 #define NVCOMP_LZW_LIT_REGS 0
+#endif
+#ifndef NVCOMP_LZW_LIT_UNIFIED
+#define NVCOMP_LZW_LIT_UNIFIED 0 /* A/B: literal runs of 1..3 bytes as one (misaligned) dword store -- measured -5 % on MI355X
+                                  * (a misaligned LDS store costs a cycle or two per ACTIVE lane: 40 % of the lanes instead of 10 %) */
 #endif
 #ifndef NVCOMP_LZW_CHASE_ENOUGH
 #define NVCOMP_LZW_CHASE_ENOUGH 64 /* tokens in hand from which the chase does not open another window (A/B: 40, 48) */
@@ -78,7 +83,7 @@ constexpr uint32_t kInLds = kInRing + 16; /* first 16 bytes mirrored after the e
 constexpr uint32_t kChaseEnough = NVCOMP_LZW_CHASE_ENOUGH;
 constexpr uint32_t kChaseWin = 256;                 /* stream positions one chase window covers */
 constexpr uint32_t kChaseLevels = 6;                /* jump tables for 1, 2, 4, 8, 16, 32 tokens ahead */
-constexpr uint32_t kChaseLds = NVCOMP_LZW_PCHASE ? kChaseLevels * kChaseWin : 0;
+constexpr uint32_t kChaseLds = kChaseLevels * kChaseWin;
 constexpr uint32_t kLdsPerWave = kOutLds + kInLds + kChaseLds;
 
 constexpr uint32_t kLitShort = 32;   /* lane-parallel literal runs: up to 8 dwords */
@@ -231,11 +236,12 @@ __device__ __forceinline__ uint32_t in_byte_uniform(const InRing& r, uint32_t v)
  * once however many batches it feeds. */
 
 constexpr uint32_t kUnknownDelta = 1u << 28; /* chunk sizes are < 2^28 */
+constexpr uint32_t kNxUnknown = 0xffffu;     /* the same in the 16-bit form the chase keeps (real deltas are < 2^15) */
 
 struct Chase
 {
   uint32_t wb;    /* virtual position of window slot 0 */
-  uint32_t nx[4]; /* nx[k] lane l: delta of position wb + 4 l + k */
+  uint32_t nx01, nx23; /* lane l: the deltas of positions wb + 4 l + {0, 1} and {2, 3}, 16 bits each (kNxUnknown = unknown) */
   uint32_t q;     /* virtual position of the next token */
   uint8_t* tab;   /* LDS, kChaseLds bytes */
 };
@@ -243,6 +249,8 @@ struct Chase
 __device__ __forceinline__ void chase_init(Chase& c, uint32_t q, uint8_t* lds)
 {
   c.q = q;
+  c.nx01 = 0;
+  c.nx23 = 0;
   c.wb = q - kChaseWin; /* forces a build */
   c.tab = lds;
 }
@@ -261,6 +269,7 @@ __device__ __forceinline__ void chase_build(Chase& c, const InRing& r, Delta del
   const uint32_t reach = c.wb + kChaseWin + Delta::kReach;
   const bool interior = c.wb >= r.lo && reach <= r.hi && reach <= r.vend;
   const uint32_t base = c.wb + 4 * lane;
+  uint32_t nx[4];
   if (interior) {
     /* 8 stream bytes from `base` on, from three aligned dwords (a misaligned ds_read_b32 costs 16x) */
     const uint32_t a0 = base & ~3u;
@@ -272,19 +281,23 @@ __device__ __forceinline__ void chase_build(Chase& c, const InRing& r, Delta del
     const uint64_t w = ((uint64_t)w1 << 32) | w0;
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {
-      c.nx[k] = delta.fast(r, base + k, w >> (8 * k));
+      nx[k] = delta.fast(r, base + k, w >> (8 * k));
     }
   } else {
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {
-      c.nx[k] = delta(r, base + k);
+      nx[k] = delta(r, base + k);
     }
   }
   uint32_t a[4];
 #pragma unroll
   for (uint32_t k = 0; k < 4; ++k) {
-    a[k] = 4 * lane + k + c.nx[k] < limit ? c.nx[k] : 255u; /* the successor must be a token inside the window */
+    a[k] = 4 * lane + k + nx[k] < limit ? nx[k] : 255u; /* the successor must be a token inside the window */
+    nx[k] = nx[k] >= kNxUnknown ? kNxUnknown : nx[k];
   }
+  /* kept for the token through which the chain leaves the window (chase_tokens): two registers, not four */
+  c.nx01 = nx[0] | (nx[1] << 16);
+  c.nx23 = nx[2] | (nx[3] << 16);
   /* the four distances of a lane travel as two dwords of two 16-bit lanes (positions 0|1 and 2|3): a doubling round
    * is two packed adds + two packed saturations instead of four of each, and one byte permute packs the table word */
   uint32_t a01 = a[0] | (a[1] << 16), a23 = a[2] | (a[3] << 16);
@@ -342,10 +355,9 @@ __device__ __forceinline__ uint32_t chase_tokens(
     } else {
       /* the window's chain is used up: leave through the last token's own delta */
       const uint32_t last = wave::read_lane(pos, count - 1);
-      const uint32_t sel = last & 3u;
-      const uint32_t v = sel == 0 ? c.nx[0] : sel == 1 ? c.nx[1] : sel == 2 ? c.nx[2] : c.nx[3];
-      const uint32_t d = wave::read_lane(v, last >> 2);
-      c.q = d >= kUnknownDelta ? slow(r, c.wb + last) : c.wb + last + d;
+      const uint32_t pair = wave::read_lane((last & 2u) ? c.nx23 : c.nx01, last >> 2);
+      const uint32_t d = (last & 1u) ? pair >> 16 : pair & 0xffffu;
+      c.q = d == kNxUnknown ? slow(r, c.wb + last) : c.wb + last + d;
     }
     LZW_T(2);
   }
@@ -359,6 +371,7 @@ struct OutWindow
   uint8_t* win;      /* LDS, kOutLds bytes, 16-byte aligned */
   uint8_t* out;      /* chunk output pointer in HBM (uniform) */
   uint32_t align;    /* out & 15: window index = position - wbase + align */
+  uint32_t falign;   /* out & (kFlushAlign - 1): position + falign is address-congruent modulo kFlushAlign */
   uint32_t wbase;    /* output position of window index `align` (multiple of 16) */
   uint32_t valid_lo; /* positions >= valid_lo (and < op) are present in the window */
   uint32_t flushed;  /* positions < flushed are in HBM; valid_lo <= flushed <= op, op - flushed < 16 between batches */
@@ -369,6 +382,7 @@ __device__ __forceinline__ void out_init(OutWindow& w, uint8_t* out, uint8_t* ld
   w.win = lds;
   w.out = out;
   w.align = (uint32_t)((uintptr_t)out & 15u);
+  w.falign = (uint32_t)((uintptr_t)out & (kFlushAlign - 1));
   w.wbase = 0;
   w.valid_lo = 0;
   w.flushed = 0;
@@ -386,6 +400,9 @@ __device__ __forceinline__ void out_make_room(OutWindow& w, uint32_t op)
     return;
   }
   uint32_t keep_from = op > kKeep ? op - kKeep : 0;
+  if (keep_from > w.flushed) {
+    keep_from = w.flushed; /* the tail that waits for its 16-byte block to fill up always stays (kKeep < 16: no history at all) */
+  }
   if (keep_from < w.valid_lo) {
     keep_from = w.valid_lo;
   }
@@ -446,10 +463,11 @@ __device__ __forceinline__ void out_flush_range(const OutWindow& w, uint32_t fro
  * a 16-byte boundary of the output address, so a batch issues aligned 16-byte stores only. */
 __device__ __forceinline__ void out_flush(OutWindow& w, uint32_t op_end)
 {
-  const uint32_t a_to = (op_end + w.align) & ~15u; /* address-congruent coordinate of the last whole block's end */
-  if (a_to > w.flushed + w.align) {
-    if (!(NVCOMP_LZW_ABLATE_EXEC & 1)) out_flush_range(w, w.flushed, a_to - w.align);
-    w.flushed = a_to - w.align;
+  /* address-congruent coordinate of the end of the last whole block (of kFlushAlign bytes: a multiple of 16) */
+  const uint32_t f_to = (op_end + w.falign) & ~(kFlushAlign - 1);
+  if (f_to > w.flushed + w.falign) {
+    if (!(NVCOMP_LZW_ABLATE_EXEC & 1)) out_flush_range(w, w.flushed, f_to - w.falign);
+    w.flushed = f_to - w.falign;
   }
 }
 
@@ -840,13 +858,22 @@ __device__ __forceinline__ uint32_t execute_window_batch(
       }
     }
     const bool resident = in_resident(ir, s.lit_src, s.lit_src + my_lit);
+#if NVCOMP_LZW_LIT_UNIFIED
+    /* A run of 1..3 bytes goes out as ONE dword like the longer ones: the excess bytes land on the lane's own match
+     * area, which every match path below writes in full afterwards (LZ4: 60 % of the sequences of the mix have no
+     * literals, 30 % have 1..3 -- the byte-wise path below now only sees runs with nothing behind them to absorb the
+     * excess: the last sequence of a chunk, Snappy literal elements without a copy, DEFLATE records). */
+    const bool lit_lane = my_lit != 0 && my_lit <= kLitShort && resident && !lit_held && (my_lit >= 4 || my_lit + my_match >= 4);
+    const bool lit_tiny = my_lit != 0 && my_lit < 4 && resident && !lit_held && !lit_lane;
+#else
     const bool lit_lane = my_lit >= 4 && my_lit <= kLitShort && resident && !lit_held;
     const bool lit_tiny = my_lit != 0 && my_lit < 4 && resident && !lit_held;
+#endif
     /* the ring wraps at kInRing; its 16-byte mirror covers a dword that starts before the end,
      * and a run crossing the end is split by the modulo per step */
     const uint32_t lit_steps = steps_for(lit_lane, my_lit);
     if (lit_lane) {
-      const uint32_t last = my_lit - 4;
+      const uint32_t last = my_lit > 4 ? my_lit - 4 : 0u;
       uint32_t data[8];
 #pragma unroll
       for (uint32_t i = 0; i < 8; ++i) {

@@ -111,6 +111,22 @@ __device__ __forceinline__ T* uniform_ptr(T* p)
   return (T*)(WAVE_GLOBAL T*)uniform64((uint64_t)p);
 }
 
+/* The kernel's argument block, read where it is USED. A kernel whose single parameter is the struct T gets it in the
+ * kernarg segment; the compiler normally loads every field once and keeps all of them in SGPRs for the kernel's lifetime --
+ * in a persistent kernel that is a dozen scalar registers held across the whole decode loop for values needed once per
+ * chunk (the LZ4 window kernel went from 7 to 34 spilled SGPRs and from 6 to 15 spilled VGPRs that way). The pointer
+ * returned here is opaque to the optimiser at every call, so a field read through it is an s_load at that point.
+ * `first_param` must be the kernel's only parameter. */
+#define WAVE_CONSTANT __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const WAVE_CONSTANT T* kernel_args(const T& first_param)
+{
+  (void)first_param;
+  uint64_t p = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return (const WAVE_CONSTANT T*)p;
+}
+
 /* `vec` with lane `lane` (wave-uniform) replaced by the uniform value `val`. */
 __device__ __forceinline__ uint32_t write_lane(uint32_t vec, uint32_t val, uint32_t lane)
 {

@@ -20,14 +20,6 @@ namespace lz4w {
  * pass (chunk sizes are < 2^28, so position + kUnknown never looks like a position). */
 constexpr uint32_t kUnknown = 1u << 28;
 
-#if !NVCOMP_LZW_PCHASE
-struct Chase
-{
-  uint32_t wb;    /* virtual position of lane 0 of nx[0] */
-  uint32_t nx[4]; /* nx[j] lane l: distance from a token at wb+64j+l to the next token; kUnknown = slow path */
-  uint32_t q;     /* virtual position of the next token */
-};
-#endif
 
 /* Distance from a (speculative) token at virtual position p to the next token.
  * Branch-free: the token and the byte behind it are fetched together, the one byte a
@@ -53,18 +45,6 @@ __device__ __forceinline__ uint32_t token_delta(const lzw::InRing& r, uint32_t p
   return unknown ? kUnknown : delta;
 }
 
-#if !NVCOMP_LZW_PCHASE
-__device__ __forceinline__ void chase_reload(Chase& c, const lzw::InRing& r)
-{
-  c.wb = c.q;
-  LZ_STAT("chase_reloads", 1);
-  const uint32_t lane = (uint32_t)wave::lane_id();
-#pragma unroll
-  for (uint32_t j = 0; j < 4; ++j) {
-    c.nx[j] = token_delta(r, c.wb + 64 * j + lane);
-  }
-}
-#endif
 
 /* Scalar walk over one token with multi-byte length extensions. */
 __device__ __forceinline__ uint32_t chase_slow_next(const lzw::InRing& r, uint32_t q)
@@ -105,56 +85,7 @@ __device__ __forceinline__ uint32_t chase_slow_next(const lzw::InRing& r, uint32
   return pos;
 }
 
-#if !NVCOMP_LZW_PCHASE
-/* Append token positions to seqpos lanes [k, 64). Returns the new count.
- * The inner loop is the serial critical path of the decoder: one s_sub, one
- * v_readlane, the lane write and two scalar adds per token. Unknown deltas are
- * stored as kUnknown so that the loop needs no extra test: the position jumps
- * out of every window and the token is re-examined by the scalar slow path. */
-__device__ __forceinline__ uint32_t chase(Chase& c, const lzw::InRing& r, uint32_t& seqpos, uint32_t k)
-{
-  while (k < 64 && c.q < r.vend) {
-    if (c.q - c.wb >= 256) {
-      chase_reload(c, r);
-    }
-#pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) {
-      const uint32_t base = c.wb + 64 * j;
-      uint32_t lim = r.vend - base; /* relative to this sub-window */
-      lim = lim < 64 ? lim : 64;
-      if (c.q >= base && c.q - base < lim) {
-        uint32_t rel = c.q - base;
-        const uint32_t k0 = k;
-        uint32_t recorded = 0;
-        if (k <= 64 - 22) { /* a 64-byte sub-window holds at most 22 tokens */
-          wave::chain_walk(c.nx[j], lim, rel, k, recorded);
-        } else {
-          while (rel < lim && k < 64) {
-            const uint32_t d = wave::read_lane(c.nx[j], rel);
-            recorded = wave::write_lane(recorded, rel, k);
-            ++k;
-            rel += d;
-          }
-        }
-        /* the walk recorded positions relative to the sub-window */
-        const uint32_t lane = (uint32_t)wave::lane_id();
-        if (lane >= k0 && lane < k) {
-          seqpos = base + recorded;
-        }
-        c.q = base + rel;
-      }
-    }
-    if (c.q >= kUnknown) { /* the last recorded token needs the scalar walk */
-      const uint32_t tok = c.q - kUnknown;
-      LZ_STAT("chase_slow", 1);
-      c.q = chase_slow_next(r, tok);
-    }
-  }
-  return k;
-}
-#endif /* !NVCOMP_LZW_PCHASE */
 
-#if NVCOMP_LZW_PCHASE
 struct DeltaFn
 {
   /* a delta looks at most this far past its position: token, 2 length bytes, 15 + 254 literals, offset, length byte */
@@ -181,7 +112,6 @@ struct SlowFn
 {
   __device__ __forceinline__ uint32_t operator()(const lzw::InRing& r, uint32_t p) const { return chase_slow_next(r, p); }
 };
-#endif
 
 /* Lane-parallel field decode of the sequence whose token is at virtual position p. */
 __device__ __forceinline__ void parse(const lzw::InRing& r, uint32_t p, bool active, lz::Seq& s, bool& bad)
@@ -325,14 +255,8 @@ __device__ __forceinline__ uint32_t decode_chunk(
   lzw::OutWindow ow;
   lzw::in_init(ir, in, in_len, lds + lzw::kOutLds);
   lzw::out_init(ow, out, lds);
-#if NVCOMP_LZW_PCHASE
   lzw::Chase c;
   lzw::chase_init(c, ir.vbeg, lds + lzw::kOutLds + lzw::kInLds);
-#else
-  Chase c;
-  c.q = ir.vbeg;
-  c.wb = c.q - 256; /* forces a reload */
-#endif
   uint32_t op = 0;
   uint32_t seqpos = 0;
   uint32_t count = 0; /* sequences recorded in seqpos lanes [0, count) and not yet executed */
@@ -363,11 +287,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
       LZW_T(10);
       lzw::in_ensure(ir, oldest, (c.q & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
       LZW_T(0);
-#if NVCOMP_LZW_PCHASE
       count = lzw::chase_tokens(c, ir, seqpos, count, DeltaFn(), SlowFn());
-#else
-      count = chase(c, ir, seqpos, count);
-#endif
       if (ABLATE == 1) {
         op += wave::reduce_add(lane < count ? seqpos : 0u) & 1u;
         count = 0;
@@ -465,14 +385,8 @@ __device__ __forceinline__ void produce(const uint8_t* __restrict__ in, uint32_t
   const Shared sh = shared_at(lds);
   lzw::InRing ir;
   lzw::in_init(ir, in, in_len, lds + lzw::kOutLds + lzw::kInLds);
-#if NVCOMP_LZW_PCHASE
   lzw::Chase c;
   lzw::chase_init(c, ir.vbeg, lds + lzw::kOutLds + 2 * lzw::kInLds);
-#else
-  Chase c;
-  c.q = ir.vbeg;
-  c.wb = c.q - 256;
-#endif
   uint32_t k = 0;
   for (;;) {
     const bool last = c.q >= ir.vend;
@@ -483,11 +397,7 @@ __device__ __forceinline__ void produce(const uint8_t* __restrict__ in, uint32_t
     if (!last) {
       lzw::in_ensure(ir, c.q, (c.q & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
       uint32_t seqpos = 0;
-#if NVCOMP_LZW_PCHASE
       count = lzw::chase_tokens(c, ir, seqpos, 0, DeltaFn(), SlowFn());
-#else
-      count = chase(c, ir, seqpos, 0);
-#endif
       if (!parse_fast(ir, seqpos, lane < count, s, bad)) {
         parse(ir, seqpos, lane < count, s, bad);
       }

@@ -39,14 +39,6 @@ __device__ __forceinline__ uint32_t copy_size(uint32_t kind) /* kind 1..3 */
   return kind == 3 ? 5u : kind + 1;
 }
 
-#if !NVCOMP_LZW_PCHASE
-struct Chase
-{
-  uint32_t wb;
-  uint32_t nx[4];
-  uint32_t q;
-};
-#endif
 
 /* Distance from a (speculative) tag at virtual position p to the next tag; kUnknown = unknown.
  * Branch-free: the tag and the four bytes behind it (a literal's length field) are fetched
@@ -82,17 +74,6 @@ __device__ __forceinline__ uint32_t tag_delta(const lzw::InRing& r, uint32_t p)
   return unknown ? kUnknown : delta;
 }
 
-#if !NVCOMP_LZW_PCHASE
-__device__ __forceinline__ void chase_reload(Chase& c, const lzw::InRing& r)
-{
-  c.wb = c.q;
-  const uint32_t lane = (uint32_t)wave::lane_id();
-#pragma unroll
-  for (uint32_t j = 0; j < 4; ++j) {
-    c.nx[j] = tag_delta(r, c.wb + 64 * j + lane);
-  }
-}
-#endif
 
 /* Scalar fallback (tag not resolvable from the ring). */
 __device__ __forceinline__ uint32_t chase_slow_next(const lzw::InRing& r, uint32_t q)
@@ -127,56 +108,7 @@ __device__ __forceinline__ uint32_t chase_slow_next(const lzw::InRing& r, uint32
   return p2;
 }
 
-#if !NVCOMP_LZW_PCHASE
-/* Append token positions to seqpos lanes [k, 64). Returns the new count.
- * The inner loop is the serial critical path of the decoder: one s_sub, one
- * v_readlane, the lane write and two scalar adds per token. Unknown deltas are
- * stored as kUnknown so that the loop needs no extra test: the position jumps
- * out of every window and the token is re-examined by the scalar slow path. */
-__device__ __forceinline__ uint32_t chase(Chase& c, const lzw::InRing& r, uint32_t& seqpos, uint32_t k)
-{
-  while (k < 64 && c.q < r.vend) {
-    if (c.q - c.wb >= 256) {
-      chase_reload(c, r);
-    }
-#pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) {
-      const uint32_t base = c.wb + 64 * j;
-      uint32_t lim = r.vend - base; /* relative to this sub-window */
-      lim = lim < 64 ? lim : 64;
-      if (c.q >= base && c.q - base < lim) {
-        uint32_t rel = c.q - base;
-        const uint32_t k0 = k;
-        uint32_t recorded = 0;
-        if (k <= 64 - 32) { /* a 64-byte sub-window holds at most 32 tokens */
-          wave::chain_walk(c.nx[j], lim, rel, k, recorded);
-        } else {
-          while (rel < lim && k < 64) {
-            const uint32_t d = wave::read_lane(c.nx[j], rel);
-            recorded = wave::write_lane(recorded, rel, k);
-            ++k;
-            rel += d;
-          }
-        }
-        /* the walk recorded positions relative to the sub-window */
-        const uint32_t lane = (uint32_t)wave::lane_id();
-        if (lane >= k0 && lane < k) {
-          seqpos = base + recorded;
-        }
-        c.q = base + rel;
-      }
-    }
-    if (c.q >= kUnknown) { /* the last recorded token needs the scalar walk */
-      const uint32_t tok = c.q - kUnknown;
-      LZ_STAT("chase_slow", 1);
-      c.q = chase_slow_next(r, tok);
-    }
-  }
-  return k;
-}
-#endif /* !NVCOMP_LZW_PCHASE */
 
-#if NVCOMP_LZW_PCHASE
 struct DeltaFn
 {
   static constexpr uint32_t kReach = 8 + kFuseMax + 8; /* tag + length field, and the tag behind a fusable literal */
@@ -202,7 +134,6 @@ struct SlowFn
 {
   __device__ __forceinline__ uint32_t operator()(const lzw::InRing& r, uint32_t p) const { return chase_slow_next(r, p); }
 };
-#endif
 
 __device__ __forceinline__ void parse(const lzw::InRing& r, uint32_t p, bool active, lz::Seq& s, bool& bad)
 {
@@ -394,14 +325,8 @@ __device__ __forceinline__ uint32_t decode_chunk(
     return 0;
   }
   const uint32_t limit = CHECKED ? total : out_cap;
-#if NVCOMP_LZW_PCHASE
   lzw::Chase c;
   lzw::chase_init(c, q, lds + lzw::kOutLds + lzw::kInLds);
-#else
-  Chase c;
-  c.q = q;
-  c.wb = c.q - 256;
-#endif
   uint32_t op = 0;
   uint32_t seqpos = 0;
   uint32_t count = 0;
@@ -421,11 +346,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
       const uint32_t oldest = count ? wave::read_lane(seqpos, 0) : c.q;
       lzw::in_ensure(ir, oldest, (c.q & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
       const uint32_t before = count;
-#if NVCOMP_LZW_PCHASE
       count = lzw::chase_tokens(c, ir, seqpos, count, DeltaFn(), SlowFn());
-#else
-      count = chase(c, ir, seqpos, count);
-#endif
       lz::Seq fresh;
       bool bad;
       if (!parse_fast(ir, seqpos, lane >= before && lane < count, fresh, bad)) {
@@ -501,14 +422,8 @@ __device__ __forceinline__ void produce(const uint8_t* __restrict__ in, uint32_t
   lzw::in_ensure(ir, ir.vbeg, ir.vbeg + lzw::kInBlock);
   uint32_t q, total;
   const bool preamble_ok = read_preamble(ir, q, total);
-#if NVCOMP_LZW_PCHASE
   lzw::Chase c;
   lzw::chase_init(c, q, lds + lzw::kOutLds + 2 * lzw::kInLds);
-#else
-  Chase c;
-  c.q = q;
-  c.wb = c.q - 256;
-#endif
   uint32_t k = 0;
   for (;;) {
     const bool last = !preamble_ok || c.q >= ir.vend;
@@ -519,11 +434,7 @@ __device__ __forceinline__ void produce(const uint8_t* __restrict__ in, uint32_t
     if (!last) {
       lzw::in_ensure(ir, c.q, (c.q & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
       uint32_t seqpos = 0;
-#if NVCOMP_LZW_PCHASE
       count = lzw::chase_tokens(c, ir, seqpos, 0, DeltaFn(), SlowFn());
-#else
-      count = chase(c, ir, seqpos, 0);
-#endif
       if (!parse_fast(ir, seqpos, lane < count, s, bad)) {
         parse(ir, seqpos, lane < count, s, bad);
       }

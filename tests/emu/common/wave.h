@@ -82,6 +82,12 @@ inline T* uniform_ptr(T* p)
   return (T*)uniform64((uint64_t)p);
 }
 
+template <typename T>
+inline const T* kernel_args(const T& first_param)
+{
+  return &first_param;
+}
+
 inline uint32_t write_lane(uint32_t vec, uint32_t val, uint32_t lane)
 {
   return ((uint32_t)lane_id() == lane) ? val : vec;
