@@ -27,19 +27,20 @@
 namespace lzw {
 
 /* Tunables (overridable with -D for the A/B builds of scripts/build_variants.sh). */
-/* Defaults from the MI355X sweeps of profiles/r01_window_variants.json, r01_pchase_variants.json and
- * r01_occupancy_variants.json: a small window at 6-7 waves/SIMD beats a large one -- the decoder is
- * instruction-issue bound, not LDS- or HBM-bound. The LDS slice (5.5 KiB/wave) allows 7 waves/SIMD; asking the
- * compiler for 8 makes it give up on the register budget (74 VGPRs = 6 waves), asking for 7 yields 72 VGPRs
- * and 3 spilled dwords: +2 %. */
-#ifndef NVCOMP_LZW_OUTWIN
-#define NVCOMP_LZW_OUTWIN 2048
-#endif
+/* The output window holds ONE BATCH: the bytes a batch produces (at most kBatchMax) plus the tail of the previous one
+ * that still waits for its 16-byte block to fill up -- no history. Measured on MI355X (profiles/r03_ab_*.jsonl): 84 % of
+ * the matches of the headline workload reach further back than any window that fits the LDS budget (61 % further than
+ * 4 KiB), so history only turned a twentieth of the far matches into near ones, and paid for it with 1 KiB of LDS per
+ * wave and a slide of 768 bytes every other batch: without it +1.6 % (LZ4 mix), +2.4 % (Snappy), +7 % (text, 1 GiB
+ * batches). Rounds 1-2 kept 768 bytes of a 2 KiB window (profiles/r01_window_variants.json). */
 #ifndef NVCOMP_LZW_BATCHMAX
-#define NVCOMP_LZW_BATCHMAX (NVCOMP_LZW_OUTWIN / 2)
+#define NVCOMP_LZW_BATCHMAX 1024
+#endif
+#ifndef NVCOMP_LZW_OUTWIN
+#define NVCOMP_LZW_OUTWIN (NVCOMP_LZW_BATCHMAX + 64)
 #endif
 #ifndef NVCOMP_LZW_KEEP
-#define NVCOMP_LZW_KEEP (NVCOMP_LZW_OUTWIN * 3 / 8)
+#define NVCOMP_LZW_KEEP 0
 #endif
 #ifndef NVCOMP_LZW_INRING
 #define NVCOMP_LZW_INRING 2048
@@ -63,19 +64,6 @@ constexpr uint32_t kInLds = kInRing + 16; /* first 16 bytes mirrored after the e
  * 1 = HBM flush stores, 2 = far-match HBM loads, 4 = literal copies, 8 = in-window match rounds, 16 = far data into LDS */
 #ifndef NVCOMP_LZW_ABLATE_EXEC
 #define NVCOMP_LZW_ABLATE_EXEC 0
-#endif
-#ifndef NVCOMP_LZW_FAR_ALIGNED
-#define NVCOMP_LZW_FAR_ALIGNED 1 /* far-match data enters the window with aligned LDS accesses only */
-#endif
-/* A/B build: short literal runs written from the registers the parser read them into (lz::Seq::lit_lo / lit_hi) instead
- * of being read from the stream ring again. Measured on MI355X: the two more live registers per lane cost more in
- * spills at the 72-VGPR budget of 7 waves/SIMD than the saved LDS round trip returns (449 vs 502 GB/s). Off. */
-#ifndef NVCOMP_LZW_LIT_REGS
-#define NVCOMP_LZW_LIT_REGS 0
-#endif
-#ifndef NVCOMP_LZW_LIT_UNIFIED
-#define NVCOMP_LZW_LIT_UNIFIED 0 /* A/B: literal runs of 1..3 bytes as one (misaligned) dword store -- measured -5 % on MI355X
-                                  * (a misaligned LDS store costs a cycle or two per ACTIVE lane: 40 % of the lanes instead of 10 %) */
 #endif
 #ifndef NVCOMP_LZW_CHASE_ENOUGH
 #define NVCOMP_LZW_CHASE_ENOUGH 64 /* tokens in hand from which the chase does not open another window (A/B: 40, 48) */
@@ -331,34 +319,37 @@ __device__ __forceinline__ uint32_t chase_tokens(
       chase_build(c, r, delta);
       LZW_T(1);
     }
-    /* lane n: the n-th token from c.q, if it lies in this window (branch-free: every lane reads every level) */
+    /* Lane k + n: the n-th token from c.q, if it lies in this window. Pure lane arithmetic, no predicate logic (the
+     * scalar unit is as busy as the vector unit in this kernel: every && of two lane conditions is a scalar
+     * instruction): a lane follows the levels named by the bits of n; a level it does not take adds 0; 255 (the
+     * successor leaves the window) poisons the lane through `worst`; the position wraps inside the table. */
+    const uint32_t idx = (lane - k) & 63u;
     uint32_t pos = c.q - c.wb;
-    bool valid = true;
+    uint32_t worst = 0;
 #pragma unroll
     for (uint32_t i = 0; i < kChaseLevels; ++i) {
       const uint32_t a = c.tab[i * kChaseWin + pos];
-      const bool step = valid && ((lane >> i) & 1u) != 0;
-      const bool out = step && a == 255u;
-      valid = valid && !out;
-      pos += step && !out ? a : 0u;
+      const uint32_t adv = a & (uint32_t)(-(int32_t)((idx >> i) & 1u));
+      worst = adv > worst ? adv : worst;
+      pos = (pos + adv) & (kChaseWin - 1);
     }
-    const uint32_t count = wave::popc64(wave::ballot(valid)); /* a prefix of the lanes; lane 0 always */
+    /* every n appears in exactly one lane, and the valid n are a prefix: their number is the ballot's population */
+    const uint32_t count = wave::popc64(wave::ballot(worst != 255u));
     const uint32_t room = 64 - k;
     const uint32_t take = count < room ? count : room;
-    const uint32_t shifted = k ? wave::shuffle(pos, (lane - k) & 63u) : pos;
-    if (lane >= k && lane < k + take) {
-      seqpos = c.wb + shifted;
+    if (idx < take) {
+      seqpos = c.wb + pos;
     }
-    k += take;
     if (take < count) {
-      c.q = c.wb + wave::read_lane(pos, take);
+      c.q = c.wb + wave::read_lane(pos, (k + take) & 63u);
     } else {
       /* the window's chain is used up: leave through the last token's own delta */
-      const uint32_t last = wave::read_lane(pos, count - 1);
+      const uint32_t last = wave::read_lane(pos, (k + count - 1) & 63u);
       const uint32_t pair = wave::read_lane((last & 2u) ? c.nx23 : c.nx01, last >> 2);
       const uint32_t d = (last & 1u) ? pair >> 16 : pair & 0xffffu;
       c.q = d == kNxUnknown ? slow(r, c.wb + last) : c.wb + last + d;
     }
+    k += take;
     LZW_T(2);
   }
   return k;
@@ -486,6 +477,21 @@ __device__ __forceinline__ void out_flush_all(OutWindow& w, uint32_t op_end)
     out_flush_range(w, w.flushed, op_end);
     w.flushed = op_end;
   }
+}
+
+/* The first `take` of `count` sequences in hand are done: the others move down to lane 0, and the lanes behind them
+ * become EMPTY sequences again (execute_window_batch relies on that instead of masking by the count). */
+__device__ __forceinline__ void drop_front(lz::Seq& s, uint32_t take, uint32_t count)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t from = (lane + take) & 63u;
+  const bool keep = lane < count - take;
+  const uint32_t a = wave::shuffle(s.lit_src, from), b = wave::shuffle(s.lit_len, from);
+  const uint32_t c = wave::shuffle(s.match_off, from), d = wave::shuffle(s.match_len, from);
+  s.lit_src = keep ? a : 0u;
+  s.lit_len = keep ? b : 0u;
+  s.match_off = keep ? c : 0u;
+  s.match_len = keep ? d : 0u;
 }
 
 /* ---- two waves per chunk: what the producer and the consumer share (lz4_decode_window.hip.h: pair) ---- */
@@ -741,27 +747,32 @@ __device__ __forceinline__ void copy_to_lds(uint8_t* dst, const uint8_t* src, ui
 
 /*
  * Execute the first sequences of a parsed batch inside the window. Lane k owns
- * sequence k (k < n); lit positions are virtual positions in the input ring's
+ * sequence k (k < n, n >= 1); lanes >= n hold EMPTY sequences (lit_len = match_len = 0:
+ * the callers keep it so), lit positions are virtual positions in the input ring's
  * coordinate system. Consumes as many leading sequences as fit kBatchMax output
  * bytes (at least one unless the first one alone is larger: then `big` is set
  * and nothing is consumed). Returns the number of sequences consumed and adds
  * the bytes produced to op.
+ *
+ * Written for the scalar unit as much as for the vector unit (they are equally busy in this kernel): every
+ * && / || of two lane conditions is a scalar instruction on 64-bit masks, so ranges are tested with one unsigned
+ * compare ((x - lo) <= hi - lo), conditions that grow with the lane are tested once for the wave, and nothing is
+ * masked that the callers' invariant already zeroes.
  */
 template <bool CHECKED, bool RING_LITERALS = false>
 __device__ __forceinline__ uint32_t execute_window_batch(
     InRing& ir, OutWindow& ow, uint32_t out_cap, uint32_t& op, uint32_t n, const lz::Seq& s, uint32_t& err, bool& big)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
-  const bool active = lane < n;
-  const uint32_t lit_len = active ? s.lit_len : 0;
-  const uint32_t match_len = active ? s.match_len : 0;
-  const uint32_t len = lit_len + match_len;
+  const uint32_t len = s.lit_len + s.match_len;
   const uint32_t incl = wave::scan_add_inclusive(len);
   big = false;
 
-  /* leading sequences whose cumulative output fits one batch */
-  const uint64_t over = wave::ballot(active && incl > kBatchMax) | (n < 64 ? (~0ull << n) : 0ull);
-  const uint32_t take = over ? wave::ctz64(over) : 64u;
+  /* leading sequences whose cumulative output fits one batch (a length is < 2^31: the first sum above kBatchMax has
+   * not wrapped, whatever the sums behind it do) */
+  const uint64_t over = wave::ballot(incl > kBatchMax);
+  uint32_t take = over ? wave::ctz64(over) : 64u;
+  take = take < n ? take : n;
   if (take == 0) {
     big = true;
     return 0;
@@ -769,17 +780,17 @@ __device__ __forceinline__ uint32_t execute_window_batch(
   const bool mine = lane < take;
   const uint32_t total = wave::read_lane(incl, take - 1);
   const uint32_t lit_dst = op + incl - len;
-  const uint32_t match_dst = lit_dst + lit_len;
-  const uint32_t my_lit = mine ? lit_len : 0;
-  const uint32_t my_match = mine ? match_len : 0;
+  const uint32_t match_dst = lit_dst + s.lit_len;
+  const uint32_t my_lit = mine ? s.lit_len : 0;
+  const uint32_t my_match = mine ? s.match_len : 0;
 
   if (CHECKED) {
-    const bool bad_out = mine && ((uint64_t)op + incl > out_cap);
-    const bool bad_off = my_match != 0 && (s.match_off == 0 || s.match_off > match_dst);
-    const uint64_t any_out = wave::ballot(bad_out);
-    const uint64_t any_off = wave::ballot(bad_off);
-    if (any_out | any_off) {
-      err |= (any_out ? lz::kErrOutput : 0u) | (any_off ? lz::kErrOffset : 0u);
+    /* the sums grow with the lane: the batch's end is the only output test (op <= out_cap <= 2^26, total <= kBatchMax);
+     * offset 0 wraps to the largest value, so one compare covers "0 or beyond the produced output" */
+    const bool bad_out = op + total > out_cap;
+    const uint64_t any_off = wave::ballot(my_match != 0 && s.match_off - 1 >= match_dst);
+    if (bad_out || any_off) {
+      err |= (bad_out ? lz::kErrOutput : 0u) | (any_off ? lz::kErrOffset : 0u);
       return 0;
     }
   }
@@ -791,17 +802,14 @@ __device__ __forceinline__ uint32_t execute_window_batch(
   out_make_room(ow, op);
   LZW_T(5);
 
-  /* ---- far matches: sources older than the window, read from HBM ---- */
+  /* ---- far matches: sources the window no longer holds, read from HBM ---- */
   const uint32_t match_src = match_dst - s.match_off;
+  const bool short_match = my_match - 4 <= kMatchShort - 4; /* 4 .. kMatchShort */
   const bool is_near = my_match != 0 && match_src >= ow.valid_lo;
-#if NVCOMP_LZW_FAR_ALIGNED
-  /* the data comes with one or two 16-byte loads, which must stay inside the chunk's buffer */
-  const bool far_lane = my_match >= 4 && !is_near && my_match <= kMatchShort && match_src + my_match <= ow.flushed
-                        && (uint64_t)match_src + (my_match > 16 ? 32u : 16u) <= out_cap;
+  /* the data comes with one or two 16-byte loads, which must stay inside the chunk's buffer (a source in the last 32
+   * bytes of the buffer, or a wrapped one of a corrupt unchecked stream, takes the cooperative path below) */
+  const bool far_lane = short_match && match_src + my_match <= ow.flushed && out_cap >= 32 && match_src <= out_cap - 32;
   uint32_t far_l4 = 0;
-#else
-  const bool far_lane = my_match >= 4 && !is_near && my_match <= kMatchShort && match_src + my_match <= ow.flushed;
-#endif
   uint32_t far_data[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const uint32_t far_steps = steps_for(far_lane, my_match);
   if (far_lane && !(NVCOMP_LZW_ABLATE_EXEC & 2)) {
@@ -810,70 +818,31 @@ __device__ __forceinline__ uint32_t execute_window_batch(
 #else
     const uint8_t* src = ow.out + match_src;
 #endif
-#if NVCOMP_LZW_FAR_ALIGNED
     /* A scattered load costs the CU's address unit a slot per lane whatever its width (profiles/r02_decode_phases.json:
      * issuing 3-9 dword loads per batch was 11 % of the wave's time): 16 bytes per load, two loads at most, plus the
      * match's last dword. */
-    {
-      const wave::u32x4 f0 = wave::gload_u32x4(src);
-      far_data[0] = f0.x, far_data[1] = f0.y, far_data[2] = f0.z, far_data[3] = f0.w;
-      if (my_match > 16) {
-        const wave::u32x4 f1 = wave::gload_u32x4(src + 16);
-        far_data[4] = f1.x, far_data[5] = f1.y, far_data[6] = f1.z, far_data[7] = f1.w;
-      }
-      far_l4 = wave::gload_u32(src + my_match - 4);
+    const wave::u32x4 f0 = wave::gload_u32x4(src);
+    far_data[0] = f0.x, far_data[1] = f0.y, far_data[2] = f0.z, far_data[3] = f0.w;
+    if (my_match > 16) {
+      const wave::u32x4 f1 = wave::gload_u32x4(src + 16);
+      far_data[4] = f1.x, far_data[5] = f1.y, far_data[6] = f1.z, far_data[7] = f1.w;
     }
-#else
-    if (far_steps == 2) {
-      load_dwords_clamped<2>(far_data, src, my_match);
-    } else if (far_steps == 4) {
-      load_dwords_clamped<4>(far_data, src, my_match);
-    } else {
-      load_dwords_clamped<8>(far_data, src, my_match);
-    }
-#endif
+    far_l4 = wave::gload_u32(src + my_match - 4);
   }
 
   LZW_T(11); /* far classification + load issue */
   /* ---- literals ---- */
   if (!(NVCOMP_LZW_ABLATE_EXEC & 4)) {
     uint8_t* dst = out_at(ow, lit_dst);
-    /* a run the parser still holds in registers is written from there: no stream read, no dependent LDS round trip */
-    const bool lit_held = NVCOMP_LZW_LIT_REGS && my_lit != 0 && (s.lit_hi >> 16) == my_lit;
-    if (wave::ballot(lit_held)) {
-      if (lit_held) {
-        const uint64_t v = ((uint64_t)(s.lit_hi & 0xffffu) << 32) | s.lit_lo;
-        if (my_lit >= 4) {
-          lz::st_u32(dst, (uint32_t)v);
-          lz::st_u32(dst + my_lit - 4, (uint32_t)(v >> (8 * (my_lit - 4))));
-        } else {
-          dst[0] = (uint8_t)v;
-          if (my_lit > 1) {
-            dst[1] = (uint8_t)(v >> 8);
-          }
-          if (my_lit > 2) {
-            dst[2] = (uint8_t)(v >> 16);
-          }
-        }
-      }
-    }
-    const bool resident = in_resident(ir, s.lit_src, s.lit_src + my_lit);
-#if NVCOMP_LZW_LIT_UNIFIED
-    /* A run of 1..3 bytes goes out as ONE dword like the longer ones: the excess bytes land on the lane's own match
-     * area, which every match path below writes in full afterwards (LZ4: 60 % of the sequences of the mix have no
-     * literals, 30 % have 1..3 -- the byte-wise path below now only sees runs with nothing behind them to absorb the
-     * excess: the last sequence of a chunk, Snappy literal elements without a copy, DEFLATE records). */
-    const bool lit_lane = my_lit != 0 && my_lit <= kLitShort && resident && !lit_held && (my_lit >= 4 || my_lit + my_match >= 4);
-    const bool lit_tiny = my_lit != 0 && my_lit < 4 && resident && !lit_held && !lit_lane;
-#else
-    const bool lit_lane = my_lit >= 4 && my_lit <= kLitShort && resident && !lit_held;
-    const bool lit_tiny = my_lit != 0 && my_lit < 4 && resident && !lit_held;
-#endif
+    /* a run of 1 .. kLitShort bytes that the ring holds is copied by its own lane (a position in front of the resident
+     * range wraps to a huge value: one compare) */
+    const bool lit_own = my_lit - 1 < kLitShort && s.lit_src - ir.lo + my_lit <= ir.hi - ir.lo;
+    const bool lit_lane = lit_own && my_lit >= 4;
     /* the ring wraps at kInRing; its 16-byte mirror covers a dword that starts before the end,
      * and a run crossing the end is split by the modulo per step */
     const uint32_t lit_steps = steps_for(lit_lane, my_lit);
     if (lit_lane) {
-      const uint32_t last = my_lit > 4 ? my_lit - 4 : 0u;
+      const uint32_t last = my_lit - 4;
       uint32_t data[8];
 #pragma unroll
       for (uint32_t i = 0; i < 8; ++i) {
@@ -891,6 +860,10 @@ __device__ __forceinline__ uint32_t execute_window_batch(
       }
     }
     LZW_T(6); /* literal runs of 4..32 bytes */
+    /* 1..3 bytes: byte-wise (as ONE misaligned dword store, whose excess bytes the match behind it would overwrite, they
+     * measured 5 % slower on the headline: a misaligned LDS store costs a cycle or two per ACTIVE lane, and 30 % of the
+     * sequences have such a run, 10 % one of four bytes or more) */
+    const bool lit_tiny = lit_own && my_lit < 4;
     if (wave::ballot(lit_tiny)) {
       if (lit_tiny) {
         dst[0] = ir.ring[s.lit_src & (kInRing - 1)];
@@ -903,8 +876,8 @@ __device__ __forceinline__ uint32_t execute_window_batch(
       }
     }
     LZW_T(12); /* literal runs of 1..3 bytes */
-    uint64_t pending = wave::ballot(my_lit != 0 && !lit_lane && !lit_tiny && !lit_held);
-    LZ_STAT("lit_lanes", wave::popc64(wave::ballot(lit_lane || lit_tiny)));
+    uint64_t pending = wave::ballot(my_lit != 0 && !lit_own);
+    LZ_STAT("lit_lanes", wave::popc64(wave::ballot(lit_own)));
     LZ_STAT("lit_coop", wave::popc64(pending));
     while (pending) {
       const uint32_t j = wave::ctz64(pending);
@@ -927,7 +900,6 @@ __device__ __forceinline__ uint32_t execute_window_batch(
 
   LZW_T(13); /* long literal runs, whole wave */
   /* ---- far match data into the window ---- */
-#if NVCOMP_LZW_FAR_ALIGNED
   if (wave::ballot(far_lane) && !(NVCOMP_LZW_ABLATE_EXEC & 16)) {
     uint8_t* dst = out_at(ow, far_lane ? match_dst : ow.wbase);
     if (far_steps == 2) {
@@ -938,24 +910,12 @@ __device__ __forceinline__ uint32_t execute_window_batch(
       far_store_aligned<8>(dst, far_data, far_l4, my_match, far_lane);
     }
   }
-#else
-  if (far_lane && !(NVCOMP_LZW_ABLATE_EXEC & 16)) {
-    uint8_t* dst = out_at(ow, match_dst);
-    if (far_steps == 2) {
-      store_dwords_clamped<2>(dst, far_data, my_match);
-    } else if (far_steps == 4) {
-      store_dwords_clamped<4>(dst, far_data, my_match);
-    } else {
-      store_dwords_clamped<8>(dst, far_data, my_match);
-    }
-  }
-#endif
   wave::sync();
   LZW_T(7);
 
   /* ---- remaining matches, oldest first: multi-round resolution in LDS ---- */
   {
-    const bool near_lane = is_near && my_match >= 4 && my_match <= kMatchShort && s.match_off >= 4;
+    const bool near_lane = is_near && short_match && s.match_off >= 4;
     uint64_t pending = (NVCOMP_LZW_ABLATE_EXEC & 8) ? 0ull : wave::ballot(my_match != 0 && !far_lane);
     const uint64_t near_mask = wave::ballot(near_lane);
     const uint64_t lane_bit = 1ull << lane;

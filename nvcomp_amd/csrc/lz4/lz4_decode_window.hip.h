@@ -196,46 +196,47 @@ __device__ __forceinline__ uint32_t ring_bytes4(const lzw::InRing& r, uint32_t p
   return wave::align_bytes(d1, d0, p & 3u);
 }
 
-/* parse() for the common batch: every lane's token, first length bytes and offset are resident, no length field is
- * longer than one extension byte. Straight-line, two dependent LDS round trips, no exec-mask changes; returns false
- * (wave-uniform) when some lane needs the general parser, which then redoes the whole batch. Same fields, same
- * validation. */
-__device__ __forceinline__ bool parse_fast(const lzw::InRing& r, uint32_t p, bool active, lz::Seq& s, bool& bad)
+/* parse() for the common batch, lanes [from, to) (to > from). Whether everything a lane may look at is resident and
+ * inside the chunk is decided ONCE for the wave, from the first and the last token position (positions grow with the
+ * lane): a sequence without a second length-extension byte spans at most kFastSpan stream bytes. Under that
+ * precondition no sequence is the chunk's last one and every field is resident, so the lanes run straight-line code with
+ * two predicates in all (a length needing a second extension byte sends the whole batch to the general parser) instead
+ * of the dozen lane conditions -- each of them a scalar instruction per && -- the bounds used to cost
+ * (profiles/r03_ab_*.jsonl). Returns false (wave-uniform) when the general parser must do the batch. */
+constexpr uint32_t kFastSpan = 288; /* token, length byte, 15 + 254 literals, offset, length byte, and the token behind */
+
+__device__ __forceinline__ bool parse_fast(
+    const lzw::InRing& r, uint32_t p, uint32_t from, uint32_t to, lz::Seq& s, bool& bad)
 {
-  const uint32_t vend = r.vend;
-  /* the token + 7 bytes and, behind the literals, offset + one length byte must sit in the ring */
-  const bool head_in = p >= r.lo && p + 12 <= r.hi;
-  const uint64_t w = ring_bytes8(r, active && head_in ? p : r.lo);
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t first = wave::read_lane(p, from);
+  const uint32_t last = wave::read_lane(p, to - 1);
+  const uint32_t lim = r.hi < r.vend ? r.hi : r.vend;
+  if (first < r.lo || last + kFastSpan > lim) {
+    return false;
+  }
+  const bool active = lane - from < to - from;
+  const uint64_t w = ring_bytes8(r, p); /* a lane outside [from, to) reads somewhere inside the ring: harmless */
   const uint32_t t = (uint32_t)w & 0xffu;
   const uint32_t e1 = (uint32_t)(w >> 8) & 0xffu;
   const uint32_t code = t >> 4;
   const bool lit_ext = code == 15;
   const uint32_t lit = code + (lit_ext ? e1 : 0u);
   const uint32_t lit_src = p + 1 + (lit_ext ? 1u : 0u);
-  const uint32_t q = lit_src + lit; /* offset position, or the end of the chunk for the last sequence */
-  const bool last = q == vend;
-  const bool tail_in = q + 12 <= r.hi; /* lit <= 270: q - p is small, p >= lo holds */
-  const uint32_t x = ring_bytes4(r, active && head_in && tail_in && !last ? q : r.lo);
+  const uint32_t q = lit_src + lit; /* the offset */
+  const uint32_t x = ring_bytes4(r, q);
   const uint32_t mcode = t & 15u;
-  const bool m_ext = mcode == 15;
   const uint32_t me = (x >> 16) & 0xffu;
-  const bool general = active && (!head_in || (lit_ext && e1 == 255) || (!last && (!tail_in || (m_ext && me == 255))) || q > vend
-                                  || (!last && vend - q < 2));
-  if (wave::ballot(general)) {
+  /* second extension bytes: literal code 15 followed by 255 = bits 4-15 of w all set; match code 15 followed by 255 */
+  const bool more = ((uint32_t)w & 0xfff0u) == 0xfff0u || ((mcode << 8) | me) == 0xfffu;
+  if (wave::ballot(active && more)) {
     return false;
   }
-  const uint32_t next = q + 2 + (m_ext ? 1u : 0u); /* a token must follow every match */
   s.lit_src = active ? lit_src : 0;
   s.lit_len = active ? lit : 0;
-  s.match_off = active && !last ? (x & 0xffffu) : 0;
-  s.match_len = active && !last ? mcode + 4 + (m_ext ? me : 0u) : 0;
-  /* a run of up to 6 literals sits in the 8 bytes just read (token, then the literals: no length byte below 15) */
-#if NVCOMP_LZW_LIT_REGS
-  const uint32_t held = active && lit <= 6 ? lit : 0u;
-  s.lit_lo = (uint32_t)(w >> 8);
-  s.lit_hi = ((uint32_t)(w >> 40) & 0xffffu) | (held << 16);
-#endif
-  bad = active && !last && next >= vend;
+  s.match_off = active ? (x & 0xffffu) : 0;
+  s.match_len = active ? mcode + 4 + (mcode == 15 ? me : 0u) : 0;
+  bad = false; /* a token follows every match: last + kFastSpan <= vend */
   return true;
 }
 
@@ -297,7 +298,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
     if (refill || !NVCOMP_LZ4W_KEEP_PARSED) {
       lz::Seq fresh;
       bool bad;
-      if (!parse_fast(ir, seqpos, lane >= before && lane < count, fresh, bad)) {
+      if (count <= before || !parse_fast(ir, seqpos, before, count, fresh, bad)) {
         parse(ir, seqpos, lane >= before && lane < count, fresh, bad);
       }
       LZW_T(3);
@@ -348,14 +349,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
       const uint32_t from = (lane + take) & 63u;
       seqpos = wave::shuffle(seqpos, from);
 #if NVCOMP_LZ4W_KEEP_PARSED
-      s.lit_src = wave::shuffle(s.lit_src, from);
-      s.lit_len = wave::shuffle(s.lit_len, from);
-      s.match_off = wave::shuffle(s.match_off, from);
-      s.match_len = wave::shuffle(s.match_len, from);
-#if NVCOMP_LZW_LIT_REGS
-      s.lit_lo = wave::shuffle(s.lit_lo, from);
-      s.lit_hi = wave::shuffle(s.lit_hi, from);
-#endif
+      lzw::drop_front(s, take, count);
 #endif
     }
     count -= take;
@@ -398,7 +392,7 @@ __device__ __forceinline__ void produce(const uint8_t* __restrict__ in, uint32_t
       lzw::in_ensure(ir, c.q, (c.q & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
       uint32_t seqpos = 0;
       count = lzw::chase_tokens(c, ir, seqpos, 0, DeltaFn(), SlowFn());
-      if (!parse_fast(ir, seqpos, lane < count, s, bad)) {
+      if (count == 0 || !parse_fast(ir, seqpos, 0, count, s, bad)) {
         parse(ir, seqpos, lane < count, s, bad);
       }
     }
@@ -515,11 +509,7 @@ __device__ __forceinline__ uint32_t consume(
       take = 1;
     }
     if (take < count) {
-      const uint32_t from = (lane + take) & 63u;
-      s.lit_src = wave::shuffle(s.lit_src, from);
-      s.lit_len = wave::shuffle(s.lit_len, from);
-      s.match_off = wave::shuffle(s.match_off, from);
-      s.match_len = wave::shuffle(s.match_len, from);
+      lzw::drop_front(s, take, count);
     }
     count -= take;
   }

@@ -8,18 +8,6 @@
  */
 #pragma once
 
-/* Snappy's own window tunables for the lane-per-sequence executor (MI355X sweep, profiles/r01_occupancy_variants.json):
- * its elements are half as long as LZ4's sequences, so a batch of 64 fills a smaller window; 1472 bytes leave 5 104 B of
- * LDS per wave = 8 waves/SIMD, which this decoder (unlike LZ4's, which loses more to the spills of a 64-VGPR budget) turns
- * into +4.5 %. */
-#if !defined(NVCOMP_LZW_OUTWIN)
-#define NVCOMP_LZW_OUTWIN 1472
-#define NVCOMP_LZW_BATCHMAX 736
-#define NVCOMP_LZW_KEEP 544
-#endif
-#if !defined(NVCOMP_LZW_WAVES_PER_SIMD)
-#define NVCOMP_LZW_WAVES_PER_SIMD 7 /* 8 = a 64-VGPR budget: 12 spilled VGPRs since the parsed sequences stay in registers; 7: 339 vs 322 GB/s */
-#endif
 #include "common/lz_window.hip.h"
 
 namespace snappyw {
@@ -216,34 +204,38 @@ __device__ __forceinline__ uint64_t ring_bytes8(const lzw::InRing& r, uint32_t p
   return ((uint64_t)hi << 32) | lo;
 }
 
-/* parse() for the common batch: literal elements of at most 60 bytes (no length bytes), everything a lane looks at
- * resident. Straight-line, two dependent LDS round trips; returns false (wave-uniform) when some lane needs the general
- * parser, which then redoes the whole batch. Same fields, same validation, same fusing rule. */
-__device__ __forceinline__ bool parse_fast(const lzw::InRing& r, uint32_t p, bool active, lz::Seq& s, bool& bad)
+/* parse() for the common batch, lanes [from, to) (to > from): literal elements of at most 60 bytes (no length bytes).
+ * As in lz4_decode_window.hip.h, residency and the chunk's end are checked once for the wave from the first and the last
+ * token position: a token of the fast kind spans at most kFastSpan stream bytes (tag, 60 literals, the fused copy's tag
+ * and offset, and the tag behind it), so under the precondition every lane's fields are resident and inside the chunk
+ * and the lanes run straight-line code. Returns false (wave-uniform) when the general parser must do the batch. */
+constexpr uint32_t kFastSpan = 80;
+
+__device__ __forceinline__ bool parse_fast(
+    const lzw::InRing& r, uint32_t p, uint32_t from, uint32_t to, lz::Seq& s, bool& bad)
 {
-  const uint32_t vend = r.vend;
-  const bool head_in = p >= r.lo && p + 12 <= r.hi;
-  const uint64_t w = ring_bytes8(r, active && head_in ? p : r.lo);
-  const uint32_t t = (uint32_t)w & 0xffu;
-  const uint32_t kind = t & 3u;
-  const bool is_lit = kind == 0;
-  const uint32_t code = t >> 2;
-  const uint32_t q = p + 2 + code; /* a literal element without length bytes ends here */
-  const bool lit_ok = code < 60 && q <= vend;
-  /* the copy element: the token itself, or the tag behind a fusable literal (kFuseMax >= 62: always fusable here) */
-  const bool look = is_lit && q < vend;
-  const bool tail_in = q + 12 <= r.hi;
-  const uint64_t y = ring_bytes8(r, active && head_in && look && tail_in && lit_ok ? q : r.lo);
-  const uint64_t c = is_lit ? y : w;
-  const uint32_t cp = is_lit ? q : p;
-  const uint32_t tag = (uint32_t)c & 0xffu;
-  const uint32_t k = tag & 3u;
-  const bool has_copy = !is_lit || (look && k != 0);
-  const uint32_t need = k == 3 ? 4u : k;
-  const bool general = active && (!head_in || (is_lit && (!lit_ok || (look && !tail_in))) || (has_copy && vend - (cp + 1) < need));
-  if (wave::ballot(general)) {
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t first = wave::read_lane(p, from);
+  const uint32_t last = wave::read_lane(p, to - 1);
+  const uint32_t lim = r.hi < r.vend ? r.hi : r.vend;
+  if (first < r.lo || last + kFastSpan > lim) {
     return false;
   }
+  const bool active = lane - from < to - from;
+  const uint64_t w = ring_bytes8(r, p); /* a lane outside [from, to) reads somewhere inside the ring: harmless */
+  const uint32_t t = (uint32_t)w & 0xffu;
+  const bool is_lit = (t & 3u) == 0;
+  const uint32_t code = t >> 2;
+  const uint32_t q = p + 2 + code; /* a literal element without length bytes ends here */
+  /* the copy element: the token itself, or the tag behind the (always fusable: kFuseMax >= 62) literal */
+  const uint64_t y = ring_bytes8(r, q);
+  const uint64_t c = is_lit ? y : w;
+  const uint32_t tag = (uint32_t)c & 0xffu;
+  const uint32_t k = tag & 3u;
+  if (wave::ballot(active && is_lit && code >= 60)) {
+    return false;
+  }
+  const bool has_copy = k != 0; /* a literal element behind a literal element is a token of its own */
   const uint32_t b1 = (uint32_t)(c >> 8) & 0xffu;
   const uint32_t b12 = (uint32_t)(c >> 8) & 0xffffu;
   const uint32_t b1234 = (uint32_t)(c >> 8);
@@ -349,7 +341,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
       count = lzw::chase_tokens(c, ir, seqpos, count, DeltaFn(), SlowFn());
       lz::Seq fresh;
       bool bad;
-      if (!parse_fast(ir, seqpos, lane >= before && lane < count, fresh, bad)) {
+      if (count <= before || !parse_fast(ir, seqpos, before, count, fresh, bad)) {
         parse(ir, seqpos, lane >= before && lane < count, fresh, bad);
       }
       if (lane >= before) {
@@ -392,10 +384,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
     if (take < count) {
       const uint32_t from = (lane + take) & 63u;
       seqpos = wave::shuffle(seqpos, from);
-      s.lit_src = wave::shuffle(s.lit_src, from);
-      s.lit_len = wave::shuffle(s.lit_len, from);
-      s.match_off = wave::shuffle(s.match_off, from);
-      s.match_len = wave::shuffle(s.match_len, from);
+      lzw::drop_front(s, take, count);
     }
     count -= take;
   }
@@ -435,7 +424,7 @@ __device__ __forceinline__ void produce(const uint8_t* __restrict__ in, uint32_t
       lzw::in_ensure(ir, c.q, (c.q & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
       uint32_t seqpos = 0;
       count = lzw::chase_tokens(c, ir, seqpos, 0, DeltaFn(), SlowFn());
-      if (!parse_fast(ir, seqpos, lane < count, s, bad)) {
+      if (count == 0 || !parse_fast(ir, seqpos, 0, count, s, bad)) {
         parse(ir, seqpos, lane < count, s, bad);
       }
       (void)merge_trains(s, count);
@@ -569,11 +558,7 @@ __device__ __forceinline__ uint32_t consume(
       take = take < count ? take : count;
     }
     if (take < count) {
-      const uint32_t from = (lane + take) & 63u;
-      s.lit_src = wave::shuffle(s.lit_src, from);
-      s.lit_len = wave::shuffle(s.lit_len, from);
-      s.match_off = wave::shuffle(s.match_off, from);
-      s.match_len = wave::shuffle(s.match_len, from);
+      lzw::drop_front(s, take, count);
     }
     count -= take;
   }

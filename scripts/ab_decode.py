@@ -41,8 +41,8 @@ def main():
     ap.add_argument("--libs", nargs="*", default=None)
     ap.add_argument("--cases", default="mix,snappy_mix")
     ap.add_argument("--mib", type=int, default=4096)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     import torch
