@@ -156,7 +156,7 @@ __device__ __forceinline__ uint32_t window_byte(const InWindow& w, uint32_t q)
 /* dst[0,len) = src[0,len), non-overlapping, any alignment. */
 __device__ __forceinline__ void wave_copy(uint8_t* dst, const uint8_t* src, uint32_t len)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   uint32_t base = 0;
   for (; base + 1024 <= len; base += 1024) {
     copy16(dst + base + lane * 16, src + base + lane * 16);
@@ -175,7 +175,7 @@ __device__ __forceinline__ void wave_copy(uint8_t* dst, const uint8_t* src, uint
  * (64 lanes x 16 / 4 / 1 bytes) never reads a byte the same step writes. */
 __device__ __forceinline__ void wave_match_copy(uint8_t* d, uint32_t off, uint32_t len)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   uint32_t done = 0;
   uint32_t E = off;
   while (done < len) {

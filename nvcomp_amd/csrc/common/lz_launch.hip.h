@@ -24,6 +24,13 @@
 #ifndef NVCOMP_LZ_PAIR_MAX_BATCH
 #define NVCOMP_LZ_PAIR_MAX_BATCH 3072 /* profiles/r02_pair_decode.json: two waves per chunk win up to ~3 000 chunks */
 #endif
+#ifndef NVCOMP_LZ_MAX_WG_PER_CU
+#define NVCOMP_LZ_MAX_WG_PER_CU 7 /* cap on the persistent workgroups (of four waves) per CU; 0 = as many as stay resident.
+                                   * Measured on MI355X (profiles/r03_ab_g.jsonl): the decoders fit 8 waves/SIMD since they stopped
+                                   * spilling, and run SLOWER there than at 7 (LZ4 mix 632 vs 644 GB/s, sorted-key column 686 vs
+                                   * 750): 28 waves per CU already keep the vector, scalar and LDS pipes two thirds busy, four more
+                                   * only add contention for L1 / L2 and the LDS pipe; 6 is worse again (607). */
+#endif
 #ifndef NVCOMP_LZ_PERSISTENT
 #define NVCOMP_LZ_PERSISTENT 1 /* A/B: 0 = one wave per chunk, static mapping (round 2) */
 #endif
@@ -76,6 +83,9 @@ inline unsigned resident_workgroups(Kernel kernel, unsigned block_threads)
       || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)block_threads, 0) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
+  }
+  if (NVCOMP_LZ_MAX_WG_PER_CU > 0 && per_cu > NVCOMP_LZ_MAX_WG_PER_CU) {
+    per_cu = NVCOMP_LZ_MAX_WG_PER_CU;
   }
   return cus > 0 && per_cu > 0 ? (unsigned)cus * (unsigned)per_cu : 0u;
 }

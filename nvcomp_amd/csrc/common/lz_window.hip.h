@@ -32,9 +32,12 @@ namespace lzw {
  * the matches of the headline workload reach further back than any window that fits the LDS budget (61 % further than
  * 4 KiB), so history only turned a twentieth of the far matches into near ones, and paid for it with 1 KiB of LDS per
  * wave and a slide of 768 bytes every other batch: without it +1.6 % (LZ4 mix), +2.4 % (Snappy), +7 % (text, 1 GiB
- * batches). Rounds 1-2 kept 768 bytes of a 2 KiB window (profiles/r01_window_variants.json). */
+ * batches). Rounds 1-2 kept 768 bytes of a 2 KiB window (profiles/r01_window_variants.json). A batch may produce up to
+ * 2 KiB: 5 712 B of LDS per wave still fit seven waves per SIMD (163 840 / 28), 64 sequences of text never get there,
+ * and data with long matches pays the per-batch costs half as often (sorted-key column 749 -> 887 GB/s, int32 column
+ * 684 -> 778, profiles/r03_ab_h.jsonl). */
 #ifndef NVCOMP_LZW_BATCHMAX
-#define NVCOMP_LZW_BATCHMAX 1024
+#define NVCOMP_LZW_BATCHMAX 2048
 #endif
 #ifndef NVCOMP_LZW_OUTWIN
 #define NVCOMP_LZW_OUTWIN (NVCOMP_LZW_BATCHMAX + 64)
@@ -145,7 +148,7 @@ __device__ __forceinline__ void in_init(InRing& r, const uint8_t* in, uint32_t i
  * into the ring. Bytes outside the chunk are never fetched (read as zero). */
 __device__ __forceinline__ void in_load_block(InRing& r, uint32_t vb)
 {
-  const uint32_t v = vb + 16u * (uint32_t)wave::lane_id();
+  const uint32_t v = vb + 16u * (uint32_t)wave::fresh_lane_id();
   wave::u32x4 x = {0, 0, 0, 0};
   if (v >= r.vbeg && v + 16 <= r.vend) {
     x = wave::gload_u32x4_aligned(r.base + v);
@@ -250,7 +253,7 @@ __device__ __forceinline__ void chase_init(Chase& c, uint32_t q, uint8_t* lds)
 template <class Delta>
 __device__ __forceinline__ void chase_build(Chase& c, const InRing& r, Delta delta)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   c.wb = c.q;
   const uint32_t room = r.vend - c.wb; /* c.q < vend */
   const uint32_t limit = room < kChaseWin ? room : kChaseWin;
@@ -404,7 +407,7 @@ __device__ __forceinline__ void out_make_room(OutWindow& w, uint32_t op)
     return;
   }
   const uint32_t len = op - new_base + w.align; /* window bytes still needed, from index 0 */
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   for (uint32_t base = 0; base < len; base += 1024) {
     const uint32_t i = base + lane * 16;
     wave::u32x4 t = {0, 0, 0, 0};
@@ -427,7 +430,7 @@ __device__ __forceinline__ void out_make_room(OutWindow& w, uint32_t op)
  * the first 16-byte boundary, aligned 16-byte lane stores, byte stores for the tail. */
 __device__ __forceinline__ void out_flush_range(const OutWindow& w, uint32_t from, uint32_t to)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   const uint32_t a_from = from + w.align; /* absolute-address-congruent coordinates */
   const uint32_t a_to = to + w.align;
   uint32_t body_lo = (a_from + 15u) & ~15u;
@@ -641,6 +644,20 @@ __device__ __forceinline__ void far_load_seq(uint32_t (&buf)[8], uint32_t& l4, c
   l4 = wave::gload_u32(src + len - 4);
 }
 
+/* x / off == umulhi(x, kMagic.v[off]) for x < 2^16 and 2 <= off < 256 (the runs' periods): a table instead of the 32-bit
+ * division 0xffffffff / off + 1, which was ~40 instructions per long match. */
+struct MagicTable
+{
+  uint32_t v[256];
+  constexpr MagicTable() : v()
+  {
+    for (uint32_t i = 2; i < 256; ++i) {
+      v[i] = 0xffffffffu / i + 1;
+    }
+  }
+};
+__constant__ static const MagicTable kMagic = MagicTable();
+
 /* Periodic fill: d[i] = d[i - off] for i in [0, len) with off < 256, i.e. the `off` bytes before d repeated. The
  * pattern is read ONCE -- lane l keeps its bytes 4l .. 4l+3 -- and every output dword is assembled from four
  * cross-lane fetches (ds_bpermute) at byte index (position mod off); the dwords go out with ALIGNED stores, 256 bytes
@@ -649,19 +666,17 @@ __device__ __forceinline__ void far_load_seq(uint32_t (&buf)[8], uint32_t& l4, c
  * one store. The pattern-doubling copy this replaces for short periods moved 4 .. 64 bytes per dependent round trip. */
 __device__ __forceinline__ void lds_periodic_fill(uint8_t* d, uint32_t off, uint32_t len)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
-  /* the pattern, a dword per lane (bytes at or behind `off` are never selected) */
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
+  /* the pattern, a dword per lane: ONE (misaligned) read by the off / 4 lanes that hold a piece of it -- a misaligned
+   * LDS access costs per active lane, and the periods of runs are short; the last lane's dword may reach past d - 1:
+   * bytes at or behind `off` are never selected */
   uint32_t pat = 0;
-#pragma unroll
-  for (uint32_t k = 0; k < 4; ++k) {
-    const uint32_t j = 4 * lane + k;
-    if (j < off) {
-      pat |= (uint32_t)d[(int32_t)j - (int32_t)off] << (8 * k);
-    }
+  if (4 * lane < off) {
+    pat = ld32(d - off + 4 * lane);
   }
   const uint32_t head = (4u - ((uint32_t)(uintptr_t)d & 3u)) & 3u; /* bytes up to the first aligned dword */
   const uint32_t h = head < len ? head : len;
-  const uint32_t magic = off == 1 ? 0u : 0xffffffffu / off + 1; /* x / off == umulhi(x, magic) for x, off < 2^16 (off 1: x mod 1 = 0 below) */
+  const uint32_t magic = kMagic.v[off]; /* x / off == umulhi(x, magic) for x < 2^16 (off 1: x mod 1 = 0 below, magic unused) */
   if (lane < h) {
     const uint32_t sidx = off == 1 ? 0u : lane - __umulhi(lane, magic) * off;
     d[lane] = (uint8_t)(wave::shuffle(pat, sidx >> 2) >> (8 * (sidx & 3u)));
@@ -709,7 +724,7 @@ __device__ __forceinline__ void lds_periodic_fill(uint8_t* d, uint32_t off, uint
  * Periods below 256 are a periodic fill; longer ones move 256 bytes per step (a step never reads what it writes). */
 __device__ __forceinline__ void lds_match_copy(uint8_t* d, uint32_t off, uint32_t len)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   if (off < 256) {
     lds_periodic_fill(d, off, len);
     return;
@@ -735,7 +750,7 @@ __device__ __forceinline__ void lds_match_copy(uint8_t* d, uint32_t off, uint32_
 /* dst (LDS) <- src (HBM), non-overlapping, whole wave, any alignment. */
 __device__ __forceinline__ void copy_to_lds(uint8_t* dst, const uint8_t* src, uint32_t len)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   uint32_t base = 0;
   for (; base + 256 <= len; base += 256) {
     lz::st_u32(dst + base + lane * 4, wave::gload_u32(src + base + lane * 4));
@@ -743,6 +758,196 @@ __device__ __forceinline__ void copy_to_lds(uint8_t* dst, const uint8_t* src, ui
   for (uint32_t i = base + lane; i < len; i += 64) {
     dst[i] = (uint8_t)wave::gload_u8(src + i);
   }
+}
+
+/* ---- long runs: straight to HBM ----------------------------------------------------------------------------------
+ *
+ * A sequence with a long literal run or a long match does not go through the window: the window's bytes are flushed,
+ * the sequence is written to the output buffer directly with 16-byte lane accesses (1 KiB per wave instruction), and the
+ * window restarts behind it (it holds no history). Data of this kind is what CAN approach the HBM roofline
+ * (incompressible chunks are one literal run, runs and sorted columns are a few long matches), and through the window
+ * it paid an LDS round trip, a per-batch cut at kBatchMax bytes and, for matches, a dependent load -> store chain per
+ * step. The reference's only published number is of this shape (doc/Benchmarks.md:88-95).
+ */
+#ifndef NVCOMP_LZW_STREAM_LIT
+#define NVCOMP_LZW_STREAM_LIT 4096 /* literal runs from this length on are streamed */
+#endif
+#ifndef NVCOMP_LZW_STREAM_MATCH
+#define NVCOMP_LZW_STREAM_MATCH 4096 /* matches from this length on are streamed */
+#endif
+constexpr uint32_t kStreamLit = NVCOMP_LZW_STREAM_LIT;
+constexpr uint32_t kStreamMatch = NVCOMP_LZW_STREAM_MATCH;
+
+/* dst[0, n) = src[0, n): different buffers or src at least 4 KiB in front of dst; any alignment. The stores are 16-byte
+ * aligned, four loads of 1 KiB are in flight before the first store (one load -> store round trip per KiB made a
+ * 64 KiB literal run latency-bound at 2 TB/s of copy traffic). */
+__device__ __forceinline__ void stream_copy(uint8_t* dst, const uint8_t* src, uint32_t n)
+{
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
+  const uint32_t head = (16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u;
+  const uint32_t h = head < n ? head : n;
+  if (lane < h) {
+    wave::gstore_u8(dst + lane, wave::gload_u8(src + lane));
+  }
+  const uint32_t body_end = h + ((n - h) & ~15u); /* the 16-byte blocks end here */
+  uint32_t base = h;
+  for (; base + 4096 <= body_end; base += 4096) {
+    const uint32_t at = base + 16 * lane;
+    const wave::u32x4 a = wave::gload_u32x4(src + at), b = wave::gload_u32x4(src + at + 1024);
+    const wave::u32x4 c = wave::gload_u32x4(src + at + 2048), d = wave::gload_u32x4(src + at + 3072);
+    wave::gstore_u32x4_aligned(dst + at, a);
+    wave::gstore_u32x4_aligned(dst + at + 1024, b);
+    wave::gstore_u32x4_aligned(dst + at + 2048, c);
+    wave::gstore_u32x4_aligned(dst + at + 3072, d);
+  }
+  for (; base < body_end; base += 1024) {
+    const uint32_t at = base + 16 * lane;
+    if (at < body_end) {
+      wave::gstore_u32x4_aligned(dst + at, wave::gload_u32x4(src + at));
+    }
+  }
+  const uint32_t tail = body_end + lane;
+  if (tail < n) {
+    wave::gstore_u8(dst + tail, wave::gload_u8(src + tail));
+  }
+}
+
+/* d[i] = d[i - off] for i in [0, len), off < 256, the off bytes in front of d already in HBM: the pattern is read once
+ * (a dword per lane) and every 16-byte store is assembled in registers from cross-lane fetches at (position mod off);
+ * when off divides 1 KiB (1, 2, 4, 8, ...: runs, typed columns) a lane's 16 bytes never change and the run is a sequence
+ * of plain stores -- no load at all behind the first. */
+__device__ __forceinline__ void stream_periodic(uint8_t* d, uint32_t off, uint32_t len)
+{
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
+  uint32_t pat = 0;
+  if (4 * lane < off) {
+    pat = wave::gload_u32(d - off + 4 * lane); /* bytes at or behind `off` are never selected */
+  }
+  const uint32_t magic = kMagic.v[off]; /* x / off == umulhi(x, magic) for x < 2^16 */
+  const uint32_t head = (16u - (uint32_t)((uintptr_t)d & 15u)) & 15u;
+  const uint32_t h = head < len ? head : len;
+  {
+    const uint32_t sidx = off == 1 ? 0u : lane - __umulhi(lane, magic) * off; /* lane < 64 <= 2^16 */
+    const uint32_t b = wave::shuffle(pat, (lane < h ? sidx : 0u) >> 2) >> (8 * (sidx & 3u));
+    if (lane < h) {
+      wave::gstore_u8(d + lane, b);
+    }
+  }
+  const uint32_t blocks = (len - h) >> 4; /* aligned 16-byte blocks */
+  const uint32_t step = off == 1 ? 0u : 1024u - __umulhi(1024u, magic) * off; /* 1024 mod off: the phase shift per KiB */
+  uint32_t r = h + 16 * lane;
+  r = off == 1 ? 0u : r - __umulhi(r, magic) * off;
+  wave::u32x4 q = {0, 0, 0, 0};
+  bool fresh = true;
+  for (uint32_t base = 0; base < blocks; base += 64) {
+    if (fresh) {
+      uint32_t sidx = r;
+      uint32_t w[4];
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) {
+        uint32_t word = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+          const uint32_t b = (wave::shuffle(pat, sidx >> 2) >> (8 * (sidx & 3u))) & 0xffu;
+          word |= b << (8 * j);
+          sidx = sidx + 1 == off ? 0 : sidx + 1;
+        }
+        w[k] = word;
+      }
+      q.x = w[0], q.y = w[1], q.z = w[2], q.w = w[3];
+      fresh = step != 0;
+      r += step;
+      r = r >= off ? r - off : r;
+    }
+    if (base + lane < blocks) {
+      wave::gstore_u32x4_aligned(d + h + 16 * (base + lane), q);
+    }
+  }
+  const uint32_t tail_at = h + 16 * blocks;
+  {
+    const uint32_t i = tail_at + lane;
+    const uint32_t x = i % off; /* once per run: i may be as large as the chunk */
+    const uint32_t b = wave::shuffle(pat, (i < len ? x : 0u) >> 2) >> (8 * (x & 3u));
+    if (i < len) {
+      wave::gstore_u8(d + i, b);
+    }
+  }
+}
+
+/* d[i] = d[i - off], i in [0, len), byte-serial semantics, everything in front of d already in HBM (one wave's vector
+ * memory operations are served in issue order: a later load sees an earlier store of the same wave). */
+__device__ __forceinline__ void stream_match(uint8_t* d, uint32_t off, uint32_t len)
+{
+  if (off < 256) {
+    stream_periodic(d, off, len);
+    return;
+  }
+  /* The effective offset E stays a multiple of off and doubles as the run grows (E <= done + off: the source never
+   * starts in front of d - off), so a step of up to E bytes reads nothing the same step writes: 4 KiB with four loads
+   * in flight once E allows it, 1 KiB or 256 bytes before, single bytes for what is left. */
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
+  uint32_t done = 0;
+  uint32_t E = off;
+  while (done < len) {
+    while (E < 4096 && 2 * E <= done + off) {
+      E *= 2;
+    }
+    const uint32_t rem = len - done;
+    if (E >= 4096 && rem >= 4096) {
+      uint8_t* t = d + done + 16 * lane;
+      const wave::u32x4 a = wave::gload_u32x4(t - E), b = wave::gload_u32x4(t - E + 1024);
+      const wave::u32x4 c = wave::gload_u32x4(t - E + 2048), e = wave::gload_u32x4(t - E + 3072);
+      wave::gstore_u32x4(t, a);
+      wave::gstore_u32x4(t + 1024, b);
+      wave::gstore_u32x4(t + 2048, c);
+      wave::gstore_u32x4(t + 3072, e);
+      done += 4096;
+    } else if (E >= 1024 && rem >= 1024) {
+      uint8_t* t = d + done + 16 * lane;
+      wave::gstore_u32x4(t, wave::gload_u32x4(t - E));
+      done += 1024;
+    } else if (rem >= 256) { /* E >= off >= 256 */
+      uint8_t* t = d + done + 4 * lane;
+      wave::gstore_u32(t, wave::gload_u32(t - E));
+      done += 256;
+    } else {
+      for (uint32_t i = lane; i < rem; i += 64) { /* rem < 256 <= E: no byte of this step reads another */
+        uint8_t* t = d + done + i;
+        wave::gstore_u8(t, wave::gload_u8(t - E));
+      }
+      done = len;
+    }
+    wave::sync();
+  }
+}
+
+/* A sequence that is streamed instead of executed in the window (execute_window_batch reported `big` for the first
+ * sequence in hand): literals [lsrc, lsrc + llen) of the stream, then the match (moff, mlen). Validates like the batch
+ * executor; returns false on error. The window is flushed first and restarts empty behind the sequence. */
+template <bool CHECKED>
+__device__ __forceinline__ bool stream_sequence(
+    const InRing& ir, OutWindow& ow, uint32_t out_cap, uint32_t& op, uint32_t lsrc, uint32_t llen, uint32_t moff, uint32_t mlen,
+    uint32_t& err)
+{
+  if (CHECKED) {
+    const uint64_t end = (uint64_t)op + llen + mlen;
+    if (end > out_cap || (mlen != 0 && (moff == 0 || moff > op + llen))) {
+      err |= end > out_cap ? lz::kErrOutput : lz::kErrOffset;
+      return false;
+    }
+  }
+  out_flush_all(ow, op); /* the copies below read what the window still held back */
+  wave::sync();
+  if (llen) {
+    stream_copy(ow.out + op, ir.base + lsrc, llen);
+    wave::sync();
+  }
+  if (mlen) {
+    stream_match(ow.out + op + llen, moff, mlen);
+  }
+  op += llen + mlen;
+  restart_window(ow, op);
+  return true;
 }
 
 /*
@@ -770,7 +975,9 @@ __device__ __forceinline__ uint32_t execute_window_batch(
 
   /* leading sequences whose cumulative output fits one batch (a length is < 2^31: the first sum above kBatchMax has
    * not wrapped, whatever the sums behind it do) */
-  const uint64_t over = wave::ballot(incl > kBatchMax);
+  /* ... and a sequence with a long literal run or a long match is not for the window at all (stream_sequence) */
+  const bool streamed = !RING_LITERALS && (s.lit_len >= kStreamLit || s.match_len >= kStreamMatch);
+  const uint64_t over = wave::ballot(incl > kBatchMax || streamed);
   uint32_t take = over ? wave::ctz64(over) : 64u;
   take = take < n ? take : n;
   if (take == 0) {
@@ -918,7 +1125,6 @@ __device__ __forceinline__ uint32_t execute_window_batch(
     const bool near_lane = is_near && short_match && s.match_off >= 4;
     uint64_t pending = (NVCOMP_LZW_ABLATE_EXEC & 8) ? 0ull : wave::ballot(my_match != 0 && !far_lane);
     const uint64_t near_mask = wave::ballot(near_lane);
-    const uint64_t lane_bit = 1ull << lane;
     LZ_STAT("match_far_lanes", wave::popc64(wave::ballot(far_lane)));
     LZ_STAT("match_near_lanes", wave::popc64(near_mask));
     LZ_STAT("match_coop", wave::popc64(pending & ~near_mask));
@@ -946,7 +1152,7 @@ __device__ __forceinline__ uint32_t execute_window_batch(
         LZW_T(14); /* matches copied by the whole wave */
         continue;
       }
-      const bool ready = near_lane && (pending & lane_bit) && (lane == f || match_src + my_match <= hw);
+      const bool ready = near_lane && wave::lane_in(pending) && (lane == f || match_src + my_match <= hw);
       const uint32_t steps = steps_for(ready, my_match);
       LZ_STAT("mrr_rounds", 1);
       LZ_STAT("mrr_iters", steps);

@@ -70,10 +70,40 @@ __device__ __forceinline__ void gstore_u32x4_aligned(uint8_t* p, u32x4 v)
 {
   *(WAVE_GLOBAL u32x4*)p = v;
 }
+__device__ __forceinline__ void gstore_u32x4(uint8_t* p, u32x4 v) /* any alignment (global_store_dwordx4) */
+{
+  WAVE_GLOBAL PackedU32x4* q = (WAVE_GLOBAL PackedU32x4*)p;
+  q->v[0] = v.x, q->v[1] = v.y, q->v[2] = v.z, q->v[3] = v.w;
+}
+__device__ __forceinline__ void gstore_u32(uint8_t* p, uint32_t v) /* any alignment */
+{
+  ((WAVE_GLOBAL PackedU32*)p)->v = v;
+}
 
 __device__ __forceinline__ int lane_id()
 {
   return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+/* The same value, computed where it is asked for. The compiler treats lane_id() as one loop-invariant value and hoists
+ * everything derived from it (16 * lane, lds + 4 * lane, 1ull << lane, ...) to the top of the kernel: a dozen
+ * registers held across the whole decode loop of the LZ kernels, enough to push them into scratch -- and a scratch
+ * reload is a vector memory load: the s_waitcnt vmcnt(0) in front of its first use also waits for every store the
+ * previous batch's flush left in flight. Code that runs once per batch or less takes its lane id from here: two VALU
+ * instructions, nothing kept live. */
+__device__ __forceinline__ int fresh_lane_id()
+{
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
+/* Is the calling lane's bit set in the wave-uniform mask? (v_cndmask with the mask as its condition: no 1ull << lane) */
+__device__ __forceinline__ bool lane_in(uint64_t mask)
+{
+  uint32_t r;
+  asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(mask));
+  return r != 0;
 }
 
 /* 64-bit mask of lanes whose predicate is true. */

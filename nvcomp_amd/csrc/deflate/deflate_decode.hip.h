@@ -31,6 +31,11 @@
  */
 #pragma once
 
+/* DEFLATE's own window size: its batches are cut by the front end at 64 records anyway, and its LDS (lookup tables, the
+ * literal ring, the bit-position jump tables) is the occupancy limiter: 1 KiB batches keep a wave at 10.1 KiB. */
+#ifndef NVCOMP_LZW_BATCHMAX
+#define NVCOMP_LZW_BATCHMAX 1024
+#endif
 #include "common/lz_window.hip.h"
 
 namespace deflate {

@@ -321,27 +321,11 @@ __device__ __forceinline__ uint32_t decode_chunk(
       return 0;
     }
     if (big) {
-      /* sequence 0 alone exceeds a batch: stream it HBM -> HBM and restart the window after it */
-      const uint32_t lsrc = wave::read_lane(s.lit_src, 0);
-      const uint32_t llen = wave::read_lane(s.lit_len, 0);
-      const uint32_t moff = wave::read_lane(s.match_off, 0);
-      const uint32_t mlen = wave::read_lane(s.match_len, 0);
-      if (CHECKED) {
-        const uint64_t end = (uint64_t)op + llen + mlen;
-        if (end > out_cap || (mlen != 0 && (moff == 0 || moff > op + llen))) {
-          err |= end > out_cap ? lz::kErrOutput : lz::kErrOffset;
-          return 0;
-        }
+      /* the first sequence in hand has a long literal run or a long match, or is larger than a batch: straight to HBM */
+      if (!lzw::stream_sequence<CHECKED>(ir, ow, out_cap, op, wave::read_lane(s.lit_src, 0), wave::read_lane(s.lit_len, 0),
+                                         wave::read_lane(s.match_off, 0), wave::read_lane(s.match_len, 0), err)) {
+        return 0;
       }
-      lzw::out_flush_all(ow, op); /* the HBM-to-HBM copies below read what the window still held back */
-      wave::sync();
-      lz::wave_copy(out + op, ir.base + lsrc, llen);
-      wave::sync();
-      if (mlen) {
-        lz::wave_match_copy(out + op + llen, moff, mlen);
-      }
-      op += llen + mlen;
-      lzw::restart_window(ow, op);
       take = 1;
     }
     /* drop the executed sequences, keep the rest for the next round */
@@ -482,30 +466,14 @@ __device__ __forceinline__ uint32_t consume(
       return 0;
     }
     if (big) {
-      /* sequence 0 alone exceeds a batch: stream it HBM -> HBM and restart the window after it */
-      const uint32_t lsrc = wave::read_lane(s.lit_src, 0);
-      const uint32_t llen = wave::read_lane(s.lit_len, 0);
-      const uint32_t moff = wave::read_lane(s.match_off, 0);
-      const uint32_t mlen = wave::read_lane(s.match_len, 0);
-      if (CHECKED) {
-        const uint64_t end = (uint64_t)op + llen + mlen;
-        if (end > out_cap || (mlen != 0 && (moff == 0 || moff > op + llen))) {
-          err |= end > out_cap ? lz::kErrOutput : lz::kErrOffset;
-          if (lane == 0) {
-            wave::lds_store_release(sh.abort, 1u);
-          }
-          return 0;
+      /* the first sequence in hand has a long literal run or a long match, or is larger than a batch: straight to HBM */
+      if (!lzw::stream_sequence<CHECKED>(ir, ow, out_cap, op, wave::read_lane(s.lit_src, 0), wave::read_lane(s.lit_len, 0),
+                                         wave::read_lane(s.match_off, 0), wave::read_lane(s.match_len, 0), err)) {
+        if (lane == 0) {
+          wave::lds_store_release(sh.abort, 1u);
         }
+        return 0;
       }
-      lzw::out_flush_all(ow, op);
-      wave::sync();
-      lz::wave_copy(out + op, ir.base + lsrc, llen);
-      wave::sync();
-      if (mlen) {
-        lz::wave_match_copy(out + op + llen, moff, mlen);
-      }
-      op += llen + mlen;
-      lzw::restart_window(ow, op);
       take = 1;
     }
     if (take < count) {

@@ -359,26 +359,11 @@ __device__ __forceinline__ uint32_t decode_chunk(
       return 0;
     }
     if (big) {
-      const uint32_t lsrc = wave::read_lane(s.lit_src, 0);
-      const uint32_t llen = wave::read_lane(s.lit_len, 0);
-      const uint32_t moff = wave::read_lane(s.match_off, 0);
-      const uint32_t mlen = wave::read_lane(s.match_len, 0);
-      if (CHECKED) {
-        const uint64_t end = (uint64_t)op + llen + mlen;
-        if (end > limit || (mlen != 0 && (moff == 0 || moff > op + llen))) {
-          err |= end > limit ? lz::kErrOutput : lz::kErrOffset;
-          return 0;
-        }
+      /* the first sequence in hand has a long literal run or a long match, or is larger than a batch: straight to HBM */
+      if (!lzw::stream_sequence<CHECKED>(ir, ow, limit, op, wave::read_lane(s.lit_src, 0), wave::read_lane(s.lit_len, 0),
+                                         wave::read_lane(s.match_off, 0), wave::read_lane(s.match_len, 0), err)) {
+        return 0;
       }
-      lzw::out_flush_all(ow, op); /* the HBM-to-HBM copies below read what the window still held back */
-      wave::sync();
-      lz::wave_copy(out + op, ir.base + lsrc, llen);
-      wave::sync();
-      if (mlen) {
-        lz::wave_match_copy(out + op + llen, moff, mlen);
-      }
-      op += llen + mlen;
-      lzw::restart_window(ow, op);
       take = 1 + wave::ctz64(~(train >> 1)); /* sequence 0 and the empty sequences of its train */
     }
     if (take < count) {
@@ -529,29 +514,14 @@ __device__ __forceinline__ uint32_t consume(
       return 0;
     }
     if (big) {
-      const uint32_t lsrc = wave::read_lane(s.lit_src, 0);
-      const uint32_t llen = wave::read_lane(s.lit_len, 0);
-      const uint32_t moff = wave::read_lane(s.match_off, 0);
-      const uint32_t mlen = wave::read_lane(s.match_len, 0);
-      if (CHECKED) {
-        const uint64_t end = (uint64_t)op + llen + mlen;
-        if (end > limit || (mlen != 0 && (moff == 0 || moff > op + llen))) {
-          err |= end > limit ? lz::kErrOutput : lz::kErrOffset;
-          if (lane == 0) {
-            wave::lds_store_release(sh.abort, 1u);
-          }
-          return 0;
+      /* the first sequence in hand has a long literal run or a long match, or is larger than a batch: straight to HBM */
+      if (!lzw::stream_sequence<CHECKED>(ir, ow, limit, op, wave::read_lane(s.lit_src, 0), wave::read_lane(s.lit_len, 0),
+                                         wave::read_lane(s.match_off, 0), wave::read_lane(s.match_len, 0), err)) {
+        if (lane == 0) {
+          wave::lds_store_release(sh.abort, 1u);
         }
+        return 0;
       }
-      lzw::out_flush_all(ow, op);
-      wave::sync();
-      lz::wave_copy(out + op, ir.base + lsrc, llen);
-      wave::sync();
-      if (mlen) {
-        lz::wave_match_copy(out + op + llen, moff, mlen);
-      }
-      op += llen + mlen;
-      lzw::restart_window(ow, op);
       /* sequence 0 and the empty sequences (the followers of its copy train) right behind it */
       const uint64_t empty = wave::ballot(lane < count && s.lit_len + s.match_len == 0);
       take = 1 + wave::ctz64(~(empty >> 1));

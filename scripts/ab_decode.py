@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--again", action="store_true", help="time the first build once more at the end (run-to-run noise)")
     a = ap.parse_args()
     import torch
 
@@ -56,6 +57,8 @@ def main():
     libs = a.libs or ([_lib.LIB_PATH] + sorted(glob.glob(os.path.join(REPO, "nvcomp_amd", "lib", "alt", "*.so"))))
     handles = [(os.path.basename(p).replace("libnvcomp_", "").replace(".so", ""), _lib.declare(C.CDLL(os.path.abspath(p))))
                for p in libs]
+    if a.again:
+        handles.append((handles[0][0] + "_again", handles[0][1]))
     dev = nvcomp_amd.TorchDevice("cuda:0")
     threads = len(os.sched_getaffinity(0))
     sink = open(a.out, "a") if a.out else None

@@ -21,6 +21,8 @@ struct u32x4
 enum OpId { kBallot = 1, kReadLane, kUniform, kShuffle, kScan, kMax, kSync };
 
 inline int lane_id() { return emu::cur()->lane; }
+inline int fresh_lane_id() { return emu::cur()->lane; }
+inline bool lane_in(uint64_t mask) { return ((mask >> emu::cur()->lane) & 1) != 0; }
 
 inline uint64_t ballot(bool pred)
 {
@@ -132,6 +134,8 @@ inline uint64_t gload_u64(const uint8_t* p)
 inline uint32_t gload_u16(const uint16_t* p) { return *p; }
 inline void gstore_u8(uint8_t* p, uint32_t v) { *p = (uint8_t)v; }
 inline void gstore_u32x4_aligned(uint8_t* p, u32x4 v) { *(u32x4*)p = v; }
+inline void gstore_u32(uint8_t* p, uint32_t v) { memcpy(p, &v, 4); }
+inline void gstore_u32x4(uint8_t* p, u32x4 v) { memcpy(p, &v, 16); }
 
 inline uint32_t shuffle(uint32_t v, uint32_t src_lane)
 {

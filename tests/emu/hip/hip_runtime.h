@@ -29,6 +29,7 @@
 #define __global__
 #define __device__
 #define __host__
+#define __constant__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static
 #define __launch_bounds__(...)

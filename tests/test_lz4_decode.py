@@ -93,6 +93,82 @@ def test_long_matches_and_overlaps(backend, lz_path, oracle):
     check_roundtrip(backend, oracle, chunks, cpu_compress(oracle, chunks))
 
 
+def _lz4_block(seqs, tail):
+    """Hand-built LZ4 block: seqs = [(literal bytes, offset, match length >= 4)], tail = the final literal-only sequence."""
+    out = bytearray()
+
+    def lens(n):
+        b = bytearray()
+        while n >= 255:
+            b.append(255)
+            n -= 255
+        b.append(n)
+        return b
+
+    for lit, off, mlen in seqs:
+        ll, ml = len(lit), mlen - 4
+        out.append((min(ll, 15) << 4) | min(ml, 15))
+        if ll >= 15:
+            out += lens(ll - 15)
+        out += lit
+        out += bytes([off & 255, off >> 8])
+        if ml >= 15:
+            out += lens(ml - 15)
+    ll = len(tail)
+    out.append(min(ll, 15) << 4)
+    if ll >= 15:
+        out += lens(ll - 15)
+    out += tail
+    return np.frombuffer(bytes(out), dtype=np.uint8)
+
+
+def _lz4_expand(seqs, tail):
+    out = bytearray()
+    for lit, off, mlen in seqs:
+        out += lit
+        for _ in range(mlen):
+            out.append(out[-off])
+    out += tail
+    return np.frombuffer(bytes(out), dtype=np.uint8)
+
+
+def test_streamed_long_runs(backend, lz_path, oracle):
+    """Long literal runs and long matches leave the window path and are written straight to the output buffer
+    (common/lz_window.hip.h: stream_sequence): every period class (a register tile that never changes, one that rotates,
+    HBM-to-HBM copies whose effective offset doubles), lengths around the thresholds and the step sizes, every output
+    alignment, short sequences in between (the window restarts behind a streamed one)."""
+    rng = np.random.RandomState(77)
+    offs = [1, 2, 3, 4, 5, 7, 8, 13, 16, 31, 32, 64, 100, 255, 256, 257, 300, 1000, 1023, 1024, 1025, 1500, 4095, 4096, 4097, 5200, 9000]
+    lens = [127, 128, 129, 200, 255, 256, 257, 300, 1023, 1024, 1025, 1040, 4095, 4096, 4113, 5000, 20000]
+    if backend.name == "emu":
+        offs, lens = offs[::2] + [256, 1024], lens[::2] + [128, 4096]
+    blocks, raws = [], []
+    for i, off in enumerate(offs):
+        seqs = [(rng.randint(0, 256, size=max(off, 8) + i % 5).astype(np.uint8).tobytes(), min(off, 4), 4)]  # something to point at
+        seqs[0] = (seqs[0][0], 1 + (i % 3), 4 + i % 7)
+        for j, mlen in enumerate(lens):
+            lit = rng.randint(0, 256, size=(j * 7 + i) % 23).astype(np.uint8).tobytes()
+            produced = sum(len(l) + m for l, _, m in seqs)
+            if off > produced + len(lit):
+                lit += rng.randint(0, 256, size=off - produced - len(lit)).astype(np.uint8).tobytes()
+            seqs.append((lit, off, mlen))
+            seqs.append((rng.randint(0, 256, size=j % 4).astype(np.uint8).tobytes(), 1 + j % 9, 4 + j % 13))  # a short one behind it
+        tail = rng.randint(0, 256, size=5 + i % 11).astype(np.uint8).tobytes()
+        blocks.append(_lz4_block(seqs, tail))
+        raws.append(_lz4_expand(seqs, tail))
+    # long literal runs: lengths around the threshold and the 1 KiB / 4 KiB steps, matches in between
+    for n in [255, 256, 257, 1000, 1024, 1039, 4096, 4111, 5000, 40000]:
+        lit = rng.randint(0, 256, size=n).astype(np.uint8).tobytes()
+        seqs = [(b"abc", 1, 9), (lit, 7, 30), (lit[: n // 3], n // 2 + 1, 500), (b"", 3, 4)]
+        blocks.append(_lz4_block(seqs, lit[:300]))
+        raws.append(_lz4_expand(seqs, lit[:300]))
+    for cc, c in zip(blocks, raws):
+        rc, ref = oracle.lz4_decompress(cc, c.size)
+        assert rc == 0 and np.array_equal(ref, c), "the hand-built block is not what the oracle reads"
+    for mis in (0, 1, 5, 15):
+        check_roundtrip(backend, oracle, raws, blocks, base_misalign=mis)
+
+
 def test_corrupt_streams_do_not_escape(backend, lz_path, oracle):
     """Invalid input -> status != success and size 0 (CHANGELOG.md:160-164); never a write
     outside the output slot (canaries) and, where the oracle accepts, identical bytes."""
