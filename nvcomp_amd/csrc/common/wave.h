@@ -206,6 +206,12 @@ __device__ __forceinline__ uint32_t shuffle(uint32_t v, uint32_t src_lane)
   return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
 }
 
+/* v of the lane below (lane 0: 0): one DPP move across the whole wave (wave_shr:1), no LDS crossbar round trip. */
+__device__ __forceinline__ uint32_t prev_lane(uint32_t v)
+{
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
+}
+
 /* Inclusive prefix sum across the wave: 4 row_shr steps inside each row of 16
  * lanes, then row_bcast:15 / row_bcast:31 to carry across rows (DPP, no LDS). */
 __device__ __forceinline__ uint32_t scan_add_inclusive(uint32_t v)

@@ -101,21 +101,20 @@ struct DeltaFn
 {
   static constexpr uint32_t kReach = 8 + kFuseMax + 8; /* tag + length field, and the tag behind a fusable literal */
   __device__ __forceinline__ uint32_t operator()(const lzw::InRing& r, uint32_t p) const { return tag_delta(r, p); }
-  /* interior window: `w` = the stream bytes from p on (tag in bits 0-7, a literal's length field in 8-39) */
+  /* interior window: `w` = the stream bytes from p on (tag in bits 0-7). A literal element with explicit length bytes
+   * (more than 60 bytes: one literal element in a thousand on the mix) is left to the scalar walk: the speculative pass
+   * runs for four positions per lane per window, and resolving the 1-4 length bytes there cost more than twice as many
+   * instructions per position as the rest of the rule (35 vs 15). The size of a copy element by kind -- 0, 2, 3, 5 --
+   * is a nibble table in a constant. */
   __device__ __forceinline__ uint32_t fast(const lzw::InRing& r, uint32_t p, uint64_t w) const
   {
     const uint32_t t = (uint32_t)w & 0xffu;
-    const uint32_t field = (uint32_t)(w >> 8);
     const uint32_t kind = t & 3u;
     const uint32_t code = t >> 2;
-    const uint32_t nb = code >= 60 ? code - 59 : 0u;
-    const uint32_t ext = nb == 4 ? field : (field & ((1u << (8 * nb)) - 1u));
-    const uint32_t lit_delta = 2 + nb + (nb ? ext : code);
-    const uint32_t copy_delta = kind == 3 ? 5u : kind + 1;
-    const bool unknown = kind == 0 && nb && ext >= 0x7fffff00u;
+    const uint32_t lit_delta = code + 2; /* tag + (code + 1) bytes */
     const uint32_t k2 = r.ring[(p + lit_delta) & (lzw::kInRing - 1)] & 3u; /* harmless when not a literal */
-    const uint32_t fused = lit_delta <= kFuseMax && k2 ? copy_size(k2) : 0u;
-    return unknown ? kUnknown : (kind == 0 ? lit_delta + fused : copy_delta);
+    const uint32_t lit_total = code >= 60 ? kUnknown : lit_delta + ((0x5320u >> (4 * k2)) & 15u); /* kFuseMax >= 62: always fused */
+    return kind == 0 ? lit_total : (0x5320u >> (4 * kind)) & 15u;
   }
 };
 struct SlowFn
@@ -273,9 +272,10 @@ __device__ __forceinline__ bool read_preamble(const lzw::InRing& ir, uint32_t& q
 __device__ __forceinline__ uint64_t merge_trains(lz::Seq& s, uint32_t count)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
-  const uint32_t prev_off = wave::shuffle(s.match_off, (lane - 1) & 63u);
-  const uint32_t prev_len = wave::shuffle(s.match_len, (lane - 1) & 63u);
-  const bool cont = lane > 0 && lane < count && s.lit_len == 0 && s.match_len != 0 && prev_len != 0 && prev_off == s.match_off;
+  /* lanes >= count hold empty sequences, lane 0's neighbour reads as one: no lane tests */
+  const uint32_t prev_off = wave::prev_lane(s.match_off);
+  const uint32_t prev_len = wave::prev_lane(s.match_len);
+  const bool cont = s.lit_len == 0 && s.match_len != 0 && prev_len != 0 && prev_off == s.match_off;
   const uint64_t train = wave::ballot(cont);
   if (train) {
     const uint32_t incl = wave::scan_add_inclusive(lane < count ? s.match_len : 0u);

@@ -137,6 +137,13 @@ inline void gstore_u32x4_aligned(uint8_t* p, u32x4 v) { *(u32x4*)p = v; }
 inline void gstore_u32(uint8_t* p, uint32_t v) { memcpy(p, &v, 4); }
 inline void gstore_u32x4(uint8_t* p, u32x4 v) { memcpy(p, &v, 16); }
 
+inline uint32_t shuffle(uint32_t v, uint32_t src_lane);
+inline uint32_t prev_lane(uint32_t v)
+{
+  const uint32_t r = shuffle(v, (uint32_t)(lane_id() - 1) & 63u);
+  return lane_id() == 0 ? 0u : r;
+}
+
 inline uint32_t shuffle(uint32_t v, uint32_t src_lane)
 {
   emu::wave_rendezvous(kShuffle, v, src_lane);
