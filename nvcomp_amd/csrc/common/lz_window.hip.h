@@ -720,11 +720,40 @@ __device__ __forceinline__ void lds_periodic_fill(uint8_t* d, uint32_t off, uint
   wave::sync();
 }
 
+/* The same for the periods of runs and typed columns -- off in {1, 2, 4, 8, 16}, len >= 32: every ALIGNED 16-byte
+ * block of the run holds the same 16 bytes. The first 32 bytes are written byte by byte (32 lanes, index & (off - 1)),
+ * the aligned block inside them is read back by all lanes at once (one address: a broadcast), and the run is a
+ * sequence of ds_write_b128 -- 1 KiB per instruction, no cross-lane fetches, no division. A sorted-key column compressed
+ * by liblz4 (the reference's published shape) is almost only such matches: 400 bytes at offset 8. */
+__device__ __forceinline__ void lds_pow2_fill(uint8_t* d, uint32_t off, uint32_t len)
+{
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
+  if (lane < 32) {
+    d[lane] = d[(int32_t)(lane & (off - 1)) - (int32_t)off];
+  }
+  wave::sync();
+  uint8_t* a = d + ((16u - ((uint32_t)(uintptr_t)d & 15u)) & 15u); /* first aligned block: inside d[0, 32) */
+  const wave::u32x4 q = *(const wave::u32x4*)a;
+  const uint32_t nblk = (uint32_t)(d + len - a) >> 4; /* whole blocks from a on */
+  for (uint32_t b = lane; b < nblk; b += 64) {
+    *(wave::u32x4*)(a + 16 * b) = q;
+  }
+  uint8_t* t = a + 16 * nblk;
+  if (t + lane < d + len) { /* the last partial block: its bytes are the block's first ones */
+    t[lane] = a[lane];
+  }
+  wave::sync();
+}
+
 /* Match copy inside the window with byte-serial semantics: d[i] = d[i - off].
  * Periods below 256 are a periodic fill; longer ones move 256 bytes per step (a step never reads what it writes). */
 __device__ __forceinline__ void lds_match_copy(uint8_t* d, uint32_t off, uint32_t len)
 {
   const uint32_t lane = (uint32_t)wave::fresh_lane_id();
+  if (off <= 16 && (off & (off - 1)) == 0 && len >= 32) {
+    lds_pow2_fill(d, off, len);
+    return;
+  }
   if (off < 256) {
     lds_periodic_fill(d, off, len);
     return;

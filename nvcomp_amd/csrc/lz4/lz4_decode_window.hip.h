@@ -46,6 +46,34 @@ __device__ __forceinline__ uint32_t token_delta(const lzw::InRing& r, uint32_t p
 }
 
 
+/* The rest of a length field whose bytes so far were all 255, from virtual position pos on: 64 bytes per step (a byte
+ * per lane, one ballot for the first byte that is not 255). Adds the bytes to `sum` (saturating: a corrupt stream may claim
+ * anything) and returns the position behind the field, or vend + 1 when the chunk ends first. Whole wave, uniform
+ * arguments. A chunk that is ONE literal run or ONE match -- incompressible data, zeros -- spells its length in 257 such
+ * bytes, and walking them one dependent LDS read at a time (twice: once for the chase, once for the parser) took a third
+ * of such a chunk's time. */
+__device__ __forceinline__ uint32_t scan_length_bytes(const lzw::InRing& r, uint32_t pos, uint32_t& sum)
+{
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
+  for (;;) {
+    const uint32_t p = pos + lane;
+    const bool inside = p < r.vend;
+    const uint32_t b = inside ? lzw::in_byte(r, p) : 0u;
+    const uint64_t stop = wave::ballot(b != 255u || !inside);
+    if (stop) {
+      const uint32_t n = wave::ctz64(stop);
+      if (pos + n >= r.vend) {
+        return r.vend + 1;
+      }
+      const uint32_t add = 255u * n + wave::read_lane(b, n);
+      sum = sum + add < 0x7fffff00u ? sum + add : 0x7fffff00u;
+      return pos + n + 1;
+    }
+    sum = sum + 255u * 64u < 0x7fffff00u ? sum + 255u * 64u : 0x7fffff00u;
+    pos += 64;
+  }
+}
+
 /* Scalar walk over one token with multi-byte length extensions. */
 __device__ __forceinline__ uint32_t chase_slow_next(const lzw::InRing& r, uint32_t q)
 {
@@ -54,16 +82,9 @@ __device__ __forceinline__ uint32_t chase_slow_next(const lzw::InRing& r, uint32
   uint32_t pos = q + 1;
   uint32_t lit = t >> 4;
   if (lit == 15) {
-    for (;;) {
-      if (pos >= vend) {
-        return vend + 1;
-      }
-      const uint32_t b = lzw::in_byte_uniform(r, pos);
-      ++pos;
-      lit += b;
-      if (b != 255) {
-        break;
-      }
+    pos = scan_length_bytes(r, pos, lit);
+    if (pos > vend) {
+      return vend + 1;
     }
   }
   if (lit >= vend - pos) {
@@ -71,15 +92,10 @@ __device__ __forceinline__ uint32_t chase_slow_next(const lzw::InRing& r, uint32
   }
   pos += lit + 2;
   if ((t & 15u) == 15u) {
-    for (;;) {
-      if (pos >= vend) {
-        return vend + 1;
-      }
-      const uint32_t b = lzw::in_byte_uniform(r, pos);
-      ++pos;
-      if (b != 255) {
-        break;
-      }
+    uint32_t ignored = 0;
+    pos = scan_length_bytes(r, pos, ignored);
+    if (pos > vend) {
+      return vend + 1;
     }
   }
   return pos;
@@ -113,65 +129,98 @@ struct SlowFn
   __device__ __forceinline__ uint32_t operator()(const lzw::InRing& r, uint32_t p) const { return chase_slow_next(r, p); }
 };
 
-/* Lane-parallel field decode of the sequence whose token is at virtual position p. */
+/* Lane-parallel field decode of the sequence whose token is at virtual position p (the general parser: any length, any
+ * residency, the chunk's last sequence). A lane reads the first byte of a length field itself; a field that goes on
+ * behind a 255 is finished by the whole wave, one such lane after the other (scan_length_bytes). */
 __device__ __forceinline__ void parse(const lzw::InRing& r, uint32_t p, bool active, lz::Seq& s, bool& bad)
 {
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t vend = r.vend;
   s.lit_src = 0;
   s.lit_len = 0;
   s.match_off = 0;
   s.match_len = 0;
   bad = false;
-  if (!active) {
-    return;
-  }
-  const uint32_t vend = r.vend;
-  const uint32_t t = lzw::in_byte(r, p);
-  uint32_t pos = p + 1;
-  uint32_t lit = t >> 4;
-  if (lit == 15) {
-    uint32_t b;
-    do {
+  uint32_t t = 0, pos = 0, lit = 0;
+  bool more = false;
+  if (active) {
+    t = lzw::in_byte(r, p);
+    pos = p + 1;
+    lit = t >> 4;
+    if (lit == 15) {
       if (pos >= vend) {
         bad = true;
-        return;
+      } else {
+        const uint32_t b = lzw::in_byte(r, pos++);
+        lit += b;
+        more = b == 255;
       }
-      b = lzw::in_byte(r, pos++);
-      lit += b;
-    } while (b == 255);
+    }
   }
-  if (lit > vend - pos) {
-    bad = true;
-    return;
+  for (uint64_t m = wave::ballot(more); m; m &= m - 1) {
+    const uint32_t j = wave::ctz64(m);
+    uint32_t sum = 0;
+    const uint32_t np = scan_length_bytes(r, wave::read_lane(pos, j), sum);
+    if (lane == j) {
+      bad = np > vend;
+      pos = np;
+      lit += sum;
+    }
   }
-  s.lit_src = pos;
-  s.lit_len = lit;
-  pos += lit;
-  if (pos == vend) {
-    return; /* last sequence: literals only */
-  }
-  if (vend - pos < 2) {
-    bad = true;
-    return;
-  }
-  s.match_off = lzw::in_byte(r, pos) | (lzw::in_byte(r, pos + 1) << 8);
-  pos += 2;
-  uint32_t mlen = t & 15u;
-  if (mlen == 15) {
-    uint32_t b;
-    do {
-      if (pos >= vend) {
-        bad = true;
-        return;
+  bool has_match = false;
+  uint32_t mlen = 0;
+  more = false;
+  if (active && !bad) {
+    if (lit > vend - pos) {
+      bad = true;
+    } else {
+      s.lit_src = pos;
+      s.lit_len = lit;
+      pos += lit;
+      if (pos != vend) { /* pos == vend: the last sequence, literals only */
+        if (vend - pos < 2) {
+          bad = true;
+        } else {
+          s.match_off = lzw::in_byte(r, pos) | (lzw::in_byte(r, pos + 1) << 8);
+          pos += 2;
+          has_match = true;
+          mlen = t & 15u;
+          if (mlen == 15) {
+            if (pos >= vend) {
+              bad = true;
+            } else {
+              const uint32_t b = lzw::in_byte(r, pos++);
+              mlen += b;
+              more = b == 255;
+            }
+          }
+        }
       }
-      b = lzw::in_byte(r, pos++);
-      mlen += b;
-    } while (b == 255);
+    }
   }
-  if (mlen > 0x40000000u || pos >= vend) { /* a token must follow every match */
-    bad = true;
-    return;
+  for (uint64_t m = wave::ballot(more); m; m &= m - 1) {
+    const uint32_t j = wave::ctz64(m);
+    uint32_t sum = 0;
+    const uint32_t np = scan_length_bytes(r, wave::read_lane(pos, j), sum);
+    if (lane == j) {
+      bad = np > vend;
+      pos = np;
+      mlen += sum;
+    }
   }
-  s.match_len = mlen + 4;
+  if (has_match && !bad) {
+    if (mlen > 0x40000000u || pos >= vend) { /* a token must follow every match */
+      bad = true;
+    } else {
+      s.match_len = mlen + 4;
+    }
+  }
+  if (bad) {
+    s.lit_src = 0;
+    s.lit_len = 0;
+    s.match_off = 0;
+    s.match_len = 0;
+  }
 }
 
 /* The n (< 8) stream bytes at virtual position p, which must be resident with p + 7 below the ring's end of residency:

@@ -26,6 +26,8 @@ CASES = {
     "snappy_mix": ("Snappy", "silesia_style", "snappy", 64, None),
     "mortgage": ("LZ4", "mortgage_col0_like", "fast", 64, 1024),
     "mortgage5k": ("LZ4", "mortgage_col0_like", "fast", 64, 314),
+    "mortgage_hc": ("LZ4", "mortgage_col0_like", "hc", 64, 1024),
+    "snappy_mortgage": ("Snappy", "mortgage_col0_like", "snappy", 64, 1024),
     "zeros": ("LZ4", "zeros", "fast", 16, 1024),
     "noise": ("LZ4", "noise", "fast", 16, 1024),
     "int32": ("LZ4", "int32", "fast", 32, 1024),
