@@ -27,6 +27,7 @@ int main(int argc, char** argv)
     int gpu = 0;
     nvcompType_t type = NVCOMP_TYPE_CHAR;
     nvcompBatchedCascadedOpts_t casc = nvcompBatchedCascadedDefaultOpts;
+    ChecksumPolicy policy = NoComputeNoVerify;
     for (int i = 2; i + 1 < argc; i += 2) {
       const std::string flag = argv[i], val = argv[i + 1];
       if (flag == "-f" || flag == "--filename") {
@@ -45,6 +46,9 @@ int main(int argc, char** argv)
         casc.num_deltas = std::atoi(val.c_str());
       } else if (flag == "-b" || flag == "--num-bps") {
         casc.use_bp = std::atoi(val.c_str());
+      } else if (flag == "--checksum") { /* extension: 0 NoComputeNoVerify (the reference's program), 1 ComputeAndNoVerify,
+                                            2 NoComputeAndVerifyIfPresent, 3 ComputeAndVerifyIfPresent, 4 ComputeAndVerify */
+        policy = (ChecksumPolicy)std::atoi(val.c_str());
       } else if (flag == "-m" || flag == "--memory") {
         /* accepted for compatibility; scratch is always managed by the manager */
       } else {
@@ -59,19 +63,19 @@ int main(int argc, char** argv)
     HIP_CHECK(hipStreamCreate(&stream));
     std::unique_ptr<nvcompManagerBase> manager;
     if (format == "lz4") {
-      manager.reset(new LZ4Manager(chunk, nvcompBatchedLZ4Opts_t{type}, stream, gpu, NoComputeNoVerify));
+      manager.reset(new LZ4Manager(chunk, nvcompBatchedLZ4Opts_t{type}, stream, gpu, policy));
     } else if (format == "snappy") {
-      manager.reset(new SnappyManager(chunk, nvcompBatchedSnappyDefaultOpts, stream, gpu, NoComputeNoVerify));
+      manager.reset(new SnappyManager(chunk, nvcompBatchedSnappyDefaultOpts, stream, gpu, policy));
     } else if (format == "cascaded") {
       casc.type = type;
-      manager.reset(new CascadedManager(chunk, casc, stream, gpu, NoComputeNoVerify));
+      manager.reset(new CascadedManager(chunk, casc, stream, gpu, policy));
     } else if (format == "bitcomp") {
       manager.reset(new BitcompManager(chunk, nvcompBatchedBitcompFormatOpts{0 /* algo--fixed for now */, type}, stream, gpu,
-                                       NoComputeNoVerify));
+                                       policy));
     } else if (format == "ans") {
-      manager.reset(new ANSManager(chunk, nvcompBatchedANSOpts_t{}, stream, gpu, NoComputeNoVerify));
+      manager.reset(new ANSManager(chunk, nvcompBatchedANSOpts_t{}, stream, gpu, policy));
     } else if (format == "deflate") {
-      manager.reset(new DeflateManager(chunk, nvcompBatchedDeflateDefaultOpts, stream, gpu, NoComputeNoVerify));
+      manager.reset(new DeflateManager(chunk, nvcompBatchedDeflateDefaultOpts, stream, gpu, policy));
     } else {
       throw std::runtime_error("ERROR: unsupported format \"" + format + "\" (this build: lz4, snappy, cascaded, bitcomp, ans, deflate)");
     }

@@ -25,6 +25,7 @@
 #include "nvcomp.hpp"
 
 #include "common/wave.h"
+#include "hlif/crc32.hip.h"
 
 namespace nvcomp {
 
@@ -208,17 +209,10 @@ __global__ void setup_decompress_kernel(
   }
 }
 
-/* CRC-32 (IEEE 802.3, reflected, as boost::crc_32_type / zlib): one thread per chunk. */
-__device__ uint32_t crc32_bytes(const uint8_t* p, size_t n, const uint32_t* table)
-{
-  uint32_t c = 0xffffffffu;
-  for (size_t i = 0; i < n; ++i) {
-    c = table[(c ^ p[i]) & 0xffu] ^ (c >> 8);
-  }
-  return c ^ 0xffffffffu;
-}
-
-__global__ void __launch_bounds__(256) crc_kernel(
+/* CRC-32 (IEEE 802.3, reflected, as boost::crc_32_type / zlib) of every chunk: one wavefront per chunk, four chunks per
+ * workgroup (hlif/crc32.hip.h). */
+constexpr unsigned kCrcWaves = 4;
+__global__ void __launch_bounds__(64 * kCrcWaves) crc_kernel(
     const void* const* ptrs, const size_t* sizes, size_t n, uint32_t* out, const uint32_t* expect, uint32_t* mismatch,
     const Header* header)
 {
@@ -226,23 +220,20 @@ __global__ void __launch_bounds__(256) crc_kernel(
   if (expect != nullptr && !(header->flags & kFlagChecksums)) {
     return;
   }
-  __shared__ uint32_t table[256];
-  {
-    uint32_t c = threadIdx.x;
-    for (int k = 0; k < 8; ++k) {
-      c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
-    }
-    table[threadIdx.x] = c;
-  }
+  __shared__ uint32_t tables[crc32w::kLdsDwords];
+  crc32w::load_tables(tables);
   __syncthreads();
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * kCrcWaves + wave::uniform(threadIdx.x >> 6);
   if (i < n) {
-    const uint32_t c = crc32_bytes((const uint8_t*)ptrs[i], sizes[i], table);
-    if (out != nullptr) {
-      out[i] = c;
-    }
-    if (expect != nullptr && expect[i] != c) {
-      atomicAdd(mismatch, 1u);
+    const uint8_t* p = wave::uniform_ptr((const uint8_t*)ptrs[i]);
+    const uint32_t c = crc32w::wave_crc32(p, (uint32_t)wave::uniform64(sizes[i]), tables);
+    if (wave::lane_id() == 0) {
+      if (out != nullptr) {
+        out[i] = c;
+      }
+      if (expect != nullptr && expect[i] != c) {
+        atomicAdd(mismatch, 1u);
+      }
     }
   }
 }
@@ -485,10 +476,10 @@ void BatchedManager::compress(const uint8_t* decomp_buffer, uint8_t* comp_buffer
     if (sums) {
       uint32_t* crc_u = (uint32_t*)(comp_buffer + sizeof(Header) + 8 * n + 8 * (n + 1));
       uint32_t* crc_c = crc_u + n;
-      const unsigned blocks = (unsigned)((n + 255) / 256);
-      hipLaunchKernelGGL(crc_kernel, dim3(blocks), dim3(256), 0, m.stream, (const void* const*)in_ptrs, in_sizes, n, crc_u,
+      const unsigned crc_blocks = (unsigned)((n + kCrcWaves - 1) / kCrcWaves);
+      hipLaunchKernelGGL(crc_kernel, dim3(crc_blocks), dim3(64 * kCrcWaves), 0, m.stream, (const void* const*)in_ptrs, in_sizes, n, crc_u,
                          (const uint32_t*)nullptr, (uint32_t*)nullptr, (const Header*)comp_buffer);
-      hipLaunchKernelGGL(crc_kernel, dim3(blocks), dim3(256), 0, m.stream, (const void* const*)out_ptrs, out_sizes, n, crc_c,
+      hipLaunchKernelGGL(crc_kernel, dim3(crc_blocks), dim3(64 * kCrcWaves), 0, m.stream, (const void* const*)out_ptrs, out_sizes, n, crc_c,
                          (const uint32_t*)nullptr, (uint32_t*)nullptr, (const Header*)comp_buffer);
     }
   }
@@ -562,13 +553,15 @@ void BatchedManager::decompress(uint8_t* decomp_buffer, const uint8_t* comp_buff
   const uint32_t* crc_c = crc_u + n;
   if (verify) {
     hip_check(hipMemsetAsync(mismatch, 0, 4, m.stream), "hipMemsetAsync");
-    hipLaunchKernelGGL(crc_kernel, dim3(blocks), dim3(256), 0, m.stream, (const void* const*)comp_ptrs, comp_sizes, n,
+    hipLaunchKernelGGL(crc_kernel, dim3((unsigned)((n + kCrcWaves - 1) / kCrcWaves)), dim3(64 * kCrcWaves), 0, m.stream,
+                       (const void* const*)comp_ptrs, comp_sizes, n,
                        (uint32_t*)nullptr, crc_c, mismatch, (const Header*)comp_buffer);
   }
   nv_check(m.decompress_async(comp_ptrs, comp_sizes, out_caps, actual, n, m.temp.ptr, tb, out_ptrs, statuses),
            "DecompressAsync");
   if (verify) {
-    hipLaunchKernelGGL(crc_kernel, dim3(blocks), dim3(256), 0, m.stream, (const void* const*)out_ptrs, out_caps, n,
+    hipLaunchKernelGGL(crc_kernel, dim3((unsigned)((n + kCrcWaves - 1) / kCrcWaves)), dim3(64 * kCrcWaves), 0, m.stream,
+                       (const void* const*)out_ptrs, out_caps, n,
                        (uint32_t*)nullptr, crc_u, mismatch, (const Header*)comp_buffer);
   }
   hipLaunchKernelGGL(status_kernel, dim3(1), dim3(256), 0, m.stream, statuses, actual, out_caps, n,
