@@ -163,29 +163,33 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lz4_decompress_size_kerne
 /* STRIDE: the element size the caller declared (nvcompBatchedLZ4Opts_t.data_type): matches are searched at element
  * boundaries only, a step covers 64 elements (common/lz_match.hip.h). */
 template <uint32_t STRIDE>
-__global__ void __launch_bounds__(64 * kEncWaves, NVCOMP_LZM_WAVES_PER_SIMD) lz4_compress_kernel(
-    const void* const* __restrict__ in_ptrs,
-    const size_t* __restrict__ in_bytes,
-    size_t max_chunk_bytes,
-    size_t batch_size,
-    void* const* __restrict__ out_ptrs,
-    size_t* out_bytes)
+__global__ void __launch_bounds__(64 * kEncWaves, NVCOMP_LZM_WAVES_PER_SIMD) lz4_compress_kernel(const lzl::CompressLaunch launch)
 {
   __shared__ uint16_t tables[kEncWaves][lzm::kTableU16];
-  __shared__ __attribute__((aligned(8))) uint8_t images[kEncWaves][lzm::kStageBytes];
+  __shared__ __attribute__((aligned(8))) uint8_t images[kEncWaves][lzm::kImageBytes];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
-  const size_t chunk = (size_t)blockIdx.x * kEncWaves + w;
-  if (chunk >= batch_size) {
-    return;
-  }
-  const uint8_t* src = wave::uniform_ptr((const uint8_t*)in_ptrs[chunk]);
-  uint8_t* dst = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
-  const size_t n64 = wave::uniform64(in_bytes[chunk]);
-  /* a chunk larger than the caller declared would overrun the output slot sized from GetMaxOutputChunkSize: it is
-   * not compressed, its size reads 0 */
-  const uint32_t produced = n64 > max_chunk_bytes ? 0u : lz4::encode_chunk<STRIDE>(src, (uint32_t)n64, dst, tables[w], images[w]);
-  if (wave::lane_id() == 0) {
-    out_bytes[chunk] = produced;
+  size_t chunk = (size_t)blockIdx.x * kEncWaves + w;
+  /* persistent waves, as in the decoders (common/lz_launch.hip.h): chunks of a batch compress at very different speeds */
+  for (;;) {
+    const auto* a = wave::kernel_args(launch);
+    if (chunk >= a->batch_size) {
+      break;
+    }
+    const uint8_t* src = wave::uniform_ptr((const uint8_t*)a->in_ptrs[chunk]);
+    uint8_t* dst = wave::uniform_ptr((uint8_t*)a->out_ptrs[chunk]);
+    const size_t n64 = wave::uniform64(a->in_bytes[chunk]);
+    /* a chunk larger than the caller declared would overrun the output slot sized from GetMaxOutputChunkSize: it is
+     * not compressed, its size reads 0 */
+    const uint32_t produced = n64 > a->max_chunk_bytes ? 0u : lz4::encode_chunk<STRIDE>(src, (uint32_t)n64, dst, tables[w], images[w]);
+    a = wave::kernel_args(launch);
+    if (wave::lane_id() == 0) {
+      a->out_bytes[chunk] = produced;
+    }
+    uint32_t* ticket = a->ticket;
+    if (ticket == nullptr) {
+      break;
+    }
+    chunk = lzl::next_chunk(ticket, a->first_dynamic);
   }
 }
 
@@ -321,7 +325,7 @@ nvcompStatus_t nvcompBatchedLZ4GetDecompressSizeAsync(
 }
 
 nvcompStatus_t nvcompBatchedLZ4CompressGetTempSize(
-    size_t /*batch_size*/, size_t max_uncompressed_chunk_bytes, nvcompBatchedLZ4Opts_t format_opts, size_t* temp_bytes)
+    size_t batch_size, size_t max_uncompressed_chunk_bytes, nvcompBatchedLZ4Opts_t format_opts, size_t* temp_bytes)
 {
   if (temp_bytes == nullptr || !lz4_type_ok(format_opts.data_type)) {
     return nvcompErrorInvalidValue;
@@ -329,7 +333,8 @@ nvcompStatus_t nvcompBatchedLZ4CompressGetTempSize(
   if (max_uncompressed_chunk_bytes > nvcompLZ4CompressionMaxAllowedChunkSize) {
     return nvcompErrorChunkSizeTooLarge;
   }
-  *temp_bytes = 0; /* the per-chunk hash tables live in LDS */
+  /* the per-chunk hash tables live in LDS; the scratch is the persistent waves' ticket counter (common/lz_launch.hip.h) */
+  *temp_bytes = batch_size != 0 ? lzl::kTicketBytes : 0;
   return nvcompSuccess;
 }
 
@@ -361,8 +366,8 @@ nvcompStatus_t nvcompBatchedLZ4CompressAsync(
     const size_t* device_uncompressed_bytes,
     size_t max_uncompressed_chunk_bytes,
     size_t batch_size,
-    void* /*device_temp_ptr*/,
-    size_t /*temp_bytes*/,
+    void* device_temp_ptr,
+    size_t temp_bytes,
     void* const* device_compressed_ptrs,
     size_t* device_compressed_bytes,
     nvcompBatchedLZ4Opts_t format_opts,
@@ -384,10 +389,24 @@ nvcompStatus_t nvcompBatchedLZ4CompressAsync(
     return nvcompErrorInvalidValue;
   }
   clear_stale_error();
-#define NVCOMP_LZ4_COMPRESS(STRIDE)                                                                                  \
-  hipLaunchKernelGGL((lz4_compress_kernel<STRIDE>), dim3((unsigned)((batch_size + kEncWaves - 1) / kEncWaves)), dim3(64 * kEncWaves), 0, stream,   \
-                     device_uncompressed_ptrs, device_uncompressed_bytes, max_uncompressed_chunk_bytes, batch_size,     \
-                     device_compressed_ptrs, device_compressed_bytes)
+  /* persistent waves when the caller's temp buffer holds the ticket counter: as many workgroups as stay resident */
+#define NVCOMP_LZ4_COMPRESS(STRIDE)                                                                                       \
+  do {                                                                                                                    \
+    unsigned groups = (unsigned)((batch_size + kEncWaves - 1) / kEncWaves);                                               \
+    uint32_t* ticket = nullptr;                                                                                           \
+    if (NVCOMP_LZ_PERSISTENT && device_temp_ptr != nullptr && temp_bytes >= sizeof(uint32_t)                              \
+        && ((uintptr_t)device_temp_ptr & 3u) == 0) {                                                                      \
+      static const unsigned fit = lzl::resident_workgroups(lz4_compress_kernel<STRIDE>, 64 * kEncWaves, 0);               \
+      if (fit != 0 && fit < groups && hipMemsetAsync(device_temp_ptr, 0, sizeof(uint32_t), stream) == hipSuccess) {       \
+        ticket = (uint32_t*)device_temp_ptr;                                                                              \
+        groups = fit;                                                                                                     \
+      }                                                                                                                   \
+    }                                                                                                                     \
+    const lzl::CompressLaunch launch = {device_uncompressed_ptrs, device_uncompressed_bytes, max_uncompressed_chunk_bytes, \
+                                        batch_size, device_compressed_ptrs, device_compressed_bytes, ticket,             \
+                                        (size_t)groups * kEncWaves};                                                      \
+    hipLaunchKernelGGL((lz4_compress_kernel<STRIDE>), dim3(groups), dim3(64 * kEncWaves), 0, stream, launch);             \
+  } while (0)
   switch (format_opts.data_type) {
   case NVCOMP_TYPE_SHORT:
   case NVCOMP_TYPE_USHORT: NVCOMP_LZ4_COMPRESS(2); break;

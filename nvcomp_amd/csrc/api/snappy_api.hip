@@ -146,29 +146,33 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) snappy_decompress_size_ke
   }
 }
 
-__global__ void __launch_bounds__(64 * kEncWaves, NVCOMP_LZM_WAVES_PER_SIMD) snappy_compress_kernel(
-    const void* const* __restrict__ in_ptrs,
-    const size_t* __restrict__ in_bytes,
-    size_t max_chunk_bytes,
-    size_t batch_size,
-    void* const* __restrict__ out_ptrs,
-    size_t* out_bytes)
+__global__ void __launch_bounds__(64 * kEncWaves, NVCOMP_LZM_WAVES_PER_SIMD) snappy_compress_kernel(const lzl::CompressLaunch launch)
 {
   __shared__ uint16_t tables[kEncWaves][lzm::kTableU16];
-  __shared__ __attribute__((aligned(8))) uint8_t images[kEncWaves][lzm::kStageBytes];
+  __shared__ __attribute__((aligned(8))) uint8_t images[kEncWaves][lzm::kImageBytes];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
-  const size_t chunk = (size_t)blockIdx.x * kEncWaves + w;
-  if (chunk >= batch_size) {
-    return;
-  }
-  const uint8_t* src = wave::uniform_ptr((const uint8_t*)in_ptrs[chunk]);
-  uint8_t* dst = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
-  const size_t n64 = wave::uniform64(in_bytes[chunk]);
-  /* a chunk larger than the caller declared would overrun the output slot sized from GetMaxOutputChunkSize: it is
-   * not compressed, its size reads 0 */
-  const uint32_t produced = n64 > max_chunk_bytes ? 0u : snappy::encode_chunk(src, (uint32_t)n64, dst, tables[w], images[w]);
-  if (wave::lane_id() == 0) {
-    out_bytes[chunk] = produced;
+  size_t chunk = (size_t)blockIdx.x * kEncWaves + w;
+  /* persistent waves, as in the decoders (common/lz_launch.hip.h): chunks of a batch compress at very different speeds */
+  for (;;) {
+    const auto* a = wave::kernel_args(launch);
+    if (chunk >= a->batch_size) {
+      break;
+    }
+    const uint8_t* src = wave::uniform_ptr((const uint8_t*)a->in_ptrs[chunk]);
+    uint8_t* dst = wave::uniform_ptr((uint8_t*)a->out_ptrs[chunk]);
+    const size_t n64 = wave::uniform64(a->in_bytes[chunk]);
+    /* a chunk larger than the caller declared would overrun the output slot sized from GetMaxOutputChunkSize: it is
+     * not compressed, its size reads 0 */
+    const uint32_t produced = n64 > a->max_chunk_bytes ? 0u : snappy::encode_chunk(src, (uint32_t)n64, dst, tables[w], images[w]);
+    a = wave::kernel_args(launch);
+    if (wave::lane_id() == 0) {
+      a->out_bytes[chunk] = produced;
+    }
+    uint32_t* ticket = a->ticket;
+    if (ticket == nullptr) {
+      break;
+    }
+    chunk = lzl::next_chunk(ticket, a->first_dynamic);
   }
 }
 
@@ -296,7 +300,7 @@ nvcompStatus_t nvcompBatchedSnappyGetDecompressSizeAsync(
 }
 
 nvcompStatus_t nvcompBatchedSnappyCompressGetTempSize(
-    size_t /*batch_size*/, size_t max_uncompressed_chunk_bytes, nvcompBatchedSnappyOpts_t format_opts, size_t* temp_bytes)
+    size_t batch_size, size_t max_uncompressed_chunk_bytes, nvcompBatchedSnappyOpts_t format_opts, size_t* temp_bytes)
 {
   if (temp_bytes == nullptr || !snappy_opts_ok(format_opts)) {
     return nvcompErrorInvalidValue;
@@ -304,7 +308,8 @@ nvcompStatus_t nvcompBatchedSnappyCompressGetTempSize(
   if (max_uncompressed_chunk_bytes > nvcompSnappyCompressionMaxAllowedChunkSize) {
     return nvcompErrorChunkSizeTooLarge;
   }
-  *temp_bytes = 0; /* the per-chunk hash tables live in LDS */
+  /* the per-chunk hash tables live in LDS; the scratch is the persistent waves' ticket counter (common/lz_launch.hip.h) */
+  *temp_bytes = batch_size != 0 ? lzl::kTicketBytes : 0;
   return nvcompSuccess;
 }
 
@@ -337,8 +342,8 @@ nvcompStatus_t nvcompBatchedSnappyCompressAsync(
     const size_t* device_uncompressed_bytes,
     size_t max_uncompressed_chunk_bytes,
     size_t batch_size,
-    void* /*device_temp_ptr*/,
-    size_t /*temp_bytes*/,
+    void* device_temp_ptr,
+    size_t temp_bytes,
     void* const* device_compressed_ptrs,
     size_t* device_compressed_bytes,
     nvcompBatchedSnappyOpts_t format_opts,
@@ -360,9 +365,20 @@ nvcompStatus_t nvcompBatchedSnappyCompressAsync(
     return nvcompErrorInvalidValue;
   }
   clear_stale_error();
-  hipLaunchKernelGGL(snappy_compress_kernel, dim3((unsigned)((batch_size + kEncWaves - 1) / kEncWaves)), dim3(64 * kEncWaves), 0, stream,
-                     device_uncompressed_ptrs, device_uncompressed_bytes, max_uncompressed_chunk_bytes, batch_size,
-                     device_compressed_ptrs, device_compressed_bytes);
+  /* persistent waves when the caller's temp buffer holds the ticket counter: as many workgroups as stay resident */
+  unsigned groups = (unsigned)((batch_size + kEncWaves - 1) / kEncWaves);
+  uint32_t* ticket = nullptr;
+  if (NVCOMP_LZ_PERSISTENT && device_temp_ptr != nullptr && temp_bytes >= sizeof(uint32_t) && ((uintptr_t)device_temp_ptr & 3u) == 0) {
+    static const unsigned fit = lzl::resident_workgroups(snappy_compress_kernel, 64 * kEncWaves, 0);
+    if (fit != 0 && fit < groups && hipMemsetAsync(device_temp_ptr, 0, sizeof(uint32_t), stream) == hipSuccess) {
+      ticket = (uint32_t*)device_temp_ptr;
+      groups = fit;
+    }
+  }
+  const lzl::CompressLaunch launch = {device_uncompressed_ptrs, device_uncompressed_bytes, max_uncompressed_chunk_bytes,
+                                      batch_size, device_compressed_ptrs, device_compressed_bytes, ticket,
+                                      (size_t)groups * kEncWaves};
+  hipLaunchKernelGGL(snappy_compress_kernel, dim3(groups), dim3(64 * kEncWaves), 0, stream, launch);
   return launch_status();
 }
 

@@ -62,6 +62,19 @@ struct Launch
   size_t first_dynamic;
 };
 
+/* The same for the compressors: the caller's arrays of one nvcompBatched<Fmt>CompressAsync call. */
+struct CompressLaunch
+{
+  const void* const* in_ptrs;
+  const size_t* in_bytes;
+  size_t max_chunk_bytes;
+  size_t batch_size;
+  void* const* out_ptrs;
+  size_t* out_bytes;
+  uint32_t* ticket;
+  size_t first_dynamic;
+};
+
 /* The wave's next chunk: `first_dynamic` + a ticket (lane 0 draws it, the wave shares it). */
 __device__ __forceinline__ size_t next_chunk(uint32_t* ticket, size_t first_dynamic)
 {
@@ -75,7 +88,7 @@ __device__ __forceinline__ size_t next_chunk(uint32_t* ticket, size_t first_dyna
 /* Workgroups of `kernel` (block threads, static LDS) the current device keeps resident at once; 0 when the runtime
  * cannot tell (the launch is then static). Asked once per kernel and device. */
 template <class Kernel>
-inline unsigned resident_workgroups(Kernel kernel, unsigned block_threads)
+inline unsigned resident_workgroups(Kernel kernel, unsigned block_threads, int max_per_cu = NVCOMP_LZ_MAX_WG_PER_CU)
 {
   int dev = 0, cus = 0, per_cu = 0;
   if (hipGetDevice(&dev) != hipSuccess
@@ -84,8 +97,8 @@ inline unsigned resident_workgroups(Kernel kernel, unsigned block_threads)
     (void)hipGetLastError();
     return 0;
   }
-  if (NVCOMP_LZ_MAX_WG_PER_CU > 0 && per_cu > NVCOMP_LZ_MAX_WG_PER_CU) {
-    per_cu = NVCOMP_LZ_MAX_WG_PER_CU;
+  if (max_per_cu > 0 && per_cu > max_per_cu) {
+    per_cu = max_per_cu;
   }
   return cus > 0 && per_cu > 0 ? (unsigned)cus * (unsigned)per_cu : 0u;
 }

@@ -50,6 +50,15 @@ namespace lzm {
 #ifndef NVCOMP_LZM_STAGE
 #define NVCOMP_LZM_STAGE 1
 #endif
+/* ---- the output staging (NVCOMP_LZM_STAGE_OUT, A/B build) ----
+ * The sequences of a window composed in LDS and written with ONE coalesced store of consecutive dwords (up to three bytes
+ * wait for the next window) instead of five or six scattered store instructions. Built and measured in round 3
+ * (profiles/r03_compress_ab.jsonl): 115.9 against 117.9 GB/s on the mix, 111.3 against 113.7 for Snappy -- the scattered
+ * stores of ten lanes are not what the address unit is busy with (the candidate loads of 64 lanes are), and the 256 bytes
+ * come out of the hash table. Off. */
+#ifndef NVCOMP_LZM_STAGE_OUT
+#define NVCOMP_LZM_STAGE_OUT 0
+#endif
 #ifndef NVCOMP_LZM_TAGS
 #define NVCOMP_LZM_TAGS 0
 #endif
@@ -58,11 +67,12 @@ namespace lzm {
 #endif
 constexpr uint32_t kHashBits = NVCOMP_LZM_HASH_BITS;
 /* Entries of the per-wave table (any multiple of 128). With the input image beside it a wave has 8 KiB of LDS at
- * 5 waves/SIMD (4-wave workgroups, 160 KB per CU): 3456 two-byte entries + 1072 bytes of image. */
+ * 5 waves/SIMD (4-wave workgroups, 160 KB per CU): 3456 two-byte entries + 1072 bytes of image (3328 when the A/B output
+ * staging takes 256 bytes). */
 #ifdef NVCOMP_LZM_HASH_ENTRIES
 constexpr uint32_t kHashSize = NVCOMP_LZM_HASH_ENTRIES;
 #elif NVCOMP_LZM_STAGE
-constexpr uint32_t kHashSize = 3456;
+constexpr uint32_t kHashSize = NVCOMP_LZM_STAGE_OUT ? 3328 : 3456;
 #else
 constexpr uint32_t kHashSize = 1u << kHashBits;
 #endif
@@ -71,7 +81,14 @@ static_assert(kHashSize % 128 == 0 && kHashSize <= 65536, "the table is cleared 
  * NVCOMP_LZM_TAGS build. */
 constexpr uint32_t kTableU16 = kHashSize + (NVCOMP_LZM_TAGS ? kHashSize / 2 : 0);
 constexpr uint32_t kMinMatch = 4;
-constexpr uint32_t kLaneCap = 32; /* per-lane match measurement: the word + 28 bytes, compared in registers */
+/* The candidate side comes with TWO 16-byte loads per lane (8 bytes before the candidate and 24 from it on) instead of
+ * three (32 from it on): a lane's load is a lookup of its own in the CU's address unit whatever its width, and the
+ * candidate loads were 40 % of a window's lookups in a kernel that is bound by exactly that unit. The per-lane
+ * measurement then stops at 24 bytes; longer matches are finished by the whole wave, as before. */
+#ifndef NVCOMP_LZM_CAND32
+#define NVCOMP_LZM_CAND32 1
+#endif
+constexpr uint32_t kLaneCap = NVCOMP_LZM_CAND32 ? 24 : 32; /* per-lane match measurement, compared in registers */
 /* Hit lanes in a window from which its first match is probed cooperatively. Runs and periodic columns hit in (nearly)
  * every lane; text hits in about half of them, and at 32 the probe ran on 40 % of its windows to find nothing
  * (60 against 32: +4 % on the mix, +8 % on the int32 column, same ratio). */
@@ -141,17 +158,34 @@ __device__ __forceinline__ uint32_t tag4(uint32_t v)
   }
 }
 
-/* Wave-cooperative extension of a match known to be at least `have` bytes long. */
+/* Wave-cooperative extension of a match known to be at least `have` bytes long: 64 bytes per step, compared as 16
+ * dwords by 16 lanes (a lane's load is a lookup of its own in the CU's address unit, whatever its width: bytes by all 64
+ * lanes cost four times as many). The last one to three bytes in front of match_end are compared singly. */
 __device__ __forceinline__ uint32_t extend_match(
     const uint8_t* __restrict__ src, uint32_t mpos, uint32_t mcand, uint32_t have, uint32_t match_end)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   uint32_t mlen = have;
   for (;;) {
-    const uint32_t p = mpos + mlen + lane;
-    const bool same = p < match_end && src[p] == src[mcand + mlen + lane];
-    const uint64_t diff = ~wave::ballot(same);
-    if (diff != 0) {
+    const uint32_t p = mpos + mlen + 4 * lane;
+    const bool mine = lane < 16;
+    const bool whole = mine && p + 4 <= match_end;
+    uint32_t x = 0;
+    if (whole) {
+      x = wave::gload_u32(src + p) ^ wave::gload_u32(src + mcand + mlen + 4 * lane);
+    }
+    const uint64_t stop = wave::ballot(mine && (x != 0 || !whole));
+    if (stop != 0) {
+      const uint32_t f = wave::ctz64(stop);
+      const uint32_t xf = wave::read_lane(x, f);
+      mlen += 4 * f;
+      if (xf != 0) {
+        return mlen + ((uint32_t)__builtin_ctz(xf) >> 3);
+      }
+      /* fewer than four bytes are left in front of match_end */
+      const uint32_t q = mpos + mlen + lane;
+      const bool same = q < match_end && wave::gload_u8(src + q) == wave::gload_u8(src + mcand + mlen + lane);
+      const uint64_t diff = ~wave::ballot(same);
       return mlen + wave::ctz64(diff);
     }
     mlen += 64;
@@ -189,6 +223,8 @@ constexpr uint32_t kStageBlock = 512;
 constexpr uint32_t kStageMirror = 48;
 constexpr uint32_t kStageBytes = NVCOMP_LZM_STAGE ? 2 * kStageBlock + kStageMirror : 8;
 constexpr uint32_t kNoBlock = ~0u;
+constexpr uint32_t kOutStage = NVCOMP_LZM_STAGE_OUT ? 256 : 0;
+constexpr uint32_t kImageBytes = kStageBytes + kOutStage; /* what a wave's `image` argument points at */
 
 __device__ __forceinline__ uint64_t stage_fetch(const uint8_t* __restrict__ src, uint32_t n, uint32_t blk)
 {
@@ -308,7 +344,11 @@ __device__ __forceinline__ Probe probe_fast(
     const uint8_t* cp = src + p.cand - (cback ? kBackMax : 0u);
     const wave::u32x4 a = wave::gload_u32x4(cp);
     const wave::u32x4 b = wave::gload_u32x4(cp + 16);
+#if NVCOMP_LZM_CAND32
+    const uint64_t d = ~(((uint64_t)me.fwd[7] << 32) | me.fwd[6]); /* not fetched: bytes 24..31 compare unequal */
+#else
     const uint64_t d = wave::gload_u64(cp + 32);
+#endif
     c.pre[0] = cback ? a.x : 0u;
     c.pre[1] = cback ? a.y : 0u;
     c.fwd[0] = cback ? a.z : a.x;
@@ -337,6 +377,7 @@ __device__ __forceinline__ Probe probe_fast(
     xv = x[i] ? x[i] : xv;
   }
   uint32_t mlen = 4 * idx + (xv ? (uint32_t)__builtin_ctz(xv) >> 3 : 0u);
+  mlen = mlen < kLaneCap ? mlen : kLaneCap; /* a candidate in the first 8 bytes of the chunk brought 32 */
   const uint32_t room = match_end - pos; /* >= 4 for an eligible position */
   mlen = mlen < room ? mlen : room;
   p.mlen = p.found ? mlen : 0;
@@ -419,6 +460,15 @@ __device__ __forceinline__ uint32_t encode_chunk(
 
   uint32_t op = 0;
   uint32_t anchor = 0;
+  /* the output staging: dst[op - fill, op) is still in stage_out[0, fill) (fill < 4 between windows) */
+  uint8_t* stage_out = image + kStageBytes;
+  uint32_t fill = 0;
+  auto flush_staged = [&]() {
+    if (lane < fill) {
+      wave::gstore_u8(dst + op - fill + lane, stage_out[lane]);
+    }
+    fill = 0;
+  };
   LZM_PROF_DECL;
   if (any_match) {
     uint32_t ip = 0;
@@ -543,6 +593,7 @@ __device__ __forceinline__ uint32_t encode_chunk(
           if constexpr (Emitter::kStream) {
             Emitter::one(*sink, src + anchor, mpos - anchor, mpos - mcand, len0);
           } else {
+            flush_staged();
             op += Emitter::match(dst + op, src + anchor, mpos - anchor, mpos - mcand, len0);
           }
           const uint32_t next = mpos + len0;
@@ -600,17 +651,19 @@ __device__ __forceinline__ uint32_t encode_chunk(
         const uint32_t size = sel ? Emitter::seq_size(lit_len, my_len, offset) : 0;
         const uint32_t incl = wave::scan_add_inclusive(size);
         const uint32_t total = wave::read_lane(incl, 63);
-        uint8_t* my_dst = dst + op + incl - size;
         const bool small = sel && Emitter::is_small(lit_len, my_len);
+        uint64_t big = wave::ballot(sel && !small);
         LZM_T(5); /* sizes + scan */
-        if (small) {
-          Emitter::emit_small_header(my_dst, lit_len, offset, my_len);
-        }
-        LZM_T(6); /* headers */
-        /* literal runs of the small sequences. Up to 8 bytes (nearly all of them on text) are the bytes right before
-         * the lane's position, which a fast window holds in registers: no load at all. Longer runs are read back,
-         * four dwords in flight per round (a load-store pair per step costs a memory round trip per step). */
-        {
+        /* the small sequences of the window, written by their own lanes at base + (their offset in the window's output) */
+        auto emit_small = [&](uint8_t* base) {
+          uint8_t* my_dst = base + incl - size;
+          if (small) {
+            Emitter::emit_small_header(my_dst, lit_len, offset, my_len);
+          }
+          LZM_T(6); /* headers */
+          /* literal runs of the small sequences. Up to 8 bytes (nearly all of them on text) are the bytes right before
+           * the lane's position, which a fast window holds in registers: no load at all. Longer runs are read back,
+           * four dwords in flight per round (a load-store pair per step costs a memory round trip per step). */
           const uint32_t run = sel ? pos - prev_end : 0; /* before the match grew backwards: the run ends at pos */
           uint8_t* ld = my_dst + Emitter::lit_offset(lit_len);
           const bool from_regs = small && fast && run <= 8 && pos >= kBackMax;
@@ -632,42 +685,62 @@ __device__ __forceinline__ uint32_t encode_chunk(
           const bool from_mem = small && !from_regs && lit_len != 0;
           const uint8_t* ls = src + prev_end;
           const bool lit4 = from_mem && lit_len >= 4;
-          for (uint32_t base = 0; wave::ballot(lit4 && lit_len > base) != 0; base += 16) {
-            if (lit4 && lit_len > base) {
+          for (uint32_t base4 = 0; wave::ballot(lit4 && lit_len > base4) != 0; base4 += 16) {
+            if (lit4 && lit_len > base4) {
               const uint32_t lastoff = lit_len - 4;
               uint32_t v[4];
-  #pragma unroll
+#pragma unroll
               for (uint32_t i = 0; i < 4; ++i) {
-                const uint32_t o = base + 4 * i < lastoff ? base + 4 * i : lastoff;
+                const uint32_t o = base4 + 4 * i < lastoff ? base4 + 4 * i : lastoff;
                 v[i] = wave::gload_u32(ls + o);
               }
-  #pragma unroll
+#pragma unroll
               for (uint32_t i = 0; i < 4; ++i) {
-                const uint32_t o = base + 4 * i < lastoff ? base + 4 * i : lastoff;
+                const uint32_t o = base4 + 4 * i < lastoff ? base4 + 4 * i : lastoff;
                 lz::st_u32(ld + o, v[i]);
               }
             }
           }
           if (from_mem && lit_len < 4) {
-            ld[0] = ls[0];
+            ld[0] = (uint8_t)wave::gload_u8(ls);
             if (lit_len > 1) {
-              ld[1] = ls[1];
+              ld[1] = (uint8_t)wave::gload_u8(ls + 1);
             }
             if (lit_len > 2) {
-              ld[2] = ls[2];
+              ld[2] = (uint8_t)wave::gload_u8(ls + 2);
             }
           }
-        }
-        LZM_T(7); /* literals */
-        /* the few sequences a single lane cannot write: long literal run (first of the step,
-         * after match-less windows) or long match (last of the step) */
-        uint64_t big = wave::ballot(sel && !small);
-        while (big) {
-          const uint32_t j = wave::ctz64(big);
-          big &= big - 1;
-          const uint32_t jdst = op + wave::read_lane(incl - size, j);
-          const uint32_t jlit = wave::read_lane(prev_end, j);
-          Emitter::match(dst + jdst, src + jlit, wave::read_lane(lit_len, j), wave::read_lane(offset, j), wave::read_lane(my_len, j));
+          LZM_T(7); /* literals */
+        };
+        if (NVCOMP_LZM_STAGE_OUT && big == 0 && fill + total <= kOutStage) {
+          /* composed in LDS behind the bytes still staged, then out with one coalesced store of whole dwords */
+          emit_small(stage_out + fill);
+          wave::sync();
+          const uint32_t bytes = fill + total;
+          const uint32_t nd = bytes >> 2;
+          uint8_t* g = dst + op - fill;
+          for (uint32_t i = lane; i < nd; i += 64) {
+            wave::gstore_u32(g + 4 * i, *(const uint32_t*)(stage_out + 4 * i));
+          }
+          fill = bytes & 3u;
+          if (fill != 0) {
+            const uint32_t carry = *(const uint32_t*)(stage_out + 4 * nd); /* every lane reads and writes the same dword */
+            wave::sync();
+            *(uint32_t*)stage_out = carry;
+          }
+          wave::sync();
+        } else {
+          flush_staged();
+          emit_small(dst + op);
+          /* the few sequences a single lane cannot write: long literal run (first of the step,
+           * after match-less windows) or long match (last of the step) */
+          while (big) {
+            const uint32_t j = wave::ctz64(big);
+            big &= big - 1;
+            const uint32_t jdst = op + wave::read_lane(incl - size, j);
+            const uint32_t jlit = wave::read_lane(prev_end, j);
+            Emitter::match(dst + jdst, src + jlit, wave::read_lane(lit_len, j), wave::read_lane(offset, j), wave::read_lane(my_len, j));
+          }
         }
         op += total;
       }
@@ -687,6 +760,7 @@ __device__ __forceinline__ uint32_t encode_chunk(
   if constexpr (Emitter::kStream) {
     Emitter::one(*sink, src + anchor, n - anchor, 0, 0);
   } else {
+    flush_staged();
     op += Emitter::tail(dst + op, src + anchor, n - anchor);
   }
   LZM_T(9);

@@ -1,16 +1,18 @@
 #!/bin/bash
-# compress-side check: round trips (ratio, compress / decompress GB/s) of the LZ codecs on several datasets
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-OUT=gpurun_out/${1:-c}
-mkdir -p "$OUT"; rm -f "$OUT/roundtrip.jsonl"
-timeout 600 python -m pytest tests -m gpu -q --timeout 600 -x -k "encode or snappy or lz4_decode" > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc=$?"; tail -2 "$OUT/pytest_gpu.log"
-for algo in lz4 snappy; do for ds in silesia_style text table int32 zeros noise; do
-  timeout 200 python scripts/bench_roundtrip.py --algo $algo --dataset $ds --unique-mib 32 --mib 1024 >> "$OUT/roundtrip.jsonl" 2>> "$OUT/roundtrip.err"
-done; done
-python -c "
-import json
-for l in open('$OUT/roundtrip.jsonl'):
-    r=json.loads(l); print(r['algo'], r['dataset'], 'ratio', r['ratio'], 'comp', r['compress_GBps'], 'decomp', r['decompress_GBps'])"
-tail -3 "$OUT/roundtrip.err"
+OUT=gpurun_out/${1:-comp}
+mkdir -p "$OUT"
+timeout 300 python -m pytest tests/test_lz4_encode.py tests/test_snappy.py -m gpu -x -q --timeout 300 2>&1 | tail -2
+timeout 900 python scripts/ab_compress.py --prof --cases ${CASES:-mix,snappy_mix,int32,text} --out "$OUT/abc.jsonl" 2> "$OUT/abc.err" | python -c "
+import sys, json, collections
+rows = collections.OrderedDict()
+for l in sys.stdin:
+    r = json.loads(l)
+    rows.setdefault(r['case'], []).append(r)
+    if 'phase_share' in r: print(r['case'], r['lib'], r['phase_share'])
+for c, rs in rows.items():
+    print(c, ' '.join('%s=%s@%s%s' % (r['lib'], r.get('GBps', 'ERR'), r.get('ratio'), '' if r.get('ok', False) else '!') for r in rs))
+"
+tail -3 "$OUT/abc.err"
