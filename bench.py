@@ -59,7 +59,8 @@ def parse_args():
                    help="CPU compressor making the inputs: liblz4 HC-12 / liblz4 default / oracle port")
     p.add_argument("--unchecked", action="store_true", help="statuses=NULL fast path (reported separately)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-extras", action="store_true", help="skip the GPU compress leg (ratio / compress GB/s)")
+    p.add_argument("--no-extras", action="store_true", help="skip the GPU compress leg (ratio / compress GB/s) and the riders")
+    p.add_argument("--no-riders", action="store_true", help="skip the other codecs' lines in extras (the compress leg stays)")
     p.add_argument("--allgather", action="store_true", help="benchmark_allgather.cpp path (N >= 2)")
     p.add_argument("--no-verify", action="store_true", help="(profiling of ablated kernels only) skip output checks")
     p.add_argument("--dry-run-emu", action="store_true",
@@ -400,25 +401,7 @@ def run_case(args, ctx):
         },
     }
     if rank == 0:
-        # HBM traffic is a PMC measurement (separate rocprofv3 --pmc passes, scripts/gpu_traffic.sh): it cannot be taken
-        # inside this run, so the committed counters are REPLAYED -- only for the same workload AND the same library
-        # sources; otherwise null.
-        traffic, traffic_source = None, "no PMC record for this workload and library build (scripts/gpu_traffic.sh)"
-        tpath = os.path.join(REPO, "profiles", f"pmc_traffic_{args.algo}.json")
-        if not os.path.exists(tpath):
-            tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                rec = json.load(open(tpath))
-                if rec.get("algo") == args.algo and rec.get("chunks_per_gpu") == n and rec.get("dataset") == args.dataset:
-                    if rec.get("lib_source_digest") == library_source_digest(args.algo):
-                        traffic = rec.get("hbm_bytes_per_launch")
-                        traffic_source = f"{os.path.relpath(tpath, REPO)} (replayed PMC counters of this library build)"
-                    else:
-                        traffic_source = (f"{os.path.relpath(tpath, REPO)} was recorded for another build of the kernels "
-                                          "(lib_source_digest differs): not replayed")
-            except Exception:
-                traffic = None
+        traffic, traffic_source = replayed_traffic(args.algo, "decompress", args.dataset, n)
         result["roofline"] = {
             "bound": "hbm",
             "kernel": (f"{args.algo}_decompress_kernel" if own_format or args.algo == "deflate"
@@ -461,7 +444,9 @@ def run_case(args, ctx):
             "compress_roofline": {
                 "bound": "hbm", "kernel": f"{args.algo}_compress_kernel", "achieved": round(comp_alg / (comp_ms * 1e-3) / 1e9, 2),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(comp_alg / (comp_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                "algorithmic_bytes_per_launch": int(comp_alg), "kernel_ms": round(comp_ms, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": int(comp_alg), "kernel_ms": round(comp_ms, 4),
+                "traffic": replayed_traffic(args.algo, "compress", args.dataset, k)[0],
+                "traffic_source": replayed_traffic(args.algo, "compress", args.dataset, k)[1],
             },
         }
         if args.algo == "deflate":
@@ -579,6 +564,29 @@ def deflate_cpu_baseline(oracle, comp, chunks, threads, unique):
     return {"value": round(total / best / 1e9, 3), "unit": "GB/s", "cores": min(threads, 64), "kind": "reference",
             "sample": f"{total >> 20} MiB ({len(blobs)} chunks) of the same workload, best of 3, zlib {zlib.ZLIB_VERSION} inflate "
                       "from Python threads"}
+
+
+def replayed_traffic(algo, kind, dataset, chunks):
+    """HBM traffic per launch is a PMC measurement (separate rocprofv3 --pmc passes, scripts/gpu_traffic.sh): it cannot be
+    taken inside this run, so the committed counters are REPLAYED -- only for the same kernel, the same workload AND the same
+    kernel sources; otherwise null. Returns (bytes or None, what it is)."""
+    path = os.path.join(REPO, "profiles", "pmc_traffic_r03.json")
+    if not os.path.exists(path):
+        return None, "no PMC record (scripts/gpu_traffic.sh)"
+    try:
+        records = json.load(open(path))
+    except Exception:
+        return None, "unreadable PMC record"
+    digest = library_source_digest(algo)
+    stale = False
+    for rec in records:
+        if rec.get("algo") == algo and rec.get("kind") == kind and rec.get("dataset") == dataset and rec.get("chunks_per_gpu") == chunks:
+            if rec.get("lib_source_digest") == digest:
+                return rec.get("hbm_bytes_per_launch"), "profiles/pmc_traffic_r03.json (replayed PMC counters of this library build)"
+            stale = True
+    if stale:
+        return None, "profiles/pmc_traffic_r03.json was recorded for another build of the kernels (lib_source_digest differs): not replayed"
+    return None, "no PMC record for this workload (scripts/gpu_traffic.sh)"
 
 
 def library_source_digest(algo="lz4"):
@@ -865,7 +873,7 @@ def main():
     ctx = setup_runtime(args)
     result = run_allgather_case(args, ctx) if args.allgather else run_case(args, ctx)
     if (ctx["rank"] == 0 and ctx["world"] == 1 and args.algo == "lz4" and not args.allgather and not args.no_extras
-            and not args.dry_run_emu):
+            and not args.no_riders and not args.dry_run_emu):
         # north_star bars BOTH LZ decoders: the Snappy line of the same workload rides along (5 timed launches); so
         # does the DEFLATE decoder's, on a quarter of the workload
         result.setdefault("extras", {})["snappy"] = rider(args, ctx, "snappy")

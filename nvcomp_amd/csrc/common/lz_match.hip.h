@@ -607,16 +607,16 @@ __device__ __forceinline__ uint32_t encode_chunk(
       }
 
       LZM_T(3); /* dense-window check */
-      /* ---- greedy selection in position order (scalar walk over the hit mask) ---- */
-      uint32_t prev_end = 0;  /* per selected lane: where its literal run starts */
+      /* ---- greedy selection in position order (scalar walk over the hit mask) ----
+       * The walk is the serial part of a window (a sixth of the compressor's time): it carries nothing but the mask --
+       * find the next hit, read its length, mask off what the match covers. Where each selected lane's literal run
+       * starts (the end of the match selected before it) is worked out afterwards, for all of them at once. */
       uint64_t selected = 0;
       uint32_t cur = 0;       /* window-relative BYTE position the next match may start at */
-      uint32_t lit_from = anchor;
       uint64_t rest = hits;
       while (rest) {
         const uint32_t f = wave::ctz64(rest);
         const uint32_t flen = wave::read_lane(mlen, f);
-        prev_end = wave::write_lane(prev_end, lit_from, f);
         selected |= 1ull << f;
         cur = f * STRIDE + flen;
         if (flen >= kLaneCap) { /* the capped match may be much longer: measure it with the whole wave */
@@ -624,11 +624,19 @@ __device__ __forceinline__ uint32_t encode_chunk(
           mlen = wave::write_lane(mlen, full, f);
           cur = f * STRIDE + full;
         }
-        lit_from = ip + cur;
         {
           const uint32_t next_lane = (cur + STRIDE - 1) / STRIDE; /* first lane at or behind the match's end */
           rest = next_lane < 64 ? (hits & (~0ull << next_lane)) : 0ull;
         }
+      }
+      const uint32_t lit_from = ip + cur; /* behind the last selected match */
+      /* a selected lane's run starts where the selected match below it ends (the first one's: at the anchor) */
+      uint32_t prev_end;
+      {
+        const uint64_t below = selected & ((1ull << lane) - 1);
+        const uint32_t prev = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+        const uint32_t prev_stop = wave::shuffle(pos + mlen, prev);
+        prev_end = below ? prev_stop : anchor;
       }
 
       LZM_T(4); /* selection */

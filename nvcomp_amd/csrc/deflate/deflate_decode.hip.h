@@ -32,9 +32,10 @@
 #pragma once
 
 /* DEFLATE's own window size: its batches are cut by the front end at 64 records anyway, and its LDS (lookup tables, the
- * literal ring, the bit-position jump tables) is the occupancy limiter: 1 KiB batches keep a wave at 10.1 KiB. */
+ * literal ring, the bit-position jump tables) is the occupancy limiter: batches of 960 bytes keep a wave at exactly
+ * 10 KiB = 16 waves per CU. */
 #ifndef NVCOMP_LZW_BATCHMAX
-#define NVCOMP_LZW_BATCHMAX 1024
+#define NVCOMP_LZW_BATCHMAX 960
 #endif
 #include "common/lz_window.hip.h"
 

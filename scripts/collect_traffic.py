@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_traffic.sh -> one JSON list of per-launch HBM traffic records
+(stdout). Every record names the kernel, the workload it ran on and the digest of the kernel sources, which is what
+bench.py matches before replaying a number beside a timing."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+# run name -> [(kernel substring, algo, kind)]
+KERNELS = {
+    "lz4": [("lz4_decompress_window_kernel", "lz4", "decompress"), ("lz4_compress_kernel", "lz4", "compress")],
+    "snappy": [("snappy_decompress_window_kernel", "snappy", "decompress")],
+    "deflate": [("deflate_decompress_kernel", "deflate", "decompress")],
+    "cascaded": [("cascaded_decompress_kernel", "cascaded", "decompress")],
+    "lz4_mortgage": [("lz4_decompress_window_kernel", "lz4", "decompress")],
+}
+
+
+def per_launch(path, substr):
+    rows = [r for r in csv.DictReader(open(path)) if substr in r["Kernel_Name"]]
+    launches = len({r["Dispatch_Id"] for r in rows})
+    total = sum(float(r["Counter_Value"]) for r in rows)
+    return (total / launches if launches else None), launches
+
+
+def main():
+    import bench
+
+    out_dir = sys.argv[1]
+    records = []
+    for run, kernels in KERNELS.items():
+        log = os.path.join(out_dir, f"{run}_FETCH_SIZE.log")
+        line = None
+        if os.path.exists(log):
+            for l in open(log):
+                if l.startswith("{"):
+                    line = json.loads(l)
+        if line is None:
+            continue
+        cfg = line["config"]
+        for substr, algo, kind in kernels:
+            vals = {}
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                hits = glob.glob(os.path.join(out_dir, f"{run}_{ctr}", "**", "*counter_collection.csv"), recursive=True)
+                if hits:
+                    vals[ctr], n = per_launch(hits[0], substr)
+            if vals.get("FETCH_SIZE") is None or vals.get("WRITE_SIZE") is None:
+                continue
+            fetch, write = vals["FETCH_SIZE"] * 1024, vals["WRITE_SIZE"] * 1024  # the counters are in KB
+            comp, raw = cfg["compressed_bytes_per_gpu"], cfg["uncompressed_bytes_per_gpu"]
+            # gfx950: FETCH_SIZE reports half the bytes of a wide coalesced streaming read (the guide's correction). The
+            # streamed input of a decoder is the compressed data (16 B / lane), of a compressor the raw data (8 B / lane
+            # into the LDS image): that part is doubled; what exceeds it (far-match gathers, candidate probes: narrow,
+            # scattered) stays as counted.
+            streamed = comp if kind == "decompress" else raw
+            uncounted = min(fetch, streamed / 2)
+            records.append({
+                "algo": algo, "kind": kind, "kernel": substr, "dataset": cfg["dataset"], "chunks_per_gpu": cfg["chunks_per_gpu"],
+                "lib_source_digest": bench.library_source_digest(algo),
+                "fetch_bytes_counted": int(fetch), "write_bytes_counted": int(write),
+                "hbm_bytes_per_launch": int(fetch + uncounted + write),
+                "algorithmic_bytes": int(comp + raw + (44 if kind == "decompress" else 40) * cfg["chunks_per_gpu"]),
+                "note": "FETCH_SIZE as counted + the uncounted half of the coalesced input stream (gfx950 tallies wide "
+                        "coalesced reads at 1/2: MI355X_MICROARCH.md, calibrated in round 1 by scripts/gpu_calib.sh) + "
+                        "WRITE_SIZE; separate rocprofv3 --pmc passes, KB units; Infinity-Cache hits are counted too",
+            })
+    print(json.dumps(records, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,23 +1,25 @@
 #!/bin/bash
-# FETCH_SIZE / WRITE_SIZE per launch of the own-format decode kernels and of Snappy's (separate --pmc passes;
-# LZ4's come from gpu_final.sh's pmc_fetch / pmc_write legs)
+# HBM traffic of the kernels behind the driver's bench line (the headline, its riders, the compress leg): FETCH_SIZE and
+# WRITE_SIZE per launch, SEPARATE rocprofv3 --pmc passes of the same commands (MI355X_MICROARCH.md: FETCH_SIZE costs 3 TCC
+# slots, WRITE_SIZE 2; never together with trace domains). scripts/collect_traffic.py turns the CSVs into
+# profiles/pmc_traffic_r03.json, which bench.py replays for the same workload AND the same kernel sources only.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-OUT=gpurun_out/${1:-tr}
+OUT=gpurun_out/${1:-traffic}
 mkdir -p "$OUT"
-for algo in bitcomp ans cascaded snappy; do for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $ctr --output-format csv -d "$OUT/${algo}_$ctr" -o r -- python bench.py --algo $algo --steps 2 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/${algo}_$ctr.log" 2>&1
-  python - "$OUT/${algo}_$ctr/r_counter_collection.csv" "$algo" <<'PY'
-import csv, sys, collections
-agg = collections.defaultdict(float); n = collections.defaultdict(set)
-for r in csv.DictReader(open(sys.argv[1])):
-    if "_decompress_" in r["Kernel_Name"] and "size_kernel" not in r["Kernel_Name"] and sys.argv[2] in r["Kernel_Name"]:
-        agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]].add(r["Dispatch_Id"])
-import json, os
-for k, v in agg.items():
-    print(sys.argv[2], k, "KB per launch:", round(v / len(n[k]), 1), "launches", len(n[k]))
-    json.dump({"KB_per_launch": v / len(n[k]), "launches": len(n[k])},
-              open(os.path.join(os.path.dirname(os.path.dirname(sys.argv[1])), f"traffic_{sys.argv[2]}_{k}.json"), "w"))
-PY
-done; done
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+run() { # name, bench args...
+  local name=$1; shift
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    timeout 400 rocprofv3 --pmc $ctr --output-format csv -d "$OUT/${name}_$ctr" -o r -- $B "$@" > "$OUT/${name}_$ctr.log" 2>&1
+    echo "$name $ctr rc=$?" | tee -a "$OUT/rc.txt"
+  done
+}
+run lz4 --no-riders                                   # lz4_decompress_window_kernel + lz4_compress_kernel (the extras leg)
+run snappy --algo snappy --no-extras
+run deflate --algo deflate --no-extras --mib-per-gpu 1024 --unique-mib 32
+run cascaded --algo cascaded --no-extras --dataset example_float_columns --mib-per-gpu 1024 --unique-mib 32
+run lz4_mortgage --no-extras --dataset mortgage_col0_like --mib-per-gpu 1024 --unique-mib 64
+find "$OUT" -name "*.csv" -size +16M -delete
+python scripts/collect_traffic.py "$OUT" > "$OUT/pmc_traffic_r03.json" && cat "$OUT/pmc_traffic_r03.json" | head -60
