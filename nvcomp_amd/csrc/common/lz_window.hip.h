@@ -73,7 +73,8 @@ constexpr uint32_t kInLds = kInRing + 16; /* first 16 bytes mirrored after the e
 #endif
 constexpr uint32_t kChaseEnough = NVCOMP_LZW_CHASE_ENOUGH;
 constexpr uint32_t kChaseWin = 256;                 /* stream positions one chase window covers */
-constexpr uint32_t kChaseLevels = 6;                /* jump tables for 1, 2, 4, 8, 16, 32 tokens ahead */
+constexpr uint32_t kChaseLevels = 5;                /* jump tables for 1, 2, 4, 8, 16 tokens ahead; 32 = two steps of the
+                                                     * last one from the start position (chase_tokens): no sixth round */
 constexpr uint32_t kChaseLds = kChaseLevels * kChaseWin;
 constexpr uint32_t kLdsPerWave = kOutLds + kInLds + kChaseLds;
 
@@ -327,8 +328,15 @@ __device__ __forceinline__ uint32_t chase_tokens(
      * instruction): a lane follows the levels named by the bits of n; a level it does not take adds 0; 255 (the
      * successor leaves the window) poisons the lane through `worst`; the position wraps inside the table. */
     const uint32_t idx = (lane - k) & 63u;
-    uint32_t pos = c.q - c.wb;
-    uint32_t worst = 0;
+    const uint32_t pos0 = c.q - c.wb;
+    /* ranks 32 and up start at the 32nd token: two steps of the 16-token table from the start position (every lane
+     * reads the same two bytes); the jump tables themselves stop at 16, one doubling round less per window */
+    const uint32_t top = (kChaseLevels - 1) * kChaseWin;
+    const uint32_t t1 = c.tab[top + pos0];
+    const uint32_t t2 = c.tab[top + ((pos0 + t1) & (kChaseWin - 1))];
+    const bool upper = (idx & 32u) != 0;
+    uint32_t pos = upper ? (pos0 + t1 + t2) & (kChaseWin - 1) : pos0;
+    uint32_t worst = upper ? (t1 > t2 ? t1 : t2) : 0u;
 #pragma unroll
     for (uint32_t i = 0; i < kChaseLevels; ++i) {
       const uint32_t a = c.tab[i * kChaseWin + pos];

@@ -66,7 +66,10 @@ __device__ __forceinline__ uint32_t emit_sequence(
 struct Emitter
 {
   static constexpr bool kStream = false;   /* sequences start at byte boundaries: lzm writes them where they go */
-  static constexpr uint32_t kReach = 65535; /* 2-byte offsets */
+#ifndef NVCOMP_LZ4_REACH
+#define NVCOMP_LZ4_REACH 65535
+#endif
+  static constexpr uint32_t kReach = NVCOMP_LZ4_REACH; /* 2-byte offsets */
   static __device__ __forceinline__ uint32_t ext_bytes(uint32_t v) /* extension bytes for a length code v */
   {
     return v >= 15 ? (v - 15) / 255 + 1 : 0;

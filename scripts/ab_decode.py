@@ -23,6 +23,12 @@ CASES = {
     "mix": ("LZ4", "silesia_style", "hc", 64, None),
     "mix1g": ("LZ4", "silesia_style", "hc", 64, 1024),
     "mix256m": ("LZ4", "silesia_style", "hc", 64, 256),
+    "mix128m": ("LZ4", "silesia_style", "hc", 64, 128),
+    "mix64m": ("LZ4", "silesia_style", "hc", 64, 64),
+    "mix16m": ("LZ4", "silesia_style", "hc", 16, 16),
+    "mix512m": ("LZ4", "silesia_style", "hc", 64, 512),
+    "snappy256m": ("Snappy", "silesia_style", "snappy", 64, 256),
+    "snappy64m": ("Snappy", "silesia_style", "snappy", 64, 64),
     "snappy_mix": ("Snappy", "silesia_style", "snappy", 64, None),
     "mortgage": ("LZ4", "mortgage_col0_like", "fast", 64, 1024),
     "mortgage5k": ("LZ4", "mortgage_col0_like", "fast", 64, 314),
