@@ -28,7 +28,7 @@ namespace lzw {
 
 /* Tunables (overridable with -D for the A/B builds of scripts/build_variants.sh). */
 /* The output window holds ONE BATCH: the bytes a batch produces (at most kBatchMax) plus the tail of the previous one
- * that still waits for its 16-byte block to fill up -- no history. Measured on MI355X (profiles/r03_ab_*.jsonl): 84 % of
+ * that still waits for its 16-byte block to fill up -- and 32 bytes of history, no more. Measured on MI355X (profiles/r03_ab_*.jsonl): 84 % of
  * the matches of the headline workload reach further back than any window that fits the LDS budget (61 % further than
  * 4 KiB), so history only turned a twentieth of the far matches into near ones, and paid for it with 1 KiB of LDS per
  * wave and a slide of 768 bytes every other batch: without it +1.6 % (LZ4 mix), +2.4 % (Snappy), +7 % (text, 1 GiB
@@ -39,11 +39,12 @@ namespace lzw {
 #ifndef NVCOMP_LZW_BATCHMAX
 #define NVCOMP_LZW_BATCHMAX 2048
 #endif
-#ifndef NVCOMP_LZW_OUTWIN
-#define NVCOMP_LZW_OUTWIN (NVCOMP_LZW_BATCHMAX + 64)
-#endif
 #ifndef NVCOMP_LZW_KEEP
-#define NVCOMP_LZW_KEEP 0
+#define NVCOMP_LZW_KEEP 32 /* the last 32 bytes stay: what the shortest offsets reach (Snappy's one-byte-offset copies, the
+                             * patterns of runs that go on across a batch boundary): Snappy mix +3 %, LZ4 mix +1 % */
+#endif
+#ifndef NVCOMP_LZW_OUTWIN
+#define NVCOMP_LZW_OUTWIN (NVCOMP_LZW_BATCHMAX + 64 + NVCOMP_LZW_KEEP)
 #endif
 #ifndef NVCOMP_LZW_INRING
 #define NVCOMP_LZW_INRING 2048
@@ -987,6 +988,23 @@ __device__ __forceinline__ bool stream_sequence(
   return true;
 }
 
+/* A match copied by the whole wave into the window at output position hw (everything below hw is final): its source
+ * may start in front of what the window holds -- those bytes are in HBM (flushed before the window let go of them). */
+__device__ __forceinline__ void coop_match(OutWindow& ow, uint32_t hw, uint32_t foff, uint32_t flen)
+{
+  const uint32_t fsrc = hw - foff;
+  if (fsrc >= ow.valid_lo) {
+    lds_match_copy(out_at(ow, hw), foff, flen);
+  } else {
+    const uint32_t n_hbm = fsrc + flen <= ow.valid_lo ? flen : ow.valid_lo - fsrc;
+    copy_to_lds(out_at(ow, hw), ow.out + fsrc, n_hbm);
+    wave::sync();
+    if (n_hbm < flen) {
+      lds_match_copy(out_at(ow, hw + n_hbm), foff, flen - n_hbm);
+    }
+  }
+}
+
 /*
  * Execute the first sequences of a parsed batch inside the window. Lane k owns
  * sequence k (k < n, n >= 1); lanes >= n hold EMPTY sequences (lit_len = match_len = 0:
@@ -1172,19 +1190,7 @@ __device__ __forceinline__ uint32_t execute_window_batch(
         /* the oldest pending match is long, has a period < 4, or reaches behind the window */
         const uint32_t foff = wave::read_lane(s.match_off, f);
         const uint32_t flen = wave::read_lane(my_match, f);
-        const uint32_t fsrc = hw - foff;
-        if (fsrc >= ow.valid_lo) {
-          lds_match_copy(out_at(ow, hw), foff, flen);
-        } else {
-          /* Source starts behind the window: bytes below valid_lo come from HBM (they were flushed
-           * before the window let go of them), everything from valid_lo on is in the window. */
-          const uint32_t n_hbm = fsrc + flen <= ow.valid_lo ? flen : ow.valid_lo - fsrc;
-          copy_to_lds(out_at(ow, hw), ow.out + fsrc, n_hbm);
-          wave::sync();
-          if (n_hbm < flen) {
-            lds_match_copy(out_at(ow, hw + n_hbm), foff, flen - n_hbm);
-          }
-        }
+        coop_match(ow, hw, foff, flen);
         pending &= ~(1ull << f);
         LZW_T(14); /* matches copied by the whole wave */
         continue;

@@ -32,10 +32,10 @@
 #pragma once
 
 /* DEFLATE's own window size: its batches are cut by the front end at 64 records anyway, and its LDS (lookup tables, the
- * literal ring, the bit-position jump tables) is the occupancy limiter: batches of 960 bytes keep a wave at exactly
+ * literal ring, the bit-position jump tables) is the occupancy limiter: batches of 928 bytes (+ 32 of history) keep a wave at exactly
  * 10 KiB = 16 waves per CU. */
 #ifndef NVCOMP_LZW_BATCHMAX
-#define NVCOMP_LZW_BATCHMAX 960
+#define NVCOMP_LZW_BATCHMAX 928
 #endif
 #include "common/lz_window.hip.h"
 

@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=gpurun_out/${1:-pmc}
 mkdir -p "$OUT"
-B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras ${EXTRA:-}"
 run_pmc() { local name=$1; shift; local algo=$1; shift
   timeout 300 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_${algo}_$name" -o r -- $B --algo $algo > "$OUT/pmc_${algo}_$name.log" 2>&1; echo "pmc $algo $name rc=$?" >> "$OUT/rc.txt"; }
 for algo in ${ALGOS:-lz4}; do
