@@ -276,6 +276,16 @@ __device__ __forceinline__ void chase_build(Chase& c, const InRing& r, Delta del
     for (uint32_t k = 0; k < 4; ++k) {
       nx[k] = delta.fast(r, base + k, w >> (8 * k));
     }
+    /* what the straight-line form gave up on gets the general one (a branch for the wave: rare on text, every window
+     * of a sorted column, whose matches take a second length byte) */
+    if (Delta::kSecondChance && wave::ballot((nx[0] | nx[1] | nx[2] | nx[3]) >= kUnknownDelta)) {
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) {
+        if (nx[k] >= kUnknownDelta) {
+          nx[k] = delta.second(r, base + k, w >> (8 * k));
+        }
+      }
+    }
   } else {
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {

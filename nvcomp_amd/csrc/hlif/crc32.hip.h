@@ -5,15 +5,16 @@
  * A CRC is a chain over the bytes, so the chunk is cut for the lanes and the pieces are combined with the algebra of
  * the checksum (the remainder of the message polynomial modulo P is linear in the message):
  *
- *   - the message, padded IN FRONT with zero bytes to a multiple of kTile = 4 KiB, is walked tile by tile; lane l
- *     owns the kSeg = 64 bytes [64 l, 64 l + 64) of every tile: four 16-byte loads per lane and tile, and the four loads of
- *     a wave together read every 64-byte line of the tile exactly once;
+ *   - the message, padded IN FRONT with zero bytes to a multiple of kTile = 64 kSeg = 2 KiB, is walked tile by tile; lane l
+ *     owns the kSeg = 32 bytes [32 l, 32 l + 32) of every tile: two 16-byte loads per lane and tile (kSeg = 64, four loads
+ *     that each touch all 64 lines of a 4 KiB tile, is as fast on 64 KiB chunks and 18 % slower on compressed chunks of
+ *     any size and alignment; kSeg = 16, fully coalesced, pays a skip per 16 bytes: scripts/probes/crc_bench.hip);
  *   - inside its 64 bytes a lane runs slicing-by-4 (one table lookup per byte, four per dword);
- *   - between two tiles a lane's state skips the 4 032 bytes that belong to the other lanes: appending Z zero bytes to a
+ *   - between two tiles a lane's state skips the 2 016 bytes that belong to the other lanes: appending Z zero bytes to a
  *     raw remainder is the linear map s -> s * x^(8Z) mod P, done as four more table lookups (one per state byte);
  *   - leading zeros do not change a raw remainder, so the front padding costs nothing, and the lane that holds the first
  *     real byte starts from the 0xffffffff every CRC-32 starts from; the padding makes every lane's distance to the END
- *     of the message the same for every chunk length, (63 - l) * 64 bytes: six conditional multiplications by constants;
+ *     of the message the same for every chunk length, (63 - l) * kSeg bytes: six conditional multiplications by constants;
  *   - an XOR across the lanes and the final complement give the checksum.
  *
  * The tables (8 KiB: slicing and skipping) and the six constants are computed at COMPILE time (constexpr) and copied to
@@ -29,8 +30,10 @@
 namespace crc32w {
 
 constexpr uint32_t kPoly = 0xedb88320u;
-constexpr uint32_t kSeg = 64;    /* bytes of a tile one lane owns */
-constexpr uint32_t kTile = 4096; /* 64 lanes x kSeg */
+#ifndef NVCOMP_CRC_SEG
+#define NVCOMP_CRC_SEG 32
+#endif
+constexpr uint32_t kSegDefault = NVCOMP_CRC_SEG; /* bytes of a tile one lane owns: 16, 32 or 64 (a tile = 64 of them) */
 
 /* a(x) * b(x) mod P(x) in the reflected representation (bit 31 is x^0) */
 constexpr uint32_t mulmod(uint32_t a, uint32_t b)
@@ -59,8 +62,10 @@ constexpr uint32_t xpow_bytes(uint64_t n)
   return r;
 }
 
+template <uint32_t kSeg>
 struct Tables
 {
+  static constexpr uint32_t kTile = 64 * kSeg;
   uint32_t slice[4][256]; /* slicing-by-4: slice[k][b] = remainder of byte b followed by k zero bytes */
   uint32_t skip[4][256];  /* skip[k][b] = (b << 8 k) * x^(8 (kTile - kSeg)) mod P */
   uint32_t fin[8];        /* fin[j] = x^(8 * kSeg * 2^j) mod P, j = 0..5 */
@@ -89,14 +94,16 @@ struct Tables
     }
   }
 };
-__constant__ static const Tables kTables = Tables();
+template <uint32_t kSeg>
+__constant__ static const Tables<kSeg> kTables = Tables<kSeg>();
 
 constexpr uint32_t kLdsDwords = 2048; /* slice | skip, per workgroup */
 
 /* Copy the lookup tables to the workgroup's LDS; a __syncthreads() must follow. */
+template <uint32_t kSeg = kSegDefault>
 __device__ __forceinline__ void load_tables(uint32_t* lds)
 {
-  const uint32_t* src = &kTables.slice[0][0];
+  const uint32_t* src = &kTables<kSeg>.slice[0][0];
   for (uint32_t i = threadIdx.x; i < kLdsDwords; i += blockDim.x) {
     lds[i] = src[i];
   }
@@ -126,9 +133,37 @@ __device__ __forceinline__ uint32_t mul_const(uint32_t s, uint32_t k)
   return p;
 }
 
-/* CRC-32 of p[0, n) with the calling wave (n < 2^31); `lds` = the tables (load_tables). The result is wave-uniform. */
+/* one lane's kSeg bytes of a tile: 16-byte loads, and the slicing steps over them */
+template <uint32_t kSeg>
+struct Piece
+{
+  wave::u32x4 w[kSeg / 16];
+  __device__ __forceinline__ void load(const uint8_t* q)
+  {
+#pragma unroll
+    for (uint32_t i = 0; i < kSeg / 16; ++i) {
+      w[i] = wave::gload_u32x4(q + 16 * i);
+    }
+  }
+  __device__ __forceinline__ uint32_t into(const uint32_t* slice, uint32_t s) const
+  {
+#pragma unroll
+    for (uint32_t i = 0; i < kSeg / 16; ++i) {
+      s = step_dword(slice, s, w[i].x), s = step_dword(slice, s, w[i].y);
+      s = step_dword(slice, s, w[i].z), s = step_dword(slice, s, w[i].w);
+    }
+    return s;
+  }
+};
+
+/* CRC-32 of p[0, n) with the calling wave (n < 2^31); `lds` = the tables (load_tables). The result is wave-uniform.
+ * (Issuing the loads of tile t + 1 before the lookups of tile t was measured and changes nothing: the other waves of the
+ * CU fill the gaps. scripts/probes/crc_bench.hip: loads alone 6.0 TB/s, lookups alone 9.2, the kernel 4.9.) */
+template <uint32_t kSeg = kSegDefault>
 __device__ __forceinline__ uint32_t wave_crc32(const uint8_t* p, uint32_t n, const uint32_t* lds)
 {
+  static_assert(kSeg == 16 || kSeg == 32 || kSeg == 64, "one, two or four 16-byte loads per lane and tile");
+  constexpr uint32_t kTile = 64 * kSeg;
   if (n == 0) {
     return 0;
   }
@@ -137,34 +172,31 @@ __device__ __forceinline__ uint32_t wave_crc32(const uint8_t* p, uint32_t n, con
   const uint32_t* skip = lds + 1024;
   const uint32_t pad = (kTile - n % kTile) % kTile; /* virtual zero bytes in front */
   const uint32_t tiles = (n + pad) / kTile;
+  const uint32_t v0 = lane * kSeg;                  /* virtual position of my bytes in the first tile */
+  const uint8_t* q = p + v0 - pad;                  /* (in front of p for the lanes of the padding: not looked at) */
   uint32_t s = 0;
-  for (uint32_t t = 0; t < tiles; ++t) {
-    if (t != 0) {
-      s = lookup4(skip, s);
-    }
-    const uint32_t v0 = t * kTile + lane * kSeg; /* virtual position of my 64 bytes */
-    if (v0 >= pad) {
-      const uint8_t* q = p + (v0 - pad);
-      s = v0 == pad ? 0xffffffffu : s; /* the message starts here: every CRC-32 starts from all ones */
-      const wave::u32x4 a = wave::gload_u32x4(q), b = wave::gload_u32x4(q + 16);
-      const wave::u32x4 c = wave::gload_u32x4(q + 32), d = wave::gload_u32x4(q + 48);
-      s = step_dword(slice, s, a.x), s = step_dword(slice, s, a.y), s = step_dword(slice, s, a.z), s = step_dword(slice, s, a.w);
-      s = step_dword(slice, s, b.x), s = step_dword(slice, s, b.y), s = step_dword(slice, s, b.z), s = step_dword(slice, s, b.w);
-      s = step_dword(slice, s, c.x), s = step_dword(slice, s, c.y), s = step_dword(slice, s, c.z), s = step_dword(slice, s, c.w);
-      s = step_dword(slice, s, d.x), s = step_dword(slice, s, d.y), s = step_dword(slice, s, d.z), s = step_dword(slice, s, d.w);
-    } else if (v0 + kSeg > pad) {
-      /* the message starts inside my 64 bytes (first tile only): byte by byte from its first byte on */
-      s = 0xffffffffu;
-      for (uint32_t i = pad - v0; i < kSeg; ++i) {
-        s = slice[(s ^ wave::gload_u8(p + (v0 + i - pad))) & 0xffu] ^ (s >> 8);
-      }
+  Piece<kSeg> cur;
+  /* the first tile: the message starts somewhere inside it */
+  if (v0 >= pad) {
+    cur.load(q);
+    s = cur.into(slice, v0 == pad ? 0xffffffffu : 0u); /* the message starts here: every CRC-32 starts from all ones */
+  } else if (v0 + kSeg > pad) {
+    /* the message starts inside my bytes: byte by byte from its first byte on */
+    s = 0xffffffffu;
+    for (uint32_t i = pad - v0; i < kSeg; ++i) {
+      s = slice[(s ^ wave::gload_u8(q + i)) & 0xffu] ^ (s >> 8);
     }
   }
-  /* (63 - lane) * 64 bytes of the message follow my last byte */
+  /* whole tiles */
+  for (uint32_t t = 1; t < tiles; ++t) {
+    cur.load(q + (size_t)t * kTile);
+    s = cur.into(slice, lookup4(skip, s));
+  }
+  /* (63 - lane) * kSeg bytes of the message follow my last byte */
   const uint32_t behind = 63u - lane;
 #pragma unroll
   for (uint32_t j = 0; j < 6; ++j) {
-    const uint32_t m = mul_const(s, kTables.fin[j]);
+    const uint32_t m = mul_const(s, kTables<kSeg>.fin[j]);
     s = ((behind >> j) & 1u) ? m : s;
   }
   /* XOR across the wave */

@@ -295,6 +295,26 @@ struct ManagerImpl
   int device;
   ChecksumPolicy policy;
   DeviceBuffer arrays, stage, temp, misc;
+  /* verification beside the decoder (decompress()): a second stream and the two events that fork it off and join it */
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  void need_side_stream()
+  {
+    if (side == nullptr) {
+      hip_check(hipStreamCreateWithFlags(&side, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+      hip_check(hipEventCreateWithFlags(&fork, hipEventDisableTiming), "hipEventCreateWithFlags");
+      hip_check(hipEventCreateWithFlags(&join, hipEventDisableTiming), "hipEventCreateWithFlags");
+    }
+  }
+  ~ManagerImpl()
+  {
+    if (side != nullptr) {
+      (void)hipStreamSynchronize(side);
+      (void)hipEventDestroy(fork);
+      (void)hipEventDestroy(join);
+      (void)hipStreamDestroy(side);
+    }
+  }
 
   bool compute_checksums() const { return policy == ComputeAndNoVerify || policy == ComputeAndVerifyIfPresent || policy == ComputeAndVerify; }
   bool verify_checksums() const { return policy == NoComputeAndVerifyIfPresent || policy == ComputeAndVerifyIfPresent || policy == ComputeAndVerify; }
@@ -551,18 +571,27 @@ void BatchedManager::decompress(uint8_t* decomp_buffer, const uint8_t* comp_buff
   const bool verify = m.verify_checksums(); /* the kernels skip the check when the buffer has no checksums */
   const uint32_t* crc_u = (const uint32_t*)(comp_buffer + sizeof(Header) + 8 * n + 8 * (n + 1));
   const uint32_t* crc_c = crc_u + n;
+  const dim3 crc_grid((unsigned)((n + kCrcWaves - 1) / kCrcWaves)), crc_block(64 * kCrcWaves);
   if (verify) {
     hip_check(hipMemsetAsync(mismatch, 0, 4, m.stream), "hipMemsetAsync");
-    hipLaunchKernelGGL(crc_kernel, dim3((unsigned)((n + kCrcWaves - 1) / kCrcWaves)), dim3(64 * kCrcWaves), 0, m.stream,
-                       (const void* const*)comp_ptrs, comp_sizes, n,
-                       (uint32_t*)nullptr, crc_c, mismatch, (const Header*)comp_buffer);
+    m.need_side_stream();
+    hip_check(hipEventRecord(m.fork, m.stream), "hipEventRecord");
   }
   nv_check(m.decompress_async(comp_ptrs, comp_sizes, out_caps, actual, n, m.temp.ptr, tb, out_ptrs, statuses),
            "DecompressAsync");
   if (verify) {
-    hipLaunchKernelGGL(crc_kernel, dim3((unsigned)((n + kCrcWaves - 1) / kCrcWaves)), dim3(64 * kCrcWaves), 0, m.stream,
-                       (const void* const*)out_ptrs, out_caps, n,
+    /* The checksums of the COMPRESSED chunks are verified BESIDE the decoder, on a second stream, launched behind it: the
+     * decoders are resident first (their persistent waves take 28 of a CU's 32 wave slots and 151 of its 160 KB of LDS,
+     * common/lz_launch.hip.h) and are bound by the vector and scalar units; a checksum workgroup (four waves, 8 KiB of
+     * tables) fits into what they leave and lives on loads and LDS lookups, which the decoders leave idle. The checksums
+     * of the decoded chunks follow the decoder on its own stream. */
+    hip_check(hipStreamWaitEvent(m.side, m.fork, 0), "hipStreamWaitEvent");
+    hipLaunchKernelGGL(crc_kernel, crc_grid, crc_block, 0, m.side, (const void* const*)comp_ptrs, comp_sizes, n,
+                       (uint32_t*)nullptr, crc_c, mismatch, (const Header*)comp_buffer);
+    hip_check(hipEventRecord(m.join, m.side), "hipEventRecord");
+    hipLaunchKernelGGL(crc_kernel, crc_grid, crc_block, 0, m.stream, (const void* const*)out_ptrs, out_caps, n,
                        (uint32_t*)nullptr, crc_u, mismatch, (const Header*)comp_buffer);
+    hip_check(hipStreamWaitEvent(m.stream, m.join, 0), "hipStreamWaitEvent");
   }
   hipLaunchKernelGGL(status_kernel, dim3(1), dim3(256), 0, m.stream, statuses, actual, out_caps, n,
                      verify ? mismatch : (const uint32_t*)nullptr, status);

@@ -21,27 +21,34 @@ namespace lz4w {
 constexpr uint32_t kUnknown = 1u << 28;
 
 
-/* Distance from a (speculative) token at virtual position p to the next token.
- * Branch-free: the token and the byte behind it are fetched together, the one byte a
- * match-length extension may need is the only dependent LDS read; whether the answer
- * can be trusted is decided at the end (kUnknown -> scalar slow path). */
+/* Distance from a (speculative) token at virtual position p to the next token, with every bound tested: the windows at
+ * the edges of the chunk and of the resident stream, and the positions of an interior window whose lengths the
+ * straight-line DeltaFn::fast() gave up on. Up to TWO extension bytes per length (literal runs to 524 bytes, matches to
+ * 528): a sorted key column compressed by liblz4 -- the reference's published shape -- is all matches of about 400
+ * bytes, and with one extension byte every one of its tokens left the chase through the scalar slow path, one
+ * enumeration per token (profiles/r03_pmc_mortgage.json: 155 scalar instructions per sequence). Longer fields ->
+ * kUnknown -> chase_slow_next(). */
 __device__ __forceinline__ uint32_t token_delta(const lzw::InRing& r, uint32_t p)
 {
   const uint8_t* ring = r.ring;
   const uint32_t m = lzw::kInRing - 1;
   const uint32_t t = ring[p & m];
   const uint32_t e1 = ring[(p + 1) & m];
+  const uint32_t e1b = ring[(p + 2) & m];
   const uint32_t lit_code = t >> 4;
   const bool lit_ext = lit_code == 15;
-  const uint32_t lit = lit_code + (lit_ext ? e1 : 0u);
-  const uint32_t lit_end = p + 1 + (lit_ext ? 1u : 0u) + lit;
+  const bool lit_ext2 = lit_ext && e1 == 255;
+  const uint32_t lit = lit_code + (lit_ext ? e1 : 0u) + (lit_ext2 ? e1b : 0u);
+  const uint32_t lit_end = p + 1 + (lit_ext ? 1u : 0u) + (lit_ext2 ? 1u : 0u) + lit;
   const bool ends = lit_end >= r.vend; /* literals reach the end of the chunk: the chase stops here */
   const uint32_t mpos = lit_end + 2;   /* where a match-length extension byte would sit */
   const uint32_t e2 = ring[mpos & m];
+  const uint32_t e3 = ring[(mpos + 1) & m];
   const bool m_ext = (t & 15u) == 15u;
-  const uint32_t delta = ends ? lit_end - p : mpos + (m_ext ? 1u : 0u) - p;
-  const bool unknown = p < r.lo || p + 2 > r.hi || p >= r.vend || (lit_ext && e1 == 255)
-                       || (!ends && m_ext && (mpos >= r.hi || e2 == 255));
+  const bool m_ext2 = m_ext && e2 == 255;
+  const uint32_t delta = ends ? lit_end - p : mpos + (m_ext ? 1u : 0u) + (m_ext2 ? 1u : 0u) - p;
+  const bool unknown = p < r.lo || p + 3 > r.hi || p >= r.vend || (lit_ext2 && e1b == 255)
+                       || (!ends && m_ext && (mpos >= r.hi || (e2 == 255 && (mpos + 1 >= r.hi || e3 == 255))));
   return unknown ? kUnknown : delta;
 }
 
@@ -104,8 +111,8 @@ __device__ __forceinline__ uint32_t chase_slow_next(const lzw::InRing& r, uint32
 
 struct DeltaFn
 {
-  /* a delta looks at most this far past its position: token, 2 length bytes, 15 + 254 literals, offset, length byte */
-  static constexpr uint32_t kReach = 280;
+  /* a delta looks at most this far past its position: token, 2 length bytes, 15 + 254 literals, offset, 2 length bytes */
+  static constexpr uint32_t kReach = 281;
   __device__ __forceinline__ uint32_t operator()(const lzw::InRing& r, uint32_t p) const { return token_delta(r, p); }
   /* interior window: `w` = the stream bytes from p on (token in bits 0-7, the byte behind it in 8-15) */
   __device__ __forceinline__ uint32_t fast(const lzw::InRing& r, uint32_t p, uint64_t w) const
@@ -122,6 +129,22 @@ struct DeltaFn
     const uint32_t e2 = r.ring[(p + d0) & (lzw::kInRing - 1)];
     const uint32_t unknown = (lit_ext & (e1 == 255 ? 1u : 0u)) | (m_ext & (e2 == 255 ? 1u : 0u));
     return unknown ? kUnknown : d0 + m_ext;
+  }
+  /* the positions fast() gave up on, once more (lzw::chase_build, under a branch of the wave): a match length with a
+   * SECOND extension byte -- 274 .. 528 bytes, every sequence of a sorted key column -- is resolved here; everything
+   * longer stays with the scalar walk */
+  static constexpr bool kSecondChance = true;
+  __device__ __forceinline__ uint32_t second(const lzw::InRing& r, uint32_t p, uint64_t w) const
+  {
+    const uint32_t t = (uint32_t)w & 0xffu;
+    const uint32_t e1 = (uint32_t)(w >> 8) & 0xffu;
+    const uint32_t lit_code = t >> 4;
+    const bool lit_ext = lit_code == 15;
+    const uint32_t d0 = 3 + lit_code + (lit_ext ? e1 + 1u : 0u);
+    const uint32_t e2 = r.ring[(p + d0) & (lzw::kInRing - 1)];
+    const uint32_t e3 = r.ring[(p + d0 + 1) & (lzw::kInRing - 1)];
+    const bool ok = !(lit_ext && e1 == 255) && (t & 15u) == 15u && e2 == 255 && e3 != 255;
+    return ok ? d0 + 2 : kUnknown;
   }
 };
 struct SlowFn
@@ -252,7 +275,7 @@ __device__ __forceinline__ uint32_t ring_bytes4(const lzw::InRing& r, uint32_t p
  * two predicates in all (a length needing a second extension byte sends the whole batch to the general parser) instead
  * of the dozen lane conditions -- each of them a scalar instruction per && -- the bounds used to cost
  * (profiles/r03_ab_*.jsonl). Returns false (wave-uniform) when the general parser must do the batch. */
-constexpr uint32_t kFastSpan = 288; /* token, length byte, 15 + 254 literals, offset, length byte, and the token behind */
+constexpr uint32_t kFastSpan = 289; /* token, length byte, 15 + 254 literals, offset, two length bytes, and the token behind */
 
 __device__ __forceinline__ bool parse_fast(
     const lzw::InRing& r, uint32_t p, uint32_t from, uint32_t to, lz::Seq& s, bool& bad)
@@ -276,15 +299,19 @@ __device__ __forceinline__ bool parse_fast(
   const uint32_t x = ring_bytes4(r, q);
   const uint32_t mcode = t & 15u;
   const uint32_t me = (x >> 16) & 0xffu;
-  /* second extension bytes: literal code 15 followed by 255 = bits 4-15 of w all set; match code 15 followed by 255 */
-  const bool more = ((uint32_t)w & 0xfff0u) == 0xfff0u || ((mcode << 8) | me) == 0xfffu;
+  const uint32_t me2 = x >> 24;
+  /* a match length may take a second extension byte (274 .. 528 bytes: what a sorted key column consists of); a THIRD
+   * one, or a second one of the literal length (code 15 followed by 255 = bits 4-15 of w all set), sends the batch to
+   * the general parser */
+  const bool m2 = ((mcode << 8) | me) == 0xfffu;
+  const bool more = ((uint32_t)w & 0xfff0u) == 0xfff0u || (m2 && me2 == 255);
   if (wave::ballot(active && more)) {
     return false;
   }
   s.lit_src = active ? lit_src : 0;
   s.lit_len = active ? lit : 0;
   s.match_off = active ? (x & 0xffffu) : 0;
-  s.match_len = active ? mcode + 4 + (mcode == 15 ? me : 0u) : 0;
+  s.match_len = active ? mcode + 4 + (mcode == 15 ? me : 0u) + (m2 ? me2 : 0u) : 0;
   bad = false; /* a token follows every match: last + kFastSpan <= vend */
   return true;
 }

@@ -116,6 +116,10 @@ struct DeltaFn
     const uint32_t lit_total = code >= 60 ? kUnknown : lit_delta + ((0x5320u >> (4 * k2)) & 15u); /* kFuseMax >= 62: always fused */
     return kind == 0 ? lit_total : (0x5320u >> (4 * kind)) & 15u;
   }
+  /* no second look at the positions fast() gave up on: one speculative position in 64 carries a literal tag with length
+   * bytes, so nearly every window would take the branch */
+  static constexpr bool kSecondChance = false;
+  __device__ __forceinline__ uint32_t second(const lzw::InRing&, uint32_t, uint64_t) const { return kUnknown; }
 };
 struct SlowFn
 {

@@ -62,6 +62,8 @@ inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+#define hipStreamNonBlocking 1u
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
 /* events: wall-clock stamps (the harness programs time their launches with them) */
 struct emuEvent { double ms; };
 typedef emuEvent* hipEvent_t;
@@ -75,6 +77,9 @@ inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr)
   return hipSuccess;
 }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+#define hipEventDisableTiming 2u
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; } /* launches run at once */
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->ms - a->ms); return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }

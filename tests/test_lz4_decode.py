@@ -169,6 +169,42 @@ def test_streamed_long_runs(backend, lz_path, oracle):
         check_roundtrip(backend, oracle, raws, blocks, base_misalign=mis)
 
 
+def test_two_byte_length_fields(backend, lz_path, oracle):
+    """Lengths that take a SECOND extension byte -- matches of 274 .. 528 bytes, literal runs of 270 .. 524 -- are what a
+    sorted key column compressed by liblz4 consists of (two literals, 400 bytes at offset 8, 165 times per chunk). The
+    token chase and the batch parser resolve the second byte of a match length themselves (lz4_decode_window.hip.h:
+    DeltaFn::second, parse_fast) and hand everything longer to the general parser: every length around both boundaries, in
+    long chains (many tokens per 256-byte stream window), mixed with short sequences, and at the end of the chunk."""
+    rng = np.random.RandomState(4242)
+    blocks, raws = [], []
+    boundary = [268, 269, 270, 271, 272, 273, 274, 275, 276, 277, 300, 398, 400, 500, 524, 525, 526, 527, 528, 529, 530, 531, 532, 600,
+                783, 784, 785, 1038, 1039, 1040]
+    # chains of one length class each: the shape of the column
+    for k, mlen in enumerate(boundary if backend.name != "emu" else boundary[::3] + [274, 528, 529]):
+        seqs = [(rng.randint(0, 256, size=16).astype(np.uint8).tobytes(), 8, 40)]
+        for j in range(60 if backend.name != "emu" else 14):
+            lit = rng.randint(0, 256, size=(j + k) % 4).astype(np.uint8).tobytes()
+            seqs.append((lit, (1, 2, 4, 8, 16, 3, 24)[(j + k) % 7], mlen + (j % 3 == 2)))
+        tail = rng.randint(0, 256, size=5 + k % 7).astype(np.uint8).tobytes()
+        blocks.append(_lz4_block(seqs, tail))
+        raws.append(_lz4_expand(seqs, tail))
+    # every class mixed, literal runs with two length bytes among them, short sequences in between
+    for k in range(6 if backend.name != "emu" else 2):
+        seqs = [(rng.randint(0, 256, size=40).astype(np.uint8).tobytes(), 5, 9)]
+        for j in range(50 if backend.name != "emu" else 16):
+            mlen = boundary[rng.randint(len(boundary))] if j % 3 else 4 + rng.randint(30)
+            nlit = (0, 1, 2, 14, 15, 16, 269, 270, 271, 300, 523, 524, 525, 526)[rng.randint(14)] if j % 5 == 4 else rng.randint(6)
+            seqs.append((rng.randint(0, 256, size=nlit).astype(np.uint8).tobytes(), 1 + rng.randint(40), mlen))
+        tail = rng.randint(0, 256, size=5 + (270 if k % 2 else 0)).astype(np.uint8).tobytes()
+        blocks.append(_lz4_block(seqs, tail))
+        raws.append(_lz4_expand(seqs, tail))
+    for cc, c in zip(blocks, raws):
+        rc, ref = oracle.lz4_decompress(cc, c.size)
+        assert rc == 0 and np.array_equal(ref, c), "the hand-built block is not what the oracle reads"
+    for mis in (0, 3):
+        check_roundtrip(backend, oracle, raws, blocks, base_misalign=mis)
+
+
 def test_corrupt_streams_do_not_escape(backend, lz_path, oracle):
     """Invalid input -> status != success and size 0 (CHANGELOG.md:160-164); never a write
     outside the output slot (canaries) and, where the oracle accepts, identical bytes."""
