@@ -7,8 +7,8 @@
  * of register j assumes a token starts at position wb + 64 j + l and computes
  * the distance to the token after it (reading the at most two length-extension
  * bytes it needs from the input ring). The real chain is then followed with one
- * v_readlane per sequence. Tokens whose lengths need more than one extension
- * byte (literal runs >= 270, matches >= 274 bytes) take a scalar slow path.
+ * v_readlane per sequence. Tokens with a literal run of 525 bytes or more or a match of
+ * 1 549 or more (a third / a seventh length-extension byte) take a scalar slow path.
  */
 #pragma once
 
@@ -21,13 +21,42 @@ namespace lz4w {
 constexpr uint32_t kUnknown = 1u << 28;
 
 
+/* The 8 (4) stream bytes at virtual position p -- those of them that are resident, the others are whatever the ring
+ * holds there: three (two) aligned dword reads (a misaligned ds_read_b32 is served lane by lane) and a funnel shift. */
+__device__ __forceinline__ uint64_t ring_bytes8(const lzw::InRing& r, uint32_t p)
+{
+  const uint32_t m = lzw::kInRing - 1;
+  const uint32_t a0 = p & ~3u;
+  const uint32_t d0 = *(const uint32_t*)(r.ring + (a0 & m));
+  const uint32_t d1 = *(const uint32_t*)(r.ring + ((a0 + 4) & m));
+  const uint32_t d2 = *(const uint32_t*)(r.ring + ((a0 + 8) & m));
+  const uint32_t lo = wave::align_bytes(d1, d0, p & 3u);
+  const uint32_t hi = wave::align_bytes(d2, d1, p & 3u);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t ring_bytes4(const lzw::InRing& r, uint32_t p)
+{
+  const uint32_t m = lzw::kInRing - 1;
+  const uint32_t a0 = p & ~3u;
+  const uint32_t d0 = *(const uint32_t*)(r.ring + (a0 & m));
+  const uint32_t d1 = *(const uint32_t*)(r.ring + ((a0 + 4) & m));
+  return wave::align_bytes(d1, d0, p & 3u);
+}
+
+/* A length field behind a nibble of 15, its bytes in `f` from bit 0 on (six of them, zeros above): how many of them are
+ * 255 (0 .. 6; 6 = the field goes on behind what f holds) */
+__device__ __forceinline__ uint32_t leading_255(uint64_t f)
+{
+  return (uint32_t)__builtin_ctzll(~f) >> 3; /* bits 48-63 of ~f are set */
+}
+
 /* Distance from a (speculative) token at virtual position p to the next token, with every bound tested: the windows at
  * the edges of the chunk and of the resident stream, and the positions of an interior window whose lengths the
- * straight-line DeltaFn::fast() gave up on. Up to TWO extension bytes per length (literal runs to 524 bytes, matches to
- * 528): a sorted key column compressed by liblz4 -- the reference's published shape -- is all matches of about 400
- * bytes, and with one extension byte every one of its tokens left the chase through the scalar slow path, one
- * enumeration per token (profiles/r03_pmc_mortgage.json: 155 scalar instructions per sequence). Longer fields ->
- * kUnknown -> chase_slow_next(). */
+ * straight-line DeltaFn::fast() gave up on. Up to two extension bytes of the literal length (runs to 524 bytes) and SIX
+ * of the match length (to 1 548 bytes): a sorted key column compressed by liblz4 -- the reference's published shape --
+ * is all matches of 170 .. 680 bytes, and with one extension byte every one of its tokens left the chase through the
+ * scalar slow path, one enumeration per token (profiles/r03_pmc_mortgage.json: 155 scalar instructions per sequence).
+ * Longer fields -> kUnknown -> chase_slow_next(). */
 __device__ __forceinline__ uint32_t token_delta(const lzw::InRing& r, uint32_t p)
 {
   const uint8_t* ring = r.ring;
@@ -42,13 +71,12 @@ __device__ __forceinline__ uint32_t token_delta(const lzw::InRing& r, uint32_t p
   const uint32_t lit_end = p + 1 + (lit_ext ? 1u : 0u) + (lit_ext2 ? 1u : 0u) + lit;
   const bool ends = lit_end >= r.vend; /* literals reach the end of the chunk: the chase stops here */
   const uint32_t mpos = lit_end + 2;   /* where a match-length extension byte would sit */
-  const uint32_t e2 = ring[mpos & m];
-  const uint32_t e3 = ring[(mpos + 1) & m];
   const bool m_ext = (t & 15u) == 15u;
-  const bool m_ext2 = m_ext && e2 == 255;
-  const uint32_t delta = ends ? lit_end - p : mpos + (m_ext ? 1u : 0u) + (m_ext2 ? 1u : 0u) - p;
+  const uint32_t n255 = leading_255(ring_bytes8(r, mpos) & 0xffffffffffffull);
+  const uint32_t mfield = m_ext ? n255 + 1 : 0u; /* bytes of the match length field: trusted below only when resident */
+  const uint32_t delta = ends ? lit_end - p : mpos + mfield - p;
   const bool unknown = p < r.lo || p + 3 > r.hi || p >= r.vend || (lit_ext2 && e1b == 255)
-                       || (!ends && m_ext && (mpos >= r.hi || (e2 == 255 && (mpos + 1 >= r.hi || e3 == 255))));
+                       || (!ends && m_ext && (n255 >= 6 || mpos + n255 >= r.hi));
   return unknown ? kUnknown : delta;
 }
 
@@ -111,8 +139,8 @@ __device__ __forceinline__ uint32_t chase_slow_next(const lzw::InRing& r, uint32
 
 struct DeltaFn
 {
-  /* a delta looks at most this far past its position: token, 2 length bytes, 15 + 254 literals, offset, 2 length bytes */
-  static constexpr uint32_t kReach = 281;
+  /* a delta looks at most this far past its position: token, 2 length bytes, 15 + 254 literals, offset, 8 bytes of length */
+  static constexpr uint32_t kReach = 288;
   __device__ __forceinline__ uint32_t operator()(const lzw::InRing& r, uint32_t p) const { return token_delta(r, p); }
   /* interior window: `w` = the stream bytes from p on (token in bits 0-7, the byte behind it in 8-15) */
   __device__ __forceinline__ uint32_t fast(const lzw::InRing& r, uint32_t p, uint64_t w) const
@@ -130,8 +158,8 @@ struct DeltaFn
     const uint32_t unknown = (lit_ext & (e1 == 255 ? 1u : 0u)) | (m_ext & (e2 == 255 ? 1u : 0u));
     return unknown ? kUnknown : d0 + m_ext;
   }
-  /* the positions fast() gave up on, once more (lzw::chase_build, under a branch of the wave): a match length with a
-   * SECOND extension byte -- 274 .. 528 bytes, every sequence of a sorted key column -- is resolved here; everything
+  /* the positions fast() gave up on, once more (lzw::chase_build, under a branch of the wave): a match length with two
+   * to six extension bytes -- 274 .. 1 548 bytes, every sequence of a sorted key column -- is resolved here; everything
    * longer stays with the scalar walk */
   static constexpr bool kSecondChance = true;
   __device__ __forceinline__ uint32_t second(const lzw::InRing& r, uint32_t p, uint64_t w) const
@@ -141,10 +169,9 @@ struct DeltaFn
     const uint32_t lit_code = t >> 4;
     const bool lit_ext = lit_code == 15;
     const uint32_t d0 = 3 + lit_code + (lit_ext ? e1 + 1u : 0u);
-    const uint32_t e2 = r.ring[(p + d0) & (lzw::kInRing - 1)];
-    const uint32_t e3 = r.ring[(p + d0 + 1) & (lzw::kInRing - 1)];
-    const bool ok = !(lit_ext && e1 == 255) && (t & 15u) == 15u && e2 == 255 && e3 != 255;
-    return ok ? d0 + 2 : kUnknown;
+    const uint32_t n255 = leading_255(ring_bytes8(r, p + d0) & 0xffffffffffffull);
+    const bool ok = !(lit_ext && e1 == 255) && (t & 15u) == 15u && n255 < 6;
+    return ok ? d0 + n255 + 1 : kUnknown;
   }
 };
 struct SlowFn
@@ -246,48 +273,18 @@ __device__ __forceinline__ void parse(const lzw::InRing& r, uint32_t p, bool act
   }
 }
 
-/* The n (< 8) stream bytes at virtual position p, which must be resident with p + 7 below the ring's end of residency:
- * two or three aligned dword reads (a misaligned ds_read_b32 is served lane by lane) and a funnel shift. */
-__device__ __forceinline__ uint64_t ring_bytes8(const lzw::InRing& r, uint32_t p)
-{
-  const uint32_t m = lzw::kInRing - 1;
-  const uint32_t a0 = p & ~3u;
-  const uint32_t d0 = *(const uint32_t*)(r.ring + (a0 & m));
-  const uint32_t d1 = *(const uint32_t*)(r.ring + ((a0 + 4) & m));
-  const uint32_t d2 = *(const uint32_t*)(r.ring + ((a0 + 8) & m));
-  const uint32_t lo = wave::align_bytes(d1, d0, p & 3u);
-  const uint32_t hi = wave::align_bytes(d2, d1, p & 3u);
-  return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint32_t ring_bytes4(const lzw::InRing& r, uint32_t p)
-{
-  const uint32_t m = lzw::kInRing - 1;
-  const uint32_t a0 = p & ~3u;
-  const uint32_t d0 = *(const uint32_t*)(r.ring + (a0 & m));
-  const uint32_t d1 = *(const uint32_t*)(r.ring + ((a0 + 4) & m));
-  return wave::align_bytes(d1, d0, p & 3u);
-}
-
-/* parse() for the common batch, lanes [from, to) (to > from). Whether everything a lane may look at is resident and
- * inside the chunk is decided ONCE for the wave, from the first and the last token position (positions grow with the
- * lane): a sequence without a second length-extension byte spans at most kFastSpan stream bytes. Under that
- * precondition no sequence is the chunk's last one and every field is resident, so the lanes run straight-line code with
- * two predicates in all (a length needing a second extension byte sends the whole batch to the general parser) instead
- * of the dozen lane conditions -- each of them a scalar instruction per && -- the bounds used to cost
- * (profiles/r03_ab_*.jsonl). Returns false (wave-uniform) when the general parser must do the batch. */
-constexpr uint32_t kFastSpan = 289; /* token, length byte, 15 + 254 literals, offset, two length bytes, and the token behind */
-
-__device__ __forceinline__ bool parse_fast(
-    const lzw::InRing& r, uint32_t p, uint32_t from, uint32_t to, lz::Seq& s, bool& bad)
+/* The parser of a batch, lanes [from, to) (to >= from). A lane whose fields are resident and inside the chunk -- the
+ * position of its offset tells: everything it looks at lies within 8 bytes of it -- runs straight-line code: one
+ * extension byte of the literal length, up to six of the match length (to 1 548 bytes; 255 * (the number of leading 255s)
+ * + the byte behind them). The other lanes -- the last sequences of a chunk, a literal run of 270 bytes or more, a
+ * longer match -- go through parse() together afterwards. (Until the middle of round 3 ONE such lane sent the whole
+ * batch to parse(), which finishes a field with a second extension byte one lane after the other: every batch of a
+ * sorted key column -- matches of 170 .. 680 bytes -- and the last 40 sequences of every such chunk.) */
+__device__ __forceinline__ void parse_batch(const lzw::InRing& r, uint32_t p, uint32_t from, uint32_t to, lz::Seq& s, bool& bad)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
-  const uint32_t first = wave::read_lane(p, from);
-  const uint32_t last = wave::read_lane(p, to - 1);
-  const uint32_t lim = r.hi < r.vend ? r.hi : r.vend;
-  if (first < r.lo || last + kFastSpan > lim) {
-    return false;
-  }
   const bool active = lane - from < to - from;
+  const uint32_t lim = r.hi < r.vend ? r.hi : r.vend;
   const uint64_t w = ring_bytes8(r, p); /* a lane outside [from, to) reads somewhere inside the ring: harmless */
   const uint32_t t = (uint32_t)w & 0xffu;
   const uint32_t e1 = (uint32_t)(w >> 8) & 0xffu;
@@ -296,24 +293,32 @@ __device__ __forceinline__ bool parse_fast(
   const uint32_t lit = code + (lit_ext ? e1 : 0u);
   const uint32_t lit_src = p + 1 + (lit_ext ? 1u : 0u);
   const uint32_t q = lit_src + lit; /* the offset */
-  const uint32_t x = ring_bytes4(r, q);
+  const uint64_t x = ring_bytes8(r, q);
   const uint32_t mcode = t & 15u;
-  const uint32_t me = (x >> 16) & 0xffu;
-  const uint32_t me2 = x >> 24;
-  /* a match length may take a second extension byte (274 .. 528 bytes: what a sorted key column consists of); a THIRD
-   * one, or a second one of the literal length (code 15 followed by 255 = bits 4-15 of w all set), sends the batch to
-   * the general parser */
-  const bool m2 = ((mcode << 8) | me) == 0xfffu;
-  const bool more = ((uint32_t)w & 0xfff0u) == 0xfff0u || (m2 && me2 == 255);
-  if (wave::ballot(active && more)) {
-    return false;
+  const uint64_t f = x >> 16; /* the match length field, if there is one */
+  const uint32_t n255 = leading_255(f);
+  const uint32_t mext = 255u * n255 + ((uint32_t)(f >> (8 * n255)) & 0xffu);
+  /* not for this path: a second extension byte of the literal length (code 15 followed by 255 = bits 4-15 of w all
+   * set), a seventh of the match length, fields that are not resident or reach the end of the chunk (q + 8 < vend also
+   * says that a token follows the match) */
+  const bool lit2 = ((uint32_t)w & 0xfff0u) == 0xfff0u;
+  const bool straight = !lit2 && n255 < 6 && p >= r.lo && q + 8 < lim;
+  const bool mine = active && straight;
+  s.lit_src = mine ? lit_src : 0;
+  s.lit_len = mine ? lit : 0;
+  s.match_off = mine ? ((uint32_t)x & 0xffffu) : 0;
+  s.match_len = mine ? mcode + 4 + (mcode == 15 ? mext : 0u) : 0;
+  bad = false;
+  const uint64_t rest = wave::ballot(active && !straight);
+  if (rest) {
+    lz::Seq g;
+    bool gbad;
+    parse(r, p, wave::lane_in(rest), g, gbad);
+    if (wave::lane_in(rest)) {
+      s = g;
+      bad = gbad;
+    }
   }
-  s.lit_src = active ? lit_src : 0;
-  s.lit_len = active ? lit : 0;
-  s.match_off = active ? (x & 0xffffu) : 0;
-  s.match_len = active ? mcode + 4 + (mcode == 15 ? me : 0u) + (m2 ? me2 : 0u) : 0;
-  bad = false; /* a token follows every match: last + kFastSpan <= vend */
-  return true;
 }
 
 /* Decode one chunk with the calling wave; `lds` is this wave's kLdsPerWave bytes. */
@@ -374,9 +379,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
     if (refill || !NVCOMP_LZ4W_KEEP_PARSED) {
       lz::Seq fresh;
       bool bad;
-      if (count <= before || !parse_fast(ir, seqpos, before, count, fresh, bad)) {
-        parse(ir, seqpos, lane >= before && lane < count, fresh, bad);
-      }
+      parse_batch(ir, seqpos, before, count, fresh, bad);
       LZW_T(3);
       if (lane >= before) {
         s = fresh;
@@ -452,9 +455,7 @@ __device__ __forceinline__ void produce(const uint8_t* __restrict__ in, uint32_t
       lzw::in_ensure(ir, c.q, (c.q & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
       uint32_t seqpos = 0;
       count = lzw::chase_tokens(c, ir, seqpos, 0, DeltaFn(), SlowFn());
-      if (count == 0 || !parse_fast(ir, seqpos, 0, count, s, bad)) {
-        parse(ir, seqpos, lane < count, s, bad);
-      }
+      parse_batch(ir, seqpos, 0, count, s, bad);
     }
     const uint32_t flags = (last ? kFlagLast : 0u) | (wave::ballot(bad) ? kFlagBad : 0u);
     while (poll(sh.state + k) != 0) {

@@ -170,17 +170,18 @@ def test_streamed_long_runs(backend, lz_path, oracle):
 
 
 def test_two_byte_length_fields(backend, lz_path, oracle):
-    """Lengths that take a SECOND extension byte -- matches of 274 .. 528 bytes, literal runs of 270 .. 524 -- are what a
-    sorted key column compressed by liblz4 consists of (two literals, 400 bytes at offset 8, 165 times per chunk). The
-    token chase and the batch parser resolve the second byte of a match length themselves (lz4_decode_window.hip.h:
-    DeltaFn::second, parse_fast) and hand everything longer to the general parser: every length around both boundaries, in
-    long chains (many tokens per 256-byte stream window), mixed with short sequences, and at the end of the chunk."""
+    """Lengths that take a second, third, ... extension byte -- matches of 274 bytes and more, literal runs of 270 and more
+    -- are what a sorted key column compressed by liblz4 consists of (two literals, 170 .. 680 bytes at offset 8, 165 times
+    per chunk). The token chase and the batch parser resolve up to six extension bytes of a match length themselves
+    (lz4_decode_window.hip.h: DeltaFn::second, parse_batch) and hand everything longer to the general parser: every length
+    around every boundary, in long chains (many tokens per 256-byte stream window), mixed with short sequences, and at
+    the end of the chunk."""
     rng = np.random.RandomState(4242)
     blocks, raws = [], []
     boundary = [268, 269, 270, 271, 272, 273, 274, 275, 276, 277, 300, 398, 400, 500, 524, 525, 526, 527, 528, 529, 530, 531, 532, 600,
-                783, 784, 785, 1038, 1039, 1040]
+                783, 784, 785, 1038, 1039, 1040, 1293, 1294, 1547, 1548, 1549, 1550, 1803, 1804, 2500]
     # chains of one length class each: the shape of the column
-    for k, mlen in enumerate(boundary if backend.name != "emu" else boundary[::3] + [274, 528, 529]):
+    for k, mlen in enumerate(boundary if backend.name != "emu" else boundary[::3] + [274, 528, 529, 1548, 1549]):
         seqs = [(rng.randint(0, 256, size=16).astype(np.uint8).tobytes(), 8, 40)]
         for j in range(60 if backend.name != "emu" else 14):
             lit = rng.randint(0, 256, size=(j + k) % 4).astype(np.uint8).tobytes()
