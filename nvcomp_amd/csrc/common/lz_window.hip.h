@@ -826,9 +826,12 @@ __device__ __forceinline__ void copy_to_lds(uint8_t* dst, const uint8_t* src, ui
 constexpr uint32_t kStreamLit = NVCOMP_LZW_STREAM_LIT;
 constexpr uint32_t kStreamMatch = NVCOMP_LZW_STREAM_MATCH;
 
-/* dst[0, n) = src[0, n): different buffers or src at least 4 KiB in front of dst; any alignment. The stores are 16-byte
- * aligned, four loads of 1 KiB are in flight before the first store (one load -> store round trip per KiB made a
- * 64 KiB literal run latency-bound at 2 TB/s of copy traffic). */
+/* dst[0, n) = src[0, n): different buffers or src at least 8 KiB in front of dst; any alignment. The stores are 16-byte
+ * aligned and non-temporal, four loads of 1 KiB are in flight before the first store (one load -> store round trip per KiB
+ * made a 64 KiB literal run latency-bound at 2 TB/s of copy traffic), and the next four are issued BEFORE the stores of
+ * the four in hand. scripts/probes/copy_bench.hip (16 384 runs of 64 KiB, the decoders' launch shape): load-then-store
+ * 2 380 GB/s -- the very rate the decoder had on incompressible chunks --, with the loads ahead 2 500, with non-temporal
+ * stores as well 2 615; hipMemcpyAsync device-to-device 2 499. */
 __device__ __forceinline__ void stream_copy(uint8_t* dst, const uint8_t* src, uint32_t n)
 {
   const uint32_t lane = (uint32_t)wave::fresh_lane_id();
@@ -839,14 +842,25 @@ __device__ __forceinline__ void stream_copy(uint8_t* dst, const uint8_t* src, ui
   }
   const uint32_t body_end = h + ((n - h) & ~15u); /* the 16-byte blocks end here */
   uint32_t base = h;
-  for (; base + 4096 <= body_end; base += 4096) {
-    const uint32_t at = base + 16 * lane;
-    const wave::u32x4 a = wave::gload_u32x4(src + at), b = wave::gload_u32x4(src + at + 1024);
-    const wave::u32x4 c = wave::gload_u32x4(src + at + 2048), d = wave::gload_u32x4(src + at + 3072);
-    wave::gstore_u32x4_aligned(dst + at, a);
-    wave::gstore_u32x4_aligned(dst + at + 1024, b);
-    wave::gstore_u32x4_aligned(dst + at + 2048, c);
-    wave::gstore_u32x4_aligned(dst + at + 3072, d);
+  if (base + 4096 <= body_end) {
+    uint32_t at = base + 16 * lane;
+    wave::u32x4 a = wave::gload_u32x4(src + at), b = wave::gload_u32x4(src + at + 1024);
+    wave::u32x4 c = wave::gload_u32x4(src + at + 2048), d = wave::gload_u32x4(src + at + 3072);
+    for (base += 4096; base + 4096 <= body_end; base += 4096) {
+      const uint32_t nx = base + 16 * lane;
+      const wave::u32x4 a2 = wave::gload_u32x4(src + nx), b2 = wave::gload_u32x4(src + nx + 1024);
+      const wave::u32x4 c2 = wave::gload_u32x4(src + nx + 2048), d2 = wave::gload_u32x4(src + nx + 3072);
+      wave::gstore_u32x4_aligned_nt(dst + at, a);
+      wave::gstore_u32x4_aligned_nt(dst + at + 1024, b);
+      wave::gstore_u32x4_aligned_nt(dst + at + 2048, c);
+      wave::gstore_u32x4_aligned_nt(dst + at + 3072, d);
+      a = a2, b = b2, c = c2, d = d2;
+      at = nx;
+    }
+    wave::gstore_u32x4_aligned_nt(dst + at, a);
+    wave::gstore_u32x4_aligned_nt(dst + at + 1024, b);
+    wave::gstore_u32x4_aligned_nt(dst + at + 2048, c);
+    wave::gstore_u32x4_aligned_nt(dst + at + 3072, d);
   }
   for (; base < body_end; base += 1024) {
     const uint32_t at = base + 16 * lane;

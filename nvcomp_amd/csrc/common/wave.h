@@ -70,6 +70,11 @@ __device__ __forceinline__ void gstore_u32x4_aligned(uint8_t* p, u32x4 v)
 {
   *(WAVE_GLOBAL u32x4*)p = v;
 }
+/* the same, non-temporal: for output that nothing on the card reads again soon (a streamed literal run) */
+__device__ __forceinline__ void gstore_u32x4_aligned_nt(uint8_t* p, u32x4 v)
+{
+  __builtin_nontemporal_store(v, (WAVE_GLOBAL u32x4*)p);
+}
 __device__ __forceinline__ void gstore_u32x4(uint8_t* p, u32x4 v) /* any alignment (global_store_dwordx4) */
 {
   WAVE_GLOBAL PackedU32x4* q = (WAVE_GLOBAL PackedU32x4*)p;

@@ -134,6 +134,7 @@ inline uint64_t gload_u64(const uint8_t* p)
 inline uint32_t gload_u16(const uint16_t* p) { return *p; }
 inline void gstore_u8(uint8_t* p, uint32_t v) { *p = (uint8_t)v; }
 inline void gstore_u32x4_aligned(uint8_t* p, u32x4 v) { *(u32x4*)p = v; }
+inline void gstore_u32x4_aligned_nt(uint8_t* p, u32x4 v) { *(u32x4*)p = v; }
 inline void gstore_u32(uint8_t* p, uint32_t v) { memcpy(p, &v, 4); }
 inline void gstore_u32x4(uint8_t* p, u32x4 v) { memcpy(p, &v, 16); }
 
