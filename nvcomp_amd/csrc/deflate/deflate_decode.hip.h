@@ -52,8 +52,20 @@ constexpr uint32_t kDistLutBits = 8;
 constexpr uint32_t kClLutBits = 7; /* the code-length code: at most 7 bits, always decoded by lookup */
 constexpr uint32_t kRunMax = 255;  /* literal bytes per sequence record (8 bits of the record) */
 constexpr uint32_t kRunClose = 192; /* a pending run this long is closed as a record of its own between rounds */
-constexpr uint32_t kScanWin = 256;   /* bit positions one speculative window covers */
-constexpr uint32_t kScanLevels = 5;  /* jump tables for 1, 2, 4, 8, 16 symbols ahead: 32 symbols per enumeration */
+/* 512 positions per window (8 per lane) halve the table builds and cut the enumerations by a third (counted on the host
+ * emulation: 2.3 -> 1.16 builds and 3.7 -> 2.6 enumerations per round of 49 symbols) and change NOTHING on the card
+ * (profiles/r03_deflate_scan.jsonl: 66.6 vs 66.6 GB/s at 1 GiB, 79.3 vs 80.3 at 4 GiB): the decoder is bound by the
+ * NUMBER of instructions per symbol -- 17 vector + 14 scalar, of which the speculative decode of every bit position is
+ * the largest part and does not depend on the window -- not by the length of its dependent chains. 256 keeps the
+ * LDS at 10 KiB per wave. */
+#ifndef NVCOMP_DEFLATE_SCAN_WIN
+#define NVCOMP_DEFLATE_SCAN_WIN 256
+#endif
+constexpr uint32_t kScanWin = NVCOMP_DEFLATE_SCAN_WIN; /* bit positions one speculative window covers: 256 or 512 */
+constexpr uint32_t kScanPer = kScanWin / 64;            /* ... of which a lane decodes this many (consecutive ones) */
+constexpr uint32_t kScanLevels = 5;  /* jump tables for 1, 2, 4, 8, 16 symbols ahead; an enumeration follows them for 64 */
+static_assert(kScanPer == 4 || kScanPer == 8, "a lane's table entries are one or two dwords");
+constexpr uint32_t kTopBias = 64;    /* the 16-symbol table holds distances of 64 .. 318 bits, minus this */
 
 /* ---- LDS of one wave, behind the executor's window and the stream ring ---- */
 constexpr uint32_t kOffLit = 0;                                  /* literal ring: lzw::kInLds bytes */
@@ -467,46 +479,82 @@ __device__ __forceinline__ uint32_t uniform_symbol(
 struct Scan
 {
   uint32_t wb;    /* bit position of window slot 0 */
-  uint32_t nx[4]; /* lane l: bits the symbol at wb + 4 l + k would take (0 = the lookups cannot tell) */
+  uint32_t nx[kScanPer / 4]; /* lane l: bits the symbol at wb + kScanPer l + k would take, a byte each (0 = the lookups cannot tell) */
   uint8_t* tab;   /* LDS: kScanLevels tables of kScanWin bytes */
   bool built;     /* the tables are those of this block's codes */
 };
 
 /* Tables of the window that starts at bit position q: J_i[p] = bits from p to the 2^i-th symbol after it (255 = it
- * leaves the window, or a symbol on the way cannot be told). lz_window.hip.h: chase_build, on bit positions. */
+ * leaves the window, a symbol on the way cannot be told, or the sum does not fit a byte). lz_window.hip.h: chase_build,
+ * on bit positions. */
 __device__ __forceinline__ void scan_build(Scan& c, const lzw::InRing& ir, const Code& ll, const Code& dd, uint32_t q)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   c.wb = q;
   c.built = true;
-  const uint32_t p0 = q + 4 * lane;
+  const uint32_t p0 = q + kScanPer * lane;
   const uint32_t a0 = (p0 >> 5) << 2;
   const uint32_t s0 = p0 & 31u;
   const uint32_t d0 = *(const uint32_t*)(ir.ring + (a0 & (lzw::kInRing - 1)));
   const uint32_t d1 = *(const uint32_t*)(ir.ring + ((a0 + 4) & (lzw::kInRing - 1)));
   const uint32_t d2 = *(const uint32_t*)(ir.ring + ((a0 + 8) & (lzw::kInRing - 1)));
   const uint64_t lo64 = ((uint64_t)d1 << 32) | d0;
-  uint32_t a[4];
+  uint32_t a[kScanPer], nx[kScanPer];
 #pragma unroll
-  for (uint32_t k = 0; k < 4; ++k) {
-    const uint32_t s = s0 + k; /* <= 34 */
+  for (uint32_t k = 0; k < kScanPer; ++k) {
+    const uint32_t s = s0 + k; /* <= 38: 58 bits at least, a symbol takes 48 at most */
     const uint64_t w = s ? (lo64 >> s) | ((uint64_t)d2 << (64 - s)) : lo64;
     uint32_t value, dist;
-    c.nx[k] = decode_at(ll, dd, w, value, dist);
-    a[k] = c.nx[k] != 0 && 4 * lane + k + c.nx[k] < kScanWin ? c.nx[k] : 255u;
+    nx[k] = decode_at(ll, dd, w, value, dist);
+    a[k] = nx[k] != 0 && kScanPer * lane + k + nx[k] < kScanWin ? nx[k] : 255u;
   }
-  uint32_t a01 = a[0] | (a[1] << 16), a23 = a[2] | (a[3] << 16);
-  *(uint32_t*)(c.tab + 4 * lane) = wave::perm_bytes(a23, a01, 0x06040200u);
+  /* the distances of a lane travel as dwords of two 16-bit lanes (positions 0|1, 2|3, ...): a doubling round is a packed
+   * add + a packed saturation per pair, and one byte permute per four positions packs the table words */
+  uint32_t pa[kScanPer / 2];
+#pragma unroll
+  for (uint32_t j = 0; j < kScanPer / 2; ++j) {
+    pa[j] = a[2 * j] | (a[2 * j + 1] << 16);
+  }
+#pragma unroll
+  for (uint32_t j = 0; j < kScanPer / 4; ++j) {
+    c.nx[j] = nx[4 * j] | (nx[4 * j + 1] << 8) | (nx[4 * j + 2] << 16) | (nx[4 * j + 3] << 24);
+    *(uint32_t*)(c.tab + kScanPer * lane + 4 * j) = wave::perm_bytes(pa[2 * j + 1], pa[2 * j], 0x06040200u);
+  }
   wave::sync();
 #pragma unroll
   for (uint32_t i = 1; i < kScanLevels; ++i) {
-    const uint8_t* prev = c.tab + (i - 1) * kScanWin + 4 * lane;
-    /* a == 255 reads past its table (into the next one, or the 3 bytes behind the last): the sum saturates anyway */
-    const uint32_t g0 = prev[0 + (a01 & 0xffffu)], g1 = prev[1 + (a01 >> 16)];
-    const uint32_t g2 = prev[2 + (a23 & 0xffffu)], g3 = prev[3 + (a23 >> 16)];
-    a01 = wave::pk_add_sat255(a01, g0 | (g1 << 16));
-    a23 = wave::pk_add_sat255(a23, g2 | (g3 << 16));
-    *(uint32_t*)(c.tab + i * kScanWin + 4 * lane) = wave::perm_bytes(a23, a01, 0x06040200u);
+    const uint8_t* prev = c.tab + (i - 1) * kScanWin + kScanPer * lane;
+    /* a == 255 reads past its table (into the next one): the sum saturates anyway */
+    uint32_t g[kScanPer];
+#pragma unroll
+    for (uint32_t k = 0; k < kScanPer; ++k) {
+      g[k] = prev[k + ((pa[k / 2] >> (16 * (k & 1u))) & 0xffffu)];
+    }
+    if (i + 1 < kScanLevels) {
+#pragma unroll
+      for (uint32_t j = 0; j < kScanPer / 2; ++j) {
+        pa[j] = wave::pk_add_sat255(pa[j], g[2 * j] | (g[2 * j + 1] << 16));
+      }
+    } else {
+      /* the top table (16 symbols ahead) holds the distance MINUS kTopBias: sixteen symbols of a zlib stream take 190 bits
+       * on average and often more than a byte can say (matches are 20 to 48 bits each), and an entry that saturates ends
+       * the enumeration at its rank */
+#pragma unroll
+      for (uint32_t j = 0; j < kScanPer / 2; ++j) {
+        uint32_t both = 0;
+#pragma unroll
+        for (uint32_t h = 0; h < 2; ++h) {
+          const uint32_t x = (pa[j] >> (16 * h)) & 0xffffu, y = g[2 * j + h];
+          const uint32_t sum = x + y - kTopBias; /* wraps when the sum is below the bias */
+          both |= (x != 255u && y != 255u && sum < 255u ? sum : 255u) << (16 * h);
+        }
+        pa[j] = both;
+      }
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kScanPer / 4; ++j) {
+      *(uint32_t*)(c.tab + i * kScanWin + kScanPer * lane + 4 * j) = wave::perm_bytes(pa[2 * j + 1], pa[2 * j], 0x06040200u);
+    }
     wave::sync();
   }
 }
@@ -528,31 +576,46 @@ __device__ __forceinline__ uint32_t scan_round(
   const uint32_t cap = 64 - f.n; /* a symbol makes at most one record */
   while (t < cap) {
     if (!c.built || q - c.wb >= kScanWin) {
-      if ((q >> 3) + 64 > ir.hi && ir.hi < ir.vend) {
+      if ((q >> 3) + kScanWin / 8 + 32 > ir.hi && ir.hi < ir.vend) {
         break; /* the window would look at bytes that are not resident yet */
       }
       scan_build(c, ir, ll, dd, q);
+      LZ_STAT("deflate_builds", 1);
     }
-    /* lane n < 32: the n-th symbol from q, if the chain gets there inside this window */
-    uint32_t pos = q - c.wb;
-    bool valid = lane < (1u << kScanLevels);
+    /* Lane n: the n-th symbol from q, if the chain gets there inside this window. Lane arithmetic only (lz_window.hip.h:
+     * chase_tokens): a lane follows the levels named by the bits of n; a level it does not take adds 0; 255 poisons the
+     * lane through `worst`; the position wraps inside the table. Ranks 32 and up start at the 32nd symbol, two steps of the
+     * 16-symbol table from the start (every lane reads the same two bytes). */
+    const uint32_t pos0 = q - c.wb;
+    const uint32_t top = (kScanLevels - 1) * kScanWin;
+    const uint32_t t1 = c.tab[top + pos0];
+    const uint32_t t2 = c.tab[top + ((pos0 + t1 + kTopBias) & (kScanWin - 1))];
+    const bool upper = (lane & 32u) != 0;
+    uint32_t pos = upper ? (pos0 + t1 + t2 + 2 * kTopBias) & (kScanWin - 1) : pos0;
+    uint32_t worst = upper ? (t1 > t2 ? t1 : t2) : 0u;
 #pragma unroll
     for (uint32_t i = 0; i < kScanLevels; ++i) {
       const uint32_t a = c.tab[i * kScanWin + pos];
-      const bool step = valid && ((lane >> i) & 1u) != 0;
-      const bool out = step && a == 255u;
-      valid = valid && !out;
-      pos += step && !out ? a : 0u;
+      const uint32_t take_it = (uint32_t)(-(int32_t)((lane >> i) & 1u));
+      const uint32_t adv = a & take_it;
+      worst = adv > worst ? adv : worst;
+      pos = (pos + adv + (i + 1 == kScanLevels ? kTopBias & take_it : 0u)) & (kScanWin - 1);
     }
-    uint32_t count = wave::popc64(wave::ballot(valid)); /* a prefix of the lanes; lane 0 always */
+    /* Every n appears in exactly one lane; lane 0 is always valid. The valid n are NOT always a prefix here: a jump of 8 or
+     * 16 symbols can be 255 bits and more (long matches take 20 to 48 bits each) without leaving a window of 512, and the
+     * byte tables cannot say so -- the lanes behind the first such rank wait for the next enumeration, which starts at it. */
+    const uint64_t invalid = ~wave::ballot(worst != 255u);
+    uint32_t count = invalid ? wave::ctz64(invalid) : 64u;
     /* the chain's last symbol in hand: its own length says where to go on */
     const uint32_t last = wave::read_lane(pos, count - 1);
-    const uint32_t sel = last & 3u;
-    const uint32_t v = sel == 0 ? c.nx[0] : sel == 1 ? c.nx[1] : sel == 2 ? c.nx[2] : c.nx[3];
-    uint32_t d = wave::read_lane(v, last >> 2);
+    const uint32_t word = kScanPer == 8 && (last & 4u) ? c.nx[kScanPer / 4 - 1] : c.nx[0];
+    uint32_t d = (wave::read_lane(word, last / kScanPer) >> (8 * (last & 3u))) & 0xffu;
     uint32_t uval = 0, udist = 0;
     bool resolved = false;
+    LZ_STAT("deflate_enumerations", 1);
+    LZ_STAT("deflate_enumerated_symbols", count);
     if (d == 0) { /* the lookups could not tell: a long code is walked here, the chain goes on */
+      LZ_STAT("deflate_uniform_symbols", 1);
       d = uniform_symbol(ir, ll, dd, c.wb + last, uval, udist);
       resolved = d != 0;
       if (!resolved) {
@@ -584,6 +647,8 @@ __device__ __forceinline__ uint32_t scan_round(
   if (t == 0) {
     return q;
   }
+  LZ_STAT("deflate_rounds", 1);
+  LZ_STAT("deflate_round_symbols", t);
   /* ---- lane k decodes symbol k ---- */
   uint32_t value = 0, dist = 0;
   const bool mine0 = lane < t;
@@ -720,7 +785,9 @@ __device__ __forceinline__ uint32_t decode_chunk(
 
   Scan sc;
   sc.wb = 0, sc.built = false, sc.tab = front + kOffScan;
-  sc.nx[0] = sc.nx[1] = sc.nx[2] = sc.nx[3] = 0;
+  for (uint32_t j = 0; j < kScanPer / 4; ++j) {
+    sc.nx[j] = 0;
+  }
   Bits b;
   lzw::in_ensure(ir, start, (start & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
   b.seek(ir, start);
