@@ -6,11 +6,14 @@
  * The reference moves the bytes between NVMe and device memory with cuFile (GPUDirect Storage). This image has no
  * hipFile / GDS driver, so the file side goes through two pinned host buffers: O_DIRECT pread / pwrite of one 8 MiB
  * piece overlaps the hipMemcpyAsync of the other (the page cache is bypassed either way; a peer-to-peer DMA path
- * drops in where `transfer()` is). Usage: nvcomp_storage <filename> [bytes]
+ * drops in where `transfer()` is). The phases carry roctx ranges where the reference has NVTX ranges
+ * (nvcomp_gds.cu:54,129-280): `rocprofv3 --marker-trace -- nvcomp_storage ...` shows them; libroctx64 is looked up at
+ * run time, without it the ranges are no-ops. Usage: nvcomp_storage <filename> [bytes]
  */
 #ifndef _GNU_SOURCE
 #define _GNU_SOURCE
 #endif
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <unistd.h>
 
@@ -39,6 +42,32 @@ __global__ void compare(const uint8_t* a, const uint8_t* b, int* invalid, size_t
     }
   }
 }
+
+/* roctxRangePushA / roctxRangePop of libroctx64.so (ROCm's NVTX), resolved at run time */
+struct Ranges
+{
+  int (*push_fn)(const char*) = nullptr;
+  int (*pop_fn)() = nullptr;
+  Ranges()
+  {
+    if (void* h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_GLOBAL)) {
+      push_fn = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+      pop_fn = (int (*)())dlsym(h, "roctxRangePop");
+    }
+  }
+  void push(const char* name) const
+  {
+    if (push_fn && pop_fn) {
+      push_fn(name);
+    }
+  }
+  void pop() const
+  {
+    if (push_fn && pop_fn) {
+      pop_fn();
+    }
+  }
+};
 
 constexpr size_t kPiece = 8u << 20; /* multiple of 4096 */
 
@@ -98,6 +127,8 @@ int main(int argc, char** argv)
     printf("Using device: %s%s\n", prop.name, direct ? "" : " (file system without O_DIRECT: buffered I/O)");
     const size_t n = argc > 2 ? strtoull(argv[2], nullptr, 10) : 100000000;
 
+    const Ranges ranges;
+    ranges.push("Compressor setup");
     uint8_t *d_input, *d_output, *d_compressed;
     hipStream_t stream, io[2];
     HIP_CHECK(hipMalloc((void**)&d_input, n));
@@ -115,22 +146,28 @@ int main(int argc, char** argv)
     size_t lcompbuf = comp_config.max_compressed_buffer_size;
     lcompbuf = ((lcompbuf - 1) / 4096 + 1) * 4096; /* O_DIRECT wants whole 4 KiB blocks */
     HIP_CHECK(hipMalloc((void**)&d_compressed, lcompbuf));
+    ranges.pop();
 
+    ranges.push("Compression");
     compressor.compress(d_input, d_compressed, comp_config);
     const size_t compressed_size = compressor.get_compressed_output_size(d_compressed);
     const size_t aligned = ((compressed_size - 1) / 4096 + 1) * 4096;
     printf("Data compressed from %zu Bytes to %zu Bytes, aligned to %zu Bytes\n", n, compressed_size, aligned);
+    ranges.pop();
 
+    ranges.push("File write");
     ssize_t nb = transfer(fd, d_compressed, aligned, true, io, pinned);
     if (nb != (ssize_t)aligned) {
       printf("Error, write returned %zd instead of %zu\n", nb, aligned);
       return -1;
     }
     printf("Wrote %zd bytes to file %s\n", nb, filename);
+    ranges.pop();
 
     HIP_CHECK(hipMemsetAsync(d_compressed, 0xff, compressed_size, stream)); /* nothing of the compressed data survives on the device */
     HIP_CHECK(hipStreamSynchronize(stream));
 
+    ranges.push("File read");
     nb = transfer(fd, d_compressed, aligned, false, io, pinned);
     if (nb != (ssize_t)aligned) {
       printf("Error, read returned %zd instead of %zu\n", nb, aligned);
@@ -139,7 +176,9 @@ int main(int argc, char** argv)
     HIP_CHECK(hipStreamSynchronize(io[0]));
     HIP_CHECK(hipStreamSynchronize(io[1]));
     printf("Read %zd bytes from file %s\n", nb, filename);
+    ranges.pop();
 
+    ranges.push("Decompression");
     /* a fresh manager, configured from the bytes that came back from the file */
     const DecompressionConfig decomp_config = compressor.configure_decompression(d_compressed);
     if (decomp_config.decomp_data_size != n) {
@@ -154,6 +193,7 @@ int main(int argc, char** argv)
     hipLaunchKernelGGL(compare, dim3(2 * (unsigned)prop.multiProcessorCount), dim3(1024), 0, stream, d_input, d_output, dh_invalid, n);
     HIP_CHECK(hipStreamSynchronize(stream));
     const bool ok = *dh_invalid == 0;
+    ranges.pop();
     printf(ok ? "PASSED: Uncompressed data is identical to the input\n" : "FAILED: Uncompressed data does not match the original\n");
     close(fd);
     unlink(filename);

@@ -326,10 +326,11 @@ __device__ __forceinline__ uint32_t count_heads(const T* A, uint32_t c)
   return m;
 }
 
-/* RLE of A[0..c) -> values in B, run lengths in runs; returns the new count. */
+/* RLE of A[0..c) -> values in B, run lengths in runs; returns the new count. B == A is allowed (compaction in place).
+ * lengths_if_runs: the caller drops the run stream of a layer that found no runs (every length is 1), so the second pass
+ * -- start indices to lengths, as long as the first on run-poor data such as float columns -- is skipped for it. */
 template <typename T>
-/* B == A is allowed (compaction in place). */
-__device__ __forceinline__ uint32_t rle_encode(const T* A, uint32_t c, T* B, uint16_t* runs, uint32_t cap)
+__device__ __forceinline__ uint32_t rle_encode(const T* A, uint32_t c, T* B, uint16_t* runs, uint32_t cap, bool lengths_if_runs = false)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   uint32_t m = 0;
@@ -364,6 +365,9 @@ __device__ __forceinline__ uint32_t rle_encode(const T* A, uint32_t c, T* B, uin
     wave::sync();
   }
   wave::sync();
+  if (lengths_if_runs && m == c) {
+    return m;
+  }
   /* pass 2: start indices -> run lengths (start of the next run minus own start) */
   for (uint32_t base = 0; base < m; base += 64) {
     const uint32_t j = base + lane;
@@ -698,7 +702,7 @@ __device__ __forceinline__ uint32_t compress_sub(
   const T* cur = in; /* HBM until layer 0 (or a delta) has put the data into V */
   for (uint32_t l = 0; l < layers && !raw; ++l) {
     if (l < rl) {
-      const uint32_t m = rle_encode(cur, c, V, pool, pool_cap);
+      const uint32_t m = rle_encode(cur, c, V, pool, pool_cap, can_skip);
       bool id;
       if (m == kRleOverflow) {
         /* a partial compaction may have overwritten the head of V: only an input still in HBM can be recounted */

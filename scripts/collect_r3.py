@@ -44,7 +44,7 @@ def main():
         if os.path.exists(p):
             d = json.load(open(p))
             if key:
-                pmc[key] = d.get("lz4", d)
+                pmc[key] = d.get("lz4") or next(iter(d.values()))
             else:
                 pmc.update(d)
     json.dump(pmc, open(os.path.join(dst, prefix + "_pmc.json"), "w"), indent=1)
