@@ -898,11 +898,17 @@ def main():
         import nvcomp_amd
         lib = nvcomp_amd.load_library()
         slots = (ctypes.c_ulonglong * 16)()
-        if hasattr(lib, "nvcompAmdProfRead") and lib.nvcompAmdProfRead(slots, 16) > 0:
+        names = ["in_ensure", "chase_build", "chase_enum", "parse", "exec_prep", "make_room", "literals_4_32",
+                 "far_store", "match_rounds", "flush", "loop_top", "far_issue", "literals_1_3", "literals_long",
+                 "matches_whole_wave", "-"]
+        reader = "nvcompAmdProfRead"
+        if args.algo == "deflate":  # scripts/build_deflate_variant.sh dprof -DNVCOMP_LZW_PROF: the front end's phases + the executor's
+            reader = "nvcompAmdProfReadDeflate"
+            for i, n in ((0, "headers_and_code_tables"), (1, "window_tables"), (2, "enumerations"), (3, "round_decode_and_records"),
+                         (10, "symbols_one_at_a_time"), (15, "front_end_rest")):
+                names[i] = n
+        if hasattr(lib, reader) and getattr(lib, reader)(slots, 16) > 0:
             tot = float(sum(slots)) or 1.0
-            names = ["in_ensure", "chase_build", "chase_enum", "parse", "exec_prep", "make_room", "literals_4_32",
-                     "far_store", "match_rounds", "flush", "loop_top", "far_issue", "literals_1_3", "literals_long",
-                     "matches_whole_wave", "-"]
             print(json.dumps({"phase_share": {n: round(v / tot, 4) for n, v in zip(names, slots)},
                               "cycles_total": tot}), file=sys.stderr, flush=True)
     ctx["rt"].shutdown()

@@ -59,7 +59,13 @@ __global__ void __launch_bounds__(64 * kDecWaves, kDecWavesPerSimd) deflate_deco
   if (in_len64 > (1u << 28)) {
     err = lz::kErrInput;
   } else {
+#ifdef NVCOMP_LZW_PROF
+    lzw::prof_begin();
+#endif
     produced = deflate::decode_chunk<true, false>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds[w], FLAGS, err);
+#ifdef NVCOMP_LZW_PROF
+    lzw::prof_end();
+#endif
   }
   if (wave::lane_id() == 0) {
     if (actual_bytes != nullptr) {
@@ -367,3 +373,22 @@ nvcompStatus_t nvcompBatchedDeflateCompressAsync(
 }
 
 } // extern "C"
+
+#ifdef NVCOMP_LZW_PROF
+/* Profiling builds only (scripts/build_deflate_variant.sh dprof -DNVCOMP_LZW_PROF): read (and clear) the per-phase cycle sums of
+ * the DEFLATE decoder. Slots 4-9, 11-14: the batch executor's (bench.py names them); 0 = block headers and code tables,
+ * 1 = window tables, 2 = enumerations, 3 = a round's decode + records, 10 = symbols decoded one at a time, 15 = the rest. */
+extern "C" int nvcompAmdProfReadDeflate(unsigned long long* host_slots, int n)
+{
+  unsigned long long v[lzw::kProfSlots] = {};
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(lzw::g_prof), sizeof(v)) != hipSuccess) {
+    return -1;
+  }
+  for (int i = 0; i < n && i < (int)lzw::kProfSlots; ++i) {
+    host_slots[i] = v[i];
+  }
+  unsigned long long z[lzw::kProfSlots] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(lzw::g_prof), z, sizeof(z));
+  return (int)lzw::kProfSlots;
+}
+#endif

@@ -62,6 +62,10 @@ namespace lzm {
 #ifndef NVCOMP_LZM_TAGS
 #define NVCOMP_LZM_TAGS 0
 #endif
+/* Literal runs of more than 8 bytes come out of the input image instead of memory (emit_small below). */
+#ifndef NVCOMP_LZM_LIT_IMAGE
+#define NVCOMP_LZM_LIT_IMAGE 1
+#endif
 #ifndef NVCOMP_LZM_WAVES_PER_SIMD
 #define NVCOMP_LZM_WAVES_PER_SIMD 5 /* what the 8 KiB hash table per wave allows (4-wave workgroups, 160 KB LDS per CU) */
 #endif
@@ -692,6 +696,16 @@ __device__ __forceinline__ uint32_t encode_chunk(
           }
           const bool from_mem = small && !from_regs && lit_len != 0;
           const uint8_t* ls = src + prev_end;
+#if NVCOMP_LZM_STAGE && NVCOMP_LZM_LIT_IMAGE
+          /* A run of more than 8 bytes is read back -- out of the input image when both its ends lie in the two blocks
+           * the image holds (nearly always: a run of up to 64 bytes that ends inside this window): six windows in ten
+           * have such a run, and read from memory each cost its window a dependent round trip (the phase clock put
+           * 17 % of the compressor's time into this copy). */
+          const uint32_t blk_a = prev_end / kStageBlock, blk_b = (prev_end + lit_len - 1) / kStageBlock;
+          const bool in_image = fast && (blk_a & 1u ? have1 : have0) == blk_a && (blk_b & 1u ? have1 : have0) == blk_b;
+#else
+          const bool in_image = false;
+#endif
           const bool lit4 = from_mem && lit_len >= 4;
           for (uint32_t base4 = 0; wave::ballot(lit4 && lit_len > base4) != 0; base4 += 16) {
             if (lit4 && lit_len > base4) {
@@ -700,7 +714,8 @@ __device__ __forceinline__ uint32_t encode_chunk(
 #pragma unroll
               for (uint32_t i = 0; i < 4; ++i) {
                 const uint32_t o = base4 + 4 * i < lastoff ? base4 + 4 * i : lastoff;
-                v[i] = wave::gload_u32(ls + o);
+                /* a dword that starts in the last three bytes of the image's second block runs into the mirror of the first */
+                v[i] = in_image ? lz::ld_u32(image + ((prev_end + o) & (2 * kStageBlock - 1))) : wave::gload_u32(ls + o);
               }
 #pragma unroll
               for (uint32_t i = 0; i < 4; ++i) {

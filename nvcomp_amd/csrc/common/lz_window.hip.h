@@ -1090,7 +1090,10 @@ __device__ __forceinline__ uint32_t execute_window_batch(
 
   /* ---- far matches: sources the window no longer holds, read from HBM ---- */
   const uint32_t match_src = match_dst - s.match_off;
-  const bool short_match = my_match - 4 <= kMatchShort - 4; /* 4 .. kMatchShort */
+  /* DEFLATE (RING_LITERALS) has matches of THREE bytes -- a sixth of all matches of a zlib stream, and as whole-wave
+   * copies, one after the other, they were 18 % of that decoder's time (phase clock, profiles/r03_deflate_phases.json) */
+  constexpr uint32_t kMinShort = RING_LITERALS ? 3 : 4;
+  const bool short_match = my_match - kMinShort <= kMatchShort - kMinShort; /* kMinShort .. kMatchShort */
   const bool is_near = my_match != 0 && match_src >= ow.valid_lo;
   /* the data comes with one or two 16-byte loads, which must stay inside the chunk's buffer (a source in the last 32
    * bytes of the buffer, or a wrapped one of a corrupt unchecked stream, takes the cooperative path below) */
@@ -1113,7 +1116,8 @@ __device__ __forceinline__ uint32_t execute_window_batch(
       const wave::u32x4 f1 = wave::gload_u32x4(src + 16);
       far_data[4] = f1.x, far_data[5] = f1.y, far_data[6] = f1.z, far_data[7] = f1.w;
     }
-    far_l4 = wave::gload_u32(src + my_match - 4);
+    /* the match's last four bytes; of a three-byte match: a byte that is never used, then its three */
+    far_l4 = RING_LITERALS && my_match < 4 ? f0.x << 8 : wave::gload_u32(src + my_match - 4);
   }
 
   LZW_T(11); /* far classification + load issue */
@@ -1207,6 +1211,9 @@ __device__ __forceinline__ uint32_t execute_window_batch(
     LZ_STAT("match_far_lanes", wave::popc64(wave::ballot(far_lane)));
     LZ_STAT("match_near_lanes", wave::popc64(near_mask));
     LZ_STAT("match_coop", wave::popc64(pending & ~near_mask));
+    LZ_STAT("match_coop_below_4", wave::popc64(wave::ballot(my_match != 0 && my_match < 4)));
+    LZ_STAT("match_coop_long", wave::popc64(wave::ballot(my_match > kMatchShort)));
+    LZ_STAT("match_coop_short_period", wave::popc64(wave::ballot(is_near && short_match && s.match_off < 4)));
     while (pending) {
       const uint32_t f = wave::ctz64(pending);
       const uint32_t hw = wave::read_lane(match_dst, f); /* every byte below hw is final */
@@ -1226,7 +1233,10 @@ __device__ __forceinline__ uint32_t execute_window_batch(
       if (ready) {
         const uint8_t* src = out_at(ow, match_src);
         uint8_t* dst = out_at(ow, match_dst);
-        if (steps == 2) {
+        if (RING_LITERALS && my_match < 4) { /* three bytes, offset >= 4 */
+          const uint8_t b0 = src[0], b1 = src[1], b2 = src[2];
+          dst[0] = b0, dst[1] = b1, dst[2] = b2;
+        } else if (steps == 2) {
           copy_dwords_clamped<2>(dst, src, my_match);
         } else if (steps == 4) {
           copy_dwords_clamped<4>(dst, src, my_match);

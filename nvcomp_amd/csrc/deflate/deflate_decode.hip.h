@@ -579,8 +579,10 @@ __device__ __forceinline__ uint32_t scan_round(
       if ((q >> 3) + kScanWin / 8 + 32 > ir.hi && ir.hi < ir.vend) {
         break; /* the window would look at bytes that are not resident yet */
       }
+      LZW_T(15);
       scan_build(c, ir, ll, dd, q);
       LZ_STAT("deflate_builds", 1);
+      LZW_T(1);
     }
     /* Lane n: the n-th symbol from q, if the chain gets there inside this window. Lane arithmetic only (lz_window.hip.h:
      * chase_tokens): a lane follows the levels named by the bits of n; a level it does not take adds 0; 255 poisons the
@@ -643,7 +645,9 @@ __device__ __forceinline__ uint32_t scan_round(
       stuck = true;
       break;
     }
+    LZW_T(2);
   }
+  LZW_T(2);
   if (t == 0) {
     return q;
   }
@@ -706,6 +710,7 @@ __device__ __forceinline__ uint32_t scan_round(
     f.run += n_lit;
   }
   f.lw += n_lit;
+  LZW_T(3);
   return q;
 }
 
@@ -930,6 +935,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
           }
           sc.built = false;
           state = kSymbols;
+          LZW_T(0);
         }
       }
     } else if (state == kSymbols && !f.carried) {
@@ -939,6 +945,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
         lzw::in_ensure(ir, at & ~3u, (at & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
       }
       bool one_symbol = SIZE_ONLY; /* SIZE_ONLY: the whole block symbol by symbol; else: what the rounds could not tell */
+      LZW_T(15);
       if (!SIZE_ONLY) {
         /* rounds until the batch is nearly full (the executor costs the same for 20 records as for 64), a symbol
          * cannot be told, or the stream ring has to move on */
@@ -962,6 +969,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
           break;
         }
       }
+      LZW_T(15);
       while (one_symbol && !f.carried) {
         if (b.next + 16 > ir.hi && ir.hi < ir.vend) {
           lzw::in_ensure(ir, b.byte_pos() & ~3u, (b.byte_pos() & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
@@ -1012,6 +1020,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
         }
         close_sequence<SIZE_ONLY>(f, mlen, dist);
       }
+      LZW_T(10);
       if (bad) {
         break;
       }
