@@ -18,13 +18,13 @@
 namespace {
 
 /* One chunk per wave. A wave's LDS (window, stream ring, literal ring, decoding and jump tables:
- * deflate::kLdsPerWave = 11 KiB) allows 14 waves per CU. Workgroups of ONE wave: chunks of a mixed batch take very
+ * deflate::kLdsPerWave = 9.1 KiB) allows 17 waves per CU. Workgroups of ONE wave: chunks of a mixed batch take very
  * different times and a workgroup's LDS is only released when its last wave ends (1 wave: 71.6 GB/s, 2: 66.1). */
 #ifndef NVCOMP_DEFLATE_WAVES_PER_BLOCK
 #define NVCOMP_DEFLATE_WAVES_PER_BLOCK 1
 #endif
 constexpr unsigned kDecWaves = NVCOMP_DEFLATE_WAVES_PER_BLOCK;
-constexpr unsigned kDecWavesPerSimd = deflate::kLdsPerWave <= 10240 ? 4 : 3;
+constexpr unsigned kDecWavesPerSimd = deflate::kLdsPerWave <= 8192 ? 5 : deflate::kLdsPerWave <= 10240 ? 4 : 3;
 constexpr unsigned kEncWaves = 2; /* 10 / 11.3 KiB of LDS per wave: 16 / 14 waves per CU in workgroups of two */
 constexpr uint32_t kMaxOutCap = 1u << 26;
 

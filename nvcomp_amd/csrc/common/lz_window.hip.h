@@ -60,7 +60,8 @@ constexpr uint32_t kOutWin = NVCOMP_LZW_OUTWIN;     /* bytes of output window pe
 constexpr uint32_t kBatchMax = NVCOMP_LZW_BATCHMAX; /* most output bytes one batch may produce */
 constexpr uint32_t kKeep = NVCOMP_LZW_KEEP;         /* history kept when the window slides */
 constexpr uint32_t kInRing = NVCOMP_LZW_INRING;     /* bytes of compressed-stream ring per wave */
-constexpr uint32_t kInBlock = 1024;  /* ring refill granule: 64 lanes x 16 bytes */
+constexpr uint32_t kInBlock = kInRing / 2; /* ring refill granule: 16 bytes per lane, 64 lanes (1 KiB) or 32 (deflate's 512-byte blocks) */
+static_assert(kInBlock == 1024 || kInBlock == 512, "in_load_block: one 16-byte load by the first kInBlock / 16 lanes");
 constexpr uint32_t kFlushAlign = NVCOMP_LZW_FLUSH_ALIGN;
 constexpr uint32_t kOutLds = kOutWin + 32;
 constexpr uint32_t kInLds = kInRing + 16; /* first 16 bytes mirrored after the end */
@@ -146,11 +147,15 @@ __device__ __forceinline__ void in_init(InRing& r, const uint8_t* in, uint32_t i
   r.hi = 0;
 }
 
-/* Load the 1 KiB block starting at virtual position vb (multiple of kInBlock)
+/* Load the block of kInBlock bytes starting at virtual position vb (multiple of kInBlock)
  * into the ring. Bytes outside the chunk are never fetched (read as zero). */
 __device__ __forceinline__ void in_load_block(InRing& r, uint32_t vb)
 {
-  const uint32_t v = vb + 16u * (uint32_t)wave::fresh_lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
+  if (kInBlock < 1024 && 16u * lane >= kInBlock) {
+    return;
+  }
+  const uint32_t v = vb + 16u * lane;
   wave::u32x4 x = {0, 0, 0, 0};
   if (v >= r.vbeg && v + 16 <= r.vend) {
     x = wave::gload_u32x4_aligned(r.base + v);

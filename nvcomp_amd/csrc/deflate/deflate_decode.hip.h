@@ -31,11 +31,16 @@
  */
 #pragma once
 
-/* DEFLATE's own window size: its batches are cut by the front end at 64 records anyway, and its LDS (lookup tables, the
- * literal ring, the bit-position jump tables) is the occupancy limiter: batches of 928 bytes (+ 32 of history) keep a wave at exactly
- * 10 KiB = 16 waves per CU. */
+/* DEFLATE's own window and ring sizes. Its LDS (lookup tables, the literal ring, the bit-position jump tables) is the
+ * occupancy limiter, and its batches are cut by the front end at 40-64 records -- about 400 bytes of a zlib stream's
+ * output -- long before they are full: batches of 768 bytes (+ 32 of history) and two rings of 1 KiB (the compressed
+ * stream, refilled 512 bytes at a time, and the decoded literals, of which a batch holds at most its own 768 bytes)
+ * keep a wave under 8 KiB = 20 waves per CU (rounds 2-3: 928 / 2 KiB / 2 KiB = 10 KiB, 16 waves). */
 #ifndef NVCOMP_LZW_BATCHMAX
-#define NVCOMP_LZW_BATCHMAX 928
+#define NVCOMP_LZW_BATCHMAX 768
+#endif
+#ifndef NVCOMP_LZW_INRING
+#define NVCOMP_LZW_INRING 1024
 #endif
 #include "common/lz_window.hip.h"
 
@@ -53,13 +58,14 @@ constexpr uint32_t kClLutBits = 7; /* the code-length code: at most 7 bits, alwa
 constexpr uint32_t kRunMax = 255;  /* literal bytes per sequence record (8 bits of the record) */
 constexpr uint32_t kRunClose = 192; /* a pending run this long is closed as a record of its own between rounds */
 /* 512 positions per window (8 per lane) halve the table builds and cut the enumerations by a third (counted on the host
- * emulation: 2.3 -> 1.16 builds and 3.7 -> 2.6 enumerations per round of 49 symbols) and change NOTHING on the card
- * (profiles/r03_deflate_scan.jsonl: 66.6 vs 66.6 GB/s at 1 GiB, 79.3 vs 80.3 at 4 GiB): the decoder is bound by the
- * NUMBER of instructions per symbol -- 17 vector + 14 scalar, of which the speculative decode of every bit position is
- * the largest part and does not depend on the window -- not by the length of its dependent chains. 256 keeps the
- * LDS at 10 KiB per wave. */
+ * emulation: 2.3 -> 1.16 builds and 3.7 -> 2.6 enumerations per round of 49 symbols). On the card that is worth 2-3 %
+ * (profiles/r03_deflate_scan.jsonl: at 10 KiB + 1.25 KiB of LDS per wave it was neutral against 256 at 10 KiB; with the
+ * rings at 1 KiB, 512 at 9.1 KiB = 17 waves per CU reads 80.1 / 97.3 GB/s at 1 / 4 GiB against 77.7 / 95.8 for 256 at
+ * 7.8 KiB = 20 waves): the decoder is bound by the NUMBER of instructions per symbol -- 17 vector + 14 scalar, of which
+ * the speculative decode of every bit position is the largest part and does not depend on the window -- more than by the
+ * length of its dependent chains. */
 #ifndef NVCOMP_DEFLATE_SCAN_WIN
-#define NVCOMP_DEFLATE_SCAN_WIN 256
+#define NVCOMP_DEFLATE_SCAN_WIN 512
 #endif
 constexpr uint32_t kScanWin = NVCOMP_DEFLATE_SCAN_WIN; /* bit positions one speculative window covers: 256 or 512 */
 constexpr uint32_t kScanPer = kScanWin / 64;            /* ... of which a lane decodes this many (consecutive ones) */
