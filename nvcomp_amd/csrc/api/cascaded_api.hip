@@ -108,8 +108,11 @@ __global__ void __launch_bounds__(256, 8) cascaded_compress_kernel(
     }
     if (sz == casc::kSubNeedsLds) {
       deferred = true; /* the whole chunk is compressed again by the next pass; the host sized the last pass for the worst case */
+      LZ_STAT("casc_compress_chunks_deferred", 1);
+      LZ_STAT("casc_compress_subs_wasted", s);
       break;
     }
+    LZ_STAT("casc_compress_subs", 1);
     pay += sz;
     if (lane == 0) {
       table[s] = pay;
@@ -239,7 +242,9 @@ __global__ void __launch_bounds__(256, 8) cascaded_decompress_kernel(
         rc = casc::decompress_sub<uint64_t>(payload + begin, end - begin, head, dst + off, bytes, num_rles, num_deltas, slice, lds_per_wave);
         break;
       }
+      LZ_STAT("casc_decompress_subs", 1);
       if (rc == casc::kSubNeedLds) {
+        LZ_STAT("casc_decompress_subs_deferred", 1);
         if (pass < 2) {
           deferred = true; /* whatever was already written is decoded again by the next pass */
         } else {
