@@ -19,7 +19,28 @@ namespace {
 constexpr uint32_t kHeaderBytes = 20;
 /* Decode runs three passes with growing LDS per wave; a sub-chunk's need follows from its actual stream counts
  * (casc::decompress_sub), so compressible data is decoded by the first pass at full occupancy. */
-constexpr uint32_t kSmallBudget = 5 * 1024;       /* pass 0: 4 waves per workgroup, 8 workgroups per CU */
+/* The first pass of each direction: 4 waves per workgroup, its own LDS slice per wave and register budget (workgroups
+ * per CU in __launch_bounds__). Swept on hardware in round 3 (profiles/r03_cascaded_passes.jsonl, 1 GiB, compress /
+ * decompress GB/s):
+ *   compress   8 workgroups x 5 KiB (64 VGPRs, 16 spilled): float columns 690, int32 column 1 670, int64 key column 2 485
+ *              6 workgroups x 6.25 KiB (85 VGPRs, 2 spilled): 785 / 1 666 / 2 712 -- and the float columns, whose sub-chunks
+ *              have ~1 000 runs (2 KiB of run pool), stay in the first pass instead of being bounced to the last, every chunk
+ *              5 workgroups x 7.75 KiB: 715 / 1 525 / 2 507
+ *   decompress 8 x 5 KiB: 1 594 / 1 883 / 2 382;  7 x 5.5 KiB: 1 454 / 1 883 / 2 360;  6: 1 418 / 1 917;  5: 1 223 / 1 744 */
+#ifndef NVCOMP_CASC_COMP_SMALL
+#define NVCOMP_CASC_COMP_SMALL 6400
+#endif
+#ifndef NVCOMP_CASC_COMP_WGS
+#define NVCOMP_CASC_COMP_WGS 6
+#endif
+constexpr uint32_t kCompSmallBudget = NVCOMP_CASC_COMP_SMALL;
+#ifndef NVCOMP_CASC_DEC_SMALL
+#define NVCOMP_CASC_DEC_SMALL (5 * 1024)
+#endif
+#ifndef NVCOMP_CASC_DEC_WGS
+#define NVCOMP_CASC_DEC_WGS 8
+#endif
+constexpr uint32_t kDecSmallBudget = NVCOMP_CASC_DEC_SMALL;
 constexpr uint32_t kMidBudget = 8 * 1024 + 512;   /* compress: a worst case up to here (4 KiB sub-chunks of >= 2-byte elements: value buffer +
                                                      one run pool) is the last pass itself; beyond it an intermediate pass of this size runs first */
 constexpr uint32_t kFastBudget = 16 * 1024;       /* decode pass 1: 4 waves per workgroup (two value buffers + pools + marks: sub-chunks with
@@ -46,7 +67,7 @@ bool opts_ok(const nvcompBatchedCascadedOpts_t& o)
          && o.chunk_size >= 256 && o.chunk_size <= 16384 && o.chunk_size % w == 0;
 }
 
-__global__ void __launch_bounds__(256, 8) cascaded_compress_kernel(
+__global__ void __launch_bounds__(256, NVCOMP_CASC_COMP_WGS) cascaded_compress_kernel(
     const void* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
     size_t batch_size,
@@ -133,7 +154,7 @@ __global__ void __launch_bounds__(256, 8) cascaded_compress_kernel(
 
 /* pass p decodes the chunks with todo == p (pass 0: all) whose streams fit its LDS budget and hands the others
  * on by setting todo = p + 1. */
-__global__ void __launch_bounds__(256, 8) cascaded_decompress_kernel(
+__global__ void __launch_bounds__(256, NVCOMP_CASC_DEC_WGS) cascaded_decompress_kernel(
     const void* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes,
     const size_t* out_caps,
@@ -371,7 +392,7 @@ nvcompStatus_t nvcompBatchedCascadedCompressAsync(
   const unsigned grid = (unsigned)((batch_size + waves - 1) / waves);
   clear_stale_error();
   uint32_t* todo = (uint32_t*)device_temp_ptr;
-  if (todo == nullptr || temp_bytes < 4 * batch_size || per_wave <= kSmallBudget) {
+  if (todo == nullptr || temp_bytes < 4 * batch_size || per_wave <= kCompSmallBudget) {
     /* no flag words (or nothing to gain): one launch sized for the worst case */
     hipLaunchKernelGGL(cascaded_compress_kernel, dim3(grid), dim3(64 * waves), per_wave * waves, stream,
                        device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
@@ -381,9 +402,9 @@ nvcompStatus_t nvcompBatchedCascadedCompressAsync(
   /* pass 0: a small LDS slice at full occupancy; chunks whose streams overflow it are flagged and compressed again by
    * the next pass; the last pass holds the worst case */
   const uint32_t last = per_wave > kMidBudget ? 2u : 1u;
-  hipLaunchKernelGGL(cascaded_compress_kernel, dim3((unsigned)((batch_size + 3) / 4)), dim3(256), 4 * kSmallBudget, stream,
+  hipLaunchKernelGGL(cascaded_compress_kernel, dim3((unsigned)((batch_size + 3) / 4)), dim3(256), 4 * kCompSmallBudget, stream,
                      device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
-                     device_compressed_bytes, p, todo, 0u, last, kSmallBudget, 4u);
+                     device_compressed_bytes, p, todo, 0u, last, kCompSmallBudget, 4u);
   if (last == 2) {
     hipLaunchKernelGGL(cascaded_compress_kernel, dim3((unsigned)((batch_size + 3) / 4)), dim3(256), 4 * kMidBudget, stream,
                        device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
@@ -428,10 +449,10 @@ nvcompStatus_t nvcompBatchedCascadedDecompressAsync(
   }
   uint32_t* todo = (uint32_t*)device_temp_ptr;
   clear_stale_error();
-  hipLaunchKernelGGL(cascaded_decompress_kernel, dim3((unsigned)((batch_size + 3) / 4)), dim3(256), 4 * kSmallBudget,
+  hipLaunchKernelGGL(cascaded_decompress_kernel, dim3((unsigned)((batch_size + 3) / 4)), dim3(256), 4 * kDecSmallBudget,
                      stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
                      device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 0u,
-                     kSmallBudget, 4u);
+                     kDecSmallBudget, 4u);
   hipLaunchKernelGGL(cascaded_decompress_kernel, dim3((unsigned)((batch_size + 3) / 4)), dim3(256), 4 * kFastBudget,
                      stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
                      device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 1u,

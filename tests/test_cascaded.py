@@ -94,6 +94,50 @@ def test_short_run_expansion(backend, oracle, typ, r, d):
     roundtrip(backend, oracle, chunks, (4096, typ, r, d, 1))
 
 
+@pytest.mark.parametrize("typ", [1, 3, 4, 6])
+@pytest.mark.parametrize("r,d,bp", [(2, 1, 1), (1, 0, 1), (2, 0, 0), (3, 1, 1)])
+def test_run_pool_choice(backend, oracle, typ, r, d, bp):
+    """The compressor's first pass has room for one run per TWO elements in its two-byte pool; a layer with more runs takes a
+    one-byte pool (start indices modulo 256), which in turn cannot hold a run of 256 elements or more (casc::rle_encode,
+    compress_sub: the choice is tried, retried the other way when the input is still in memory, hinted from the chunk's
+    previous sub-chunk). Sub-chunks on every side of both limits, in every order inside one chunk -- the hint is wrong at
+    each change --, runs of 254 / 255 / 256 / 257 / 300 elements among a run per element, at the start, in the middle and at
+    the end of a sub-chunk. The bytes must be the CPU model's whatever path produced them."""
+    w = WIDTH[typ]
+    rng = np.random.RandomState(1000 * typ + 100 * r + 10 * d + bp)
+    dt = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[w]
+    n = 4096 // w  # elements per sub-chunk
+
+    def distinct(k):  # k elements, neighbours differ
+        v = np.cumsum(rng.randint(1, 5, size=k)).astype(np.uint64)
+        return (v % (1 << (8 * w - 1) if w < 8 else 1 << 62)).astype(dt)
+
+    def crowded_with_run(run, where):  # a run per element, and ONE run of `run` elements
+        rest = n - run
+        a = {"start": 0, "middle": rest // 2, "end": rest}[where]
+        v = distinct(rest + 1)
+        return np.concatenate([v[:a], np.repeat(v[a: a + 1] + 1, run), v[a + 1: rest + 1]])[:n]
+
+    def few_runs():  # fits the two-byte pool: runs of 2 .. 700
+        parts, total = [], 0
+        while total < n:
+            k = int(rng.choice([2, 3, 50, 255, 256, 700]))
+            parts.append(np.full(k, rng.randint(0, 200), dtype=dt))
+            total += k
+        return np.concatenate(parts)[:n]
+
+    subs = [distinct(n), few_runs(), distinct(n)]
+    for run in (254, 255, 256, 257, 300):
+        for where in ("start", "middle", "end"):
+            if run < n:
+                subs += [crowded_with_run(run, where), distinct(n)]
+    subs += [few_runs(), crowded_with_run(min(255, n // 2), "middle"), np.repeat(distinct(n // 2), 2), few_runs(), distinct(n - 7)]
+    flat = np.concatenate(subs).astype(dt)
+    per_chunk = 16 * n
+    chunks = [flat[i: i + per_chunk].view(np.uint8) for i in range(0, flat.size, per_chunk)]
+    roundtrip(backend, oracle, chunks, (4096, typ, r, d, bp))
+
+
 def test_sub_chunk_sizes(backend, oracle):
     chunks = [datasets.int32_column(40000, 9), datasets.table_rows(12000, 4)]
     for sub in (256, 512, 1000, 4096, 8192, 16384):
