@@ -16,8 +16,14 @@ namespace {
 constexpr unsigned kWavesPerBlock = 4;
 constexpr uint32_t kMaxOutCap = 1u << 26;
 
+/* Workgroups per CU the register allocation aims at: 8 (64 registers) spills 12-20 registers of the 8-byte element types,
+ * whose values travel as two parts; 6 (85 registers) does not and is 5-24 % faster on them (round 3, 1 GiB: int64 key column
+ * 2 809 -> 3 015 GB/s, 64-bit view of the float columns 1 928 -> 2 390; 7: slower than both). */
+#ifndef NVCOMP_BITCOMP_WGS64
+#define NVCOMP_BITCOMP_WGS64 6
+#endif
 template <class T, bool DELTA>
-__global__ void __launch_bounds__(64 * kWavesPerBlock, 8) bitcomp_compress_kernel(
+__global__ void __launch_bounds__(64 * kWavesPerBlock, sizeof(T) == 8 ? NVCOMP_BITCOMP_WGS64 : 8) bitcomp_compress_kernel(
     const void* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
     size_t max_chunk_bytes,
