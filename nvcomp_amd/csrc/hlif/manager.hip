@@ -184,11 +184,23 @@ __global__ void __launch_bounds__(256) gather_kernel(const uint8_t* stage, size_
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t* sizes = (const uint64_t*)(comp_buffer + sizeof(Header));
   const uint64_t* offsets = sizes + n;
-  const uint64_t* src = (const uint64_t*)(stage + i * stride); /* both sides are 8-byte aligned */
-  uint64_t* dst = (uint64_t*)(comp_buffer + sizeof(Header) + tables + offsets[i]);
-  const size_t words = (sizes[i] + 7) / 8;
-  for (size_t k = lane; k < words; k += 64) {
-    dst[k] = src[k];
+  const uint8_t* src = stage + i * stride; /* both sides are 8-byte aligned */
+  uint8_t* dst = comp_buffer + sizeof(Header) + tables + offsets[i];
+  const size_t bytes = (sizes[i] + 7) / 8 * 8;
+  /* 16 bytes per lane, four loads of 1 KiB in flight before the first store (8 bytes per lane, one load -> store round
+   * trip per 512 bytes, took 270 microseconds per GiB of input: 2.6 % of an LZ4 manager's compress()) */
+  size_t at = 0;
+  for (; at + 4096 <= bytes; at += 4096) {
+    const size_t o = at + 16 * lane;
+    const wave::u32x4 a = wave::gload_u32x4(src + o), b = wave::gload_u32x4(src + o + 1024);
+    const wave::u32x4 c = wave::gload_u32x4(src + o + 2048), d = wave::gload_u32x4(src + o + 3072);
+    wave::gstore_u32x4(dst + o, a);
+    wave::gstore_u32x4(dst + o + 1024, b);
+    wave::gstore_u32x4(dst + o + 2048, c);
+    wave::gstore_u32x4(dst + o + 3072, d);
+  }
+  for (size_t o = at + 8 * lane; o < bytes; o += 512) {
+    *(uint64_t*)(dst + o) = *(const uint64_t*)(src + o);
   }
 }
 
@@ -239,7 +251,9 @@ __global__ void __launch_bounds__(64 * kCrcWaves) crc_kernel(
 }
 
 /* Fold the per-chunk statuses / sizes / checksum mismatches into the batch status word. */
-__global__ void __launch_bounds__(256) status_kernel(
+/* One workgroup of 1024 threads, four chunks per thread and step with their loads issued together (256 threads and a load
+ * -> test round trip per chunk took 55 microseconds for 16 384 chunks: 2 % of an LZ4 manager's decompress()). */
+__global__ void __launch_bounds__(1024) status_kernel(
     const nvcompStatus_t* statuses, const size_t* actual, const size_t* expect, size_t n, const uint32_t* mismatch,
     nvcompStatus_t* out)
 {
@@ -248,10 +262,25 @@ __global__ void __launch_bounds__(256) status_kernel(
     bad = 0;
   }
   __syncthreads();
-  for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
-    if (statuses[i] != nvcompSuccess || actual[i] != expect[i]) {
-      atomicAdd(&bad, 1u);
+  uint32_t mine = 0;
+  for (size_t base = threadIdx.x; base < n; base += 4 * (size_t)blockDim.x) {
+    nvcompStatus_t st[4];
+    size_t a[4], e[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      const size_t i = base + u * (size_t)blockDim.x;
+      const bool in = i < n;
+      st[u] = in ? statuses[i] : nvcompSuccess;
+      a[u] = in ? actual[i] : 0;
+      e[u] = in ? expect[i] : 0;
     }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      mine |= (st[u] != nvcompSuccess || a[u] != e[u]) ? 1u : 0u;
+    }
+  }
+  if (mine) {
+    atomicOr(&bad, 1u);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -593,7 +622,7 @@ void BatchedManager::decompress(uint8_t* decomp_buffer, const uint8_t* comp_buff
                        (uint32_t*)nullptr, crc_u, mismatch, (const Header*)comp_buffer);
     hip_check(hipStreamWaitEvent(m.stream, m.join, 0), "hipStreamWaitEvent");
   }
-  hipLaunchKernelGGL(status_kernel, dim3(1), dim3(256), 0, m.stream, statuses, actual, out_caps, n,
+  hipLaunchKernelGGL(status_kernel, dim3(1), dim3(1024), 0, m.stream, statuses, actual, out_caps, n,
                      verify ? mismatch : (const uint32_t*)nullptr, status);
   hip_check(hipGetLastError(), "decompress launch");
 }
