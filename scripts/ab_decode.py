@@ -71,7 +71,11 @@ def main():
     threads = len(os.sched_getaffinity(0))
     sink = open(a.out, "a") if a.out else None
     for case in a.cases.split(","):
-        fmt, ds, producer, unique_mib, mib = CASES[case]
+        if ":" in case:  # ad hoc: format:dataset:producer, 32 MiB unique, 1 GiB per launch
+            fmt, ds, producer = case.split(":")
+            unique_mib, mib = 32, 1024
+        else:
+            fmt, ds, producer, unique_mib, mib = CASES[case]
         mib = mib or a.mib
         unique = unique_mib << 20
         gen = getattr(datasets, ds) if hasattr(datasets, ds) else datasets.CLASSES[ds]
