@@ -32,7 +32,8 @@ def main():
     p = os.path.join(src, "hlif", "hlif.log")
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f"{prefix}_hlif.log"))
-    for sub, out in (("trace", "lz4"), ("trace_snappy", "snappy"), ("trace_deflate", "deflate"), ("trace_compress", "lz4_with_compress")):
+    for sub, out in (("trace", "lz4"), ("trace_snappy", "snappy"), ("trace_deflate", "deflate"), ("trace_cascaded", "cascaded"),
+                     ("trace_bitcomp", "bitcomp"), ("trace_ans", "ans"), ("trace_compress", "lz4_with_compress")):
         hits = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
         if hits:
             shutil.copy(hits[0], os.path.join(dst, f"{prefix}_kernel_stats_{out}.csv"))

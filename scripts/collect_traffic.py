@@ -19,6 +19,11 @@ KERNELS = {
     "deflate": [("deflate_decompress_kernel", "deflate", "decompress")],
     "cascaded": [("cascaded_decompress_kernel", "cascaded", "decompress")],
     "lz4_mortgage": [("lz4_decompress_window_kernel", "lz4", "decompress")],
+    # the other codecs' own bench lines (python bench.py --algo X at its default size)
+    "cascaded_line": [("cascaded_decompress_kernel", "cascaded", "decompress")],
+    "bitcomp_line": [("bitcomp_decompress_kernel", "bitcomp", "decompress")],
+    "ans_line": [("ans_decompress_kernel", "ans", "decompress")],
+    "deflate_line": [("deflate_decompress_kernel", "deflate", "decompress")],
 }
 
 

@@ -22,7 +22,7 @@ for a in snappy cascaded bitcomp ans deflate; do
 done
 B="python $REPO/bench.py --no-cpu-baseline --no-extras"
 cd /tmp
-for spec in "trace:" "trace_snappy:--algo snappy" "trace_deflate:--algo deflate" "trace_compress:--extras-compress-only"; do
+for spec in "trace:" "trace_snappy:--algo snappy" "trace_deflate:--algo deflate" "trace_cascaded:--algo cascaded" "trace_bitcomp:--algo bitcomp" "trace_ans:--algo ans" "trace_compress:--extras-compress-only"; do
   name=${spec%%:*}; args=${spec#*:}
   if [ "$name" = trace_compress ]; then
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -o r -- python $REPO/bench.py --no-cpu-baseline --no-riders --steps 3 --warmup 1 > "$OUT/$name.log" 2>&1

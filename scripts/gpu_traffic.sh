@@ -21,5 +21,11 @@ run snappy --algo snappy --no-extras
 run deflate --algo deflate --no-extras --mib-per-gpu 1024 --unique-mib 32
 run cascaded --algo cascaded --no-extras --dataset example_float_columns --mib-per-gpu 1024 --unique-mib 32
 run lz4_mortgage --no-extras --dataset mortgage_col0_like --mib-per-gpu 1024 --unique-mib 64
+if [ "${LINES:-1}" = 1 ]; then # the other codecs' own lines at their default sizes
+  run cascaded_line --algo cascaded --no-extras
+  run bitcomp_line --algo bitcomp --no-extras
+  run ans_line --algo ans --no-extras
+  run deflate_line --algo deflate --no-extras
+fi
 find "$OUT" -name "*.csv" -size +16M -delete
 python scripts/collect_traffic.py "$OUT" > "$OUT/pmc_traffic_r03.json" && cat "$OUT/pmc_traffic_r03.json" | head -60
