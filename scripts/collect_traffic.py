@@ -27,9 +27,13 @@ KERNELS = {
 }
 
 
+# dispatches of the kernel per API call (the Cascaded decoder runs three passes of one kernel: the traffic of a call is their sum)
+DISPATCHES_PER_CALL = {"cascaded_decompress_kernel": 3}
+
+
 def per_launch(path, substr):
     rows = [r for r in csv.DictReader(open(path)) if substr in r["Kernel_Name"]]
-    launches = len({r["Dispatch_Id"] for r in rows})
+    launches = len({r["Dispatch_Id"] for r in rows}) // DISPATCHES_PER_CALL.get(substr, 1)
     total = sum(float(r["Counter_Value"]) for r in rows)
     return (total / launches if launches else None), launches
 
