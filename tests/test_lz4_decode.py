@@ -206,6 +206,59 @@ def test_two_byte_length_fields(backend, lz_path, oracle):
         check_roundtrip(backend, oracle, raws, blocks, base_misalign=mis)
 
 
+def test_stream_ends_on_ring_block_boundaries(backend, lz_path, oracle):
+    """The end of a chunk against the stream ring's geometry (common/lz_window.hip.h): the ring is refilled in 1 KiB blocks of
+    the chunk's 16-byte-aligned coordinates, bytes behind the chunk's end read as zero inside the last loaded block and as
+    OLDER stream bytes when the chunk ends exactly on a block boundary, and the token chase's last windows must not let
+    either leak into a token position. Blocks whose last byte lies on, right before and right behind such a boundary, for
+    pointers at every offset modulo 16 that matters, ending in short and in long literal runs and in chains of short
+    sequences; tiny blocks (a stream shorter than one chase window). (Written for an experiment that let the last windows
+    take the straight-line distance function -- neutral on the card, not kept; the cases stay.)"""
+    rng = np.random.RandomState(515)
+
+    def block_of(total, style):
+        seqs = [(rng.randint(0, 256, size=24).astype(np.uint8).tobytes(), 3, 11)]
+        while True:
+            body = _lz4_block(seqs, b"12345").size - 6  # without the final literal-only sequence
+            room = total - body
+            if room < 40:
+                break
+            produced = sum(len(l) + m for l, _, m in seqs)
+            if style == "short":
+                lit = rng.randint(0, 256, size=rng.randint(0, 4)).astype(np.uint8).tobytes()
+                seqs.append((lit, 1 + rng.randint(min(20, produced + len(lit))), 4 + rng.randint(12)))
+            else:
+                lit = rng.randint(0, 256, size=rng.randint(5, max(6, min(60, room - 14)))).astype(np.uint8).tobytes()
+                seqs.append((lit, 1 + rng.randint(min(200, produced + len(lit))), 4 + rng.randint(300)))
+        for _ in range(4):
+            for n in range(5, 400):  # the tail literal run that makes the block exactly `total` bytes long
+                tail = rng.randint(0, 256, size=n).astype(np.uint8).tobytes()
+                b = _lz4_block(seqs, tail)
+                if b.size == total:
+                    return b, _lz4_expand(seqs, tail)
+            # a tail of 15 bytes takes a length byte: one size in 256 cannot be reached -- one more literal in front of it can
+            lit, off, mlen = seqs[-1]
+            seqs[-1] = (lit + b"x", off, mlen)
+        raise AssertionError("no tail length fits")
+
+    for mis in (0, 1, 7, 15):
+        blocks, raws = [], []
+        for k in (1, 2, 3, 5):
+            for delta in (-1, 0, 1):
+                for style in ("short", "long"):
+                    b, r = block_of(1024 * k - mis + delta, style)
+                    blocks.append(b)
+                    raws.append(r)
+        for total in (14, 20, 37, 100, 255, 256, 257):
+            b, r = block_of(total + 40, "short")
+            blocks.append(b)
+            raws.append(r)
+        for cc, c in zip(blocks, raws):
+            rc, ref = oracle.lz4_decompress(cc, c.size)
+            assert rc == 0 and np.array_equal(ref, c), "the hand-built block is not what the oracle reads"
+        check_roundtrip(backend, oracle, raws, blocks, comp_align=16, base_misalign=mis)
+
+
 def test_corrupt_streams_do_not_escape(backend, lz_path, oracle):
     """Invalid input -> status != success and size 0 (CHANGELOG.md:160-164); never a write
     outside the output slot (canaries) and, where the oracle accepts, identical bytes."""
