@@ -70,7 +70,11 @@ nvcompStatus_t nvcompBatchedSnappyCompressGetMaxOutputChunkSize(
  * device_compressed_bytes reads 0 (no other chunk has a compressed size of 0 unless it was empty itself). The call
  * still returns nvcompSuccess -- it is asynchronous and has no per-chunk status array to write to -- so a caller
  * that cannot vouch for its chunk sizes checks for 0; the nvcomp::*Manager layer does and reports
- * nvcompErrorInvalidValue through the compression status. */
+ * nvcompErrorInvalidValue through the compression status.
+ *
+ * device_temp_ptr holds working state of the launch (the persistent waves' chunk counter): ONE TEMP BUFFER PER
+ * IN-FLIGHT CALL. Two *Async calls that may overlap -- on different streams, or from different host threads -- must
+ * be given different temp buffers (calls queued on one stream may share one). */
 nvcompStatus_t nvcompBatchedSnappyCompressAsync(
     const void* const* device_uncompressed_ptrs,
     const size_t* device_uncompressed_bytes,
@@ -101,7 +105,12 @@ nvcompStatus_t nvcompBatchedSnappyDecompressGetTempSizeEx(
  * device_uncompressed_bytes and device_actual_uncompressed_bytes: aliasing is legal) ;
  * doc/lowlevel_c_quickstart.md:127-140.
  * device_actual_uncompressed_bytes and device_statuses may each be NULL;
- * with device_statuses == NULL no per-chunk bounds checking is performed. */
+ * with device_statuses == NULL no per-chunk bounds checking is performed: pass NULL for TRUSTED streams only (a
+ * corrupt stream may then write past its output slot; sequences of 4 KiB and more are checked either way).
+ *
+ * device_temp_ptr holds working state of the launch (the persistent waves' chunk counter): ONE TEMP BUFFER PER
+ * IN-FLIGHT CALL. Two *Async calls that may overlap -- on different streams, or from different host threads -- must
+ * be given different temp buffers (calls queued on one stream may share one). */
 nvcompStatus_t nvcompBatchedSnappyDecompressAsync(
     const void* const* device_compressed_ptrs,
     const size_t* device_compressed_bytes,

@@ -286,10 +286,9 @@ nvcompStatus_t nvcompBatchedLZ4DecompressAsync(
   uint32_t* ticket = nullptr;
 #if NVCOMP_LZ_PERSISTENT
   if (device_temp_ptr != nullptr && temp_bytes >= sizeof(uint32_t) && ((uintptr_t)device_temp_ptr & 3u) == 0) {
-    static const unsigned resident[2] = {
-        lzl::resident_workgroups(lz4_decompress_window_kernel<false>, 64 * kDecWaves),
-        lzl::resident_workgroups(lz4_decompress_window_kernel<true>, 64 * kDecWaves)};
-    const unsigned fit = resident[checked ? 1 : 0];
+    static lzl::ResidentCache resident[2]; /* per device ordinal */
+    const unsigned fit = checked ? resident[1].get(lz4_decompress_window_kernel<true>, 64 * kDecWaves)
+                                 : resident[0].get(lz4_decompress_window_kernel<false>, 64 * kDecWaves);
     if (fit != 0 && fit < groups && hipMemsetAsync(device_temp_ptr, 0, sizeof(uint32_t), stream) == hipSuccess) {
       ticket = (uint32_t*)device_temp_ptr;
       groups = fit;
@@ -396,7 +395,8 @@ nvcompStatus_t nvcompBatchedLZ4CompressAsync(
     uint32_t* ticket = nullptr;                                                                                           \
     if (NVCOMP_LZ_PERSISTENT && device_temp_ptr != nullptr && temp_bytes >= sizeof(uint32_t)                              \
         && ((uintptr_t)device_temp_ptr & 3u) == 0) {                                                                      \
-      static const unsigned fit = lzl::resident_workgroups(lz4_compress_kernel<STRIDE>, 64 * kEncWaves, 0);               \
+      static lzl::ResidentCache resident; /* per device ordinal */                                                      \
+      const unsigned fit = resident.get(lz4_compress_kernel<STRIDE>, 64 * kEncWaves, 0);                                 \
       if (fit != 0 && fit < groups && hipMemsetAsync(device_temp_ptr, 0, sizeof(uint32_t), stream) == hipSuccess) {       \
         ticket = (uint32_t*)device_temp_ptr;                                                                              \
         groups = fit;                                                                                                     \

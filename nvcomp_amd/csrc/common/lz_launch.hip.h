@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "common/wave.h"
 
 #ifndef NVCOMP_LZ_PAIR_MAX_BATCH
@@ -86,9 +88,9 @@ __device__ __forceinline__ size_t next_chunk(uint32_t* ticket, size_t first_dyna
 }
 
 /* Workgroups of `kernel` (block threads, static LDS) the current device keeps resident at once; 0 when the runtime
- * cannot tell (the launch is then static). Asked once per kernel and device. */
+ * cannot tell (the launch is then static). */
 template <class Kernel>
-inline unsigned resident_workgroups(Kernel kernel, unsigned block_threads, int max_per_cu = NVCOMP_LZ_MAX_WG_PER_CU)
+inline unsigned resident_workgroups(Kernel kernel, unsigned block_threads, int max_per_cu = NVCOMP_LZ_MAX_WG_PER_CU, int* device = nullptr)
 {
   int dev = 0, cus = 0, per_cu = 0;
   if (hipGetDevice(&dev) != hipSuccess
@@ -97,10 +99,42 @@ inline unsigned resident_workgroups(Kernel kernel, unsigned block_threads, int m
     (void)hipGetLastError();
     return 0;
   }
+  if (device != nullptr) {
+    *device = dev;
+  }
   if (max_per_cu > 0 && per_cu > max_per_cu) {
     per_cu = max_per_cu;
   }
   return cus > 0 && per_cu > 0 ? (unsigned)cus * (unsigned)per_cu : 0u;
 }
+
+/* The same, remembered PER DEVICE ORDINAL (one instance per kernel, a function-local static of the caller): a process
+ * that drives several cards from one thread (benchmarks/benchmark_allgather.cpp: hipSetDevice in a loop) gets each
+ * card's own geometry, and the two runtime queries are made once per kernel and card. Lock-free; two threads racing on
+ * the first call both ask and store the same answer. */
+struct ResidentCache
+{
+  static constexpr int kDevices = 64;
+  std::atomic<unsigned> known[kDevices] = {}; /* answer + 1; 0 = not asked yet */
+  template <class Kernel>
+  unsigned get(Kernel kernel, unsigned block_threads, int max_per_cu = NVCOMP_LZ_MAX_WG_PER_CU)
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    if (dev < 0 || dev >= kDevices) {
+      return resident_workgroups(kernel, block_threads, max_per_cu);
+    }
+    const unsigned seen = known[dev].load(std::memory_order_relaxed);
+    if (seen != 0) {
+      return seen - 1;
+    }
+    const unsigned fit = resident_workgroups(kernel, block_threads, max_per_cu);
+    known[dev].store(fit + 1, std::memory_order_relaxed);
+    return fit;
+  }
+};
 
 } // namespace lzl

@@ -996,7 +996,9 @@ __device__ __forceinline__ bool stream_sequence(
     const InRing& ir, OutWindow& ow, uint32_t out_cap, uint32_t& op, uint32_t lsrc, uint32_t llen, uint32_t moff, uint32_t mlen,
     uint32_t& err)
 {
-  if (CHECKED) {
+  /* tested whether or not the caller asked for statuses (once per streamed sequence: nothing): an unchecked decode of a
+   * corrupt stream must not turn a claimed length of megabytes into an HBM-to-HBM copy past the output slot */
+  {
     const uint64_t end = (uint64_t)op + llen + mlen;
     if (end > out_cap || (mlen != 0 && (moff == 0 || moff > op + llen))) {
       err |= end > out_cap ? lz::kErrOutput : lz::kErrOffset;

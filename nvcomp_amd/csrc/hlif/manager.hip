@@ -613,7 +613,10 @@ void BatchedManager::decompress(uint8_t* decomp_buffer, const uint8_t* comp_buff
      * decoders are resident first (their persistent waves take 28 of a CU's 32 wave slots and 151 of its 160 KB of LDS,
      * common/lz_launch.hip.h) and are bound by the vector and scalar units; a checksum workgroup (four waves, 8 KiB of
      * tables) fits into what they leave and lives on loads and LDS lookups, which the decoders leave idle. The checksums
-     * of the decoded chunks follow the decoder on its own stream. */
+     * of the decoded chunks follow the decoder on its own stream.
+     * Verification therefore does NOT gate decoding: the decoder always reads chunks whose checksums are still being
+     * computed. That is safe because the decoders bound-check every access when statuses are requested (the managers
+     * always request them; tests/test_fuzz_corrupt.py) and a decode error outranks a bad checksum in the status. */
     hip_check(hipStreamWaitEvent(m.side, m.fork, 0), "hipStreamWaitEvent");
     hipLaunchKernelGGL(crc_kernel, crc_grid, crc_block, 0, m.side, (const void* const*)comp_ptrs, comp_sizes, n,
                        (uint32_t*)nullptr, crc_c, mismatch, (const Header*)comp_buffer);

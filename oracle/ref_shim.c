@@ -18,7 +18,9 @@
  * (scripts/make_golden.py), to prepare CPU-compressed inputs for tests and
  * bench.py, and as bench.py's cpu_baseline ("reference" kind).
  */
+#ifdef HAVE_LIBDEFLATE
 #include <libdeflate.h>
+#endif
 #include <lz4.h>
 #include <lz4hc.h>
 #include <snappy-c.h>
@@ -137,6 +139,7 @@ static int zlib_deflate_level(const uint8_t* s, size_t n, uint8_t* d, size_t cap
 static int r_zlib_deflate1(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out) { return zlib_deflate_level(s, n, d, cap, out, 1); }
 static int r_zlib_deflate9(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out) { return zlib_deflate_level(s, n, d, cap, out, 9); }
 
+#ifdef HAVE_LIBDEFLATE
 /* libdeflate, raw DEFLATE streams; one compressor / decompressor per thread, kept (the reference's example allocates one
  * per chunk: the figure that favours the CPU again) */
 static int r_libdeflate_dec(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out)
@@ -165,6 +168,10 @@ static int r_libdeflate_enc6(const uint8_t* s, size_t n, uint8_t* d, size_t cap,
 int ref_libdeflate_decompress(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out) { return r_libdeflate_dec(s, n, d, cap, out); }
 int ref_libdeflate_compress(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t* out) { return r_libdeflate_enc6(s, n, d, cap, out); }
 size_t ref_libdeflate_bound(size_t n) { return libdeflate_deflate_compress_bound(NULL, n); }
+#else /* built without libdeflate: codecs 8 and 9 are absent and the ref_libdeflate_* symbols with them (oracle_py.have_libdeflate) */
+#define r_libdeflate_dec NULL
+#define r_libdeflate_enc6 NULL
+#endif
 
 /* codec: 0 lz4 dec, 1 snappy dec, 2 lz4 enc (default), 3 snappy enc, 4 lz4 enc HC level 12, 5 zlib inflate (raw),
  * 6 zlib deflate level 1 (raw), 7 zlib deflate level 9 (raw), 8 libdeflate decompress (raw), 9 libdeflate compress level 6 */
@@ -175,7 +182,7 @@ double ref_batch_run(
 {
   static const batch_codec_fn table[10] = {r_lz4_dec, r_snappy_dec, r_lz4_enc, r_snappy_enc, r_lz4_enc_hc,
                                            r_zlib_inflate, r_zlib_deflate1, r_zlib_deflate9, r_libdeflate_dec, r_libdeflate_enc6};
-  if (codec < 0 || codec > 9) {
+  if (codec < 0 || codec > 9 || table[codec] == NULL) {
     return -1.0;
   }
   return batch_run_generic(
