@@ -10,9 +10,11 @@
  * stream in front of the kernel; without a temp buffer (a caller that passes NULL) the launch falls back to one
  * wave per chunk, statically.
  *
- * PATH BY BATCH SIZE. Batches of at most kPairMaxBatch chunks cannot fill the card with one wave per chunk and run
- * two waves per chunk (producer / consumer, lz4_decode_window.hip.h: pair). The threshold is a compile-time
- * constant: the library has no run-time tuning state (tests force either path with an A/B build of this file's macro).
+ * PATH BY BATCH SIZE. Batches of at most kTeamMaxBatch chunks cannot fill the card with one wave per chunk and run a
+ * WORKGROUP of eight waves per chunk (common/lz_team.hip.h); kPairMaxBatch is the same for round 2's two waves per chunk
+ * (producer / consumer, lz4_decode_window.hip.h: pair), which the team supersedes where both apply. The thresholds are
+ * compile-time constants: the library has no run-time tuning state (tests force each path with an A/B build of this
+ * file's macros).
  */
 #pragma once
 
@@ -25,6 +27,9 @@
 
 #ifndef NVCOMP_LZ_PAIR_MAX_BATCH
 #define NVCOMP_LZ_PAIR_MAX_BATCH 3072 /* profiles/r02_pair_decode.json: two waves per chunk win up to ~3 000 chunks */
+#endif
+#ifndef NVCOMP_LZ_TEAM_MAX_BATCH
+#define NVCOMP_LZ_TEAM_MAX_BATCH 4096 /* a WORKGROUP per chunk up to this many chunks (common/lz_team.hip.h) */
 #endif
 #ifndef NVCOMP_LZ_MAX_WG_PER_CU
 #define NVCOMP_LZ_MAX_WG_PER_CU 7 /* cap on the persistent workgroups (of four waves) per CU; 0 = as many as stay resident.
@@ -40,6 +45,7 @@
 namespace lzl {
 
 constexpr size_t kPairMaxBatch = (size_t)(NVCOMP_LZ_PAIR_MAX_BATCH);
+constexpr size_t kTeamMaxBatch = (size_t)(NVCOMP_LZ_TEAM_MAX_BATCH);
 constexpr uint32_t kMaxOutCap = 1u << 26;
 constexpr size_t kTicketBytes = 16; /* what the temp-size queries ask for: one u32 counter, padded */
 

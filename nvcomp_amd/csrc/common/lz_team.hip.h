@@ -1,0 +1,603 @@
+/*
+ * common/lz_team.hip.h -- a WORKGROUP per chunk: the LZ77 decoder for batches that cannot fill the card with one wave per
+ * chunk (nvcompBatched{LZ4,Snappy}DecompressAsync below lzl::kTeamMaxBatch chunks; reference call sites
+ * benchmarks/benchmark_template_chunked.cuh:519-530, benchmarks/benchmark_lz4_synth.cpp:64-72 -- 1 ... 8 192 chunks --,
+ * doc/Benchmarks.md:88-95 -- 5 021 chunks).
+ *
+ * Why: a wave needs ~0.4 ms for a 64 KiB chunk of text-like data whatever the load -- ~1 000 dependent instructions per batch
+ * of 64 sequences, measured the same with every match served from LDS (profiles/r04_feasibility.json) -- so a batch of a few
+ * thousand chunks leaves most of the card idle for most of that time. Here eight waves share ONE chunk:
+ *
+ *   buffer   the chunk's whole OUTPUT (up to 64 KiB) lives in LDS, and so does its whole compressed STREAM, right-aligned
+ *            behind it in the same buffer ("in place": a decoder's write position never passes its read position by more
+ *            than the format's overhead, kMargin covers it; checked every step, a stream that breaks it -- or a chunk
+ *            that does not fit -- is decoded by wave 0 with the one-wave decoder). Every match is an LDS -> LDS copy:
+ *            no far-match gathers, HBM traffic = stream in + output out.
+ *   step     per step the eight waves look at eight consecutive windows of kPositions stream positions, one each:
+ *              1. every wave builds the jump tables of its window (lzw::chase_build: they do not depend on where the
+ *                 token chain enters the window) and -- speculatively -- the exit of the chain that starts at the
+ *                 window's first byte; chains merge within a few tokens, so that exit is almost always the true one;
+ *              2. with the exits of the windows in front of it as its entry a wave enumerates and parses its own
+ *                 tokens; a window whose true exit differs from the speculated one ends the step there (the waves
+ *                 behind it did useless work and repeat it in the next step);
+ *              3. a prefix sum over the waves' output sizes places every sequence; literals are copied;
+ *              4. matches are copied as soon as their source bytes are final: per-granule counters of pending match
+ *                 destinations (16 bytes a granule) tell, the oldest pending match of the step is always free to go.
+ *            Four workgroup barriers a step.
+ *
+ * kPositions is the format's: the largest window that cannot hold more than 64 tokens (LZ4: 192 = 64 x 3 bytes), so a
+ * wave's window is one batch, one sequence per lane.
+ */
+#pragma once
+
+#include "common/lz_window.hip.h"
+
+namespace lzt {
+
+#ifdef LZT_TRACE /* host emulation only: where a team is */
+#define LZT_TR(...) do { if (wave::lane_id() == 0) { fprintf(stderr, __VA_ARGS__); } } while (0)
+#else
+#define LZT_TR(...) ((void)0)
+#endif
+
+#ifndef NVCOMP_LZT_MARGIN
+#define NVCOMP_LZT_MARGIN 2560
+#endif
+constexpr uint32_t kWaves = 8;
+constexpr uint32_t kThreads = 64 * kWaves;
+constexpr uint32_t kMaxOut = 65536;              /* the largest chunk (output capacity) a team takes */
+constexpr uint32_t kMargin = NVCOMP_LZT_MARGIN;  /* room between the end of the output and the end of the stream */
+constexpr uint32_t kBuf = kMaxOut + kMargin + 32; /* + the two 16-byte alignment slacks (output front, stream back) */
+constexpr uint32_t kBufLds = kBuf + 32;          /* zeroes behind the stream: field reads may run past its end */
+constexpr uint32_t kMaxIn = kMaxOut + 512;       /* compressed bytes a team takes (LZ4's bound is 65 809) */
+constexpr uint32_t kGran = 16;                   /* bytes per readiness granule */
+constexpr uint32_t kTrack = 16384;               /* output bytes of a step the granule counters cover */
+constexpr uint32_t kGranules = kTrack / kGran;
+constexpr uint32_t kCntLds = kGranules + 16;     /* one byte a granule (+ what a 4-counter read may touch behind the last) */
+constexpr uint32_t kCtlWords = 48;
+constexpr uint32_t kLds = kBufLds + kWaves * lzw::kChaseLds + kCntLds + 4 * kCtlWords;
+static_assert(kLds <= 81920, "two workgroups per CU");
+static_assert(kWaves * lzw::kChaseLds >= lzw::kLdsPerWave, "the fallback decoder's scratch is the table area");
+
+constexpr uint32_t kUnknownExit = 0xffffffffu;
+
+/* control words in LDS */
+enum : uint32_t {
+  kCtlErr = 0,
+  kCtlFallback = 1,
+  kCtlTicket = 2,
+  kCtlSpec = 4,   /* [kWaves] speculated exit of window w */
+  kCtlExit = 12,  /* [kWaves] true exit */
+  kCtlBytes = 20, /* [kWaves] output bytes of window w's sequences */
+  kCtlProg = 28,  /* [kWaves] everything of slot w below this output position is final */
+  kCtlBad = 36,   /* [kWaves] parse error */
+};
+
+/* The whole chunk's stream, staged in LDS: ring[v] is the byte at virtual position v (v = chunk offset + (chunk & 15)),
+ * the same interface as lzw::InRing without the wrap. */
+struct Stream
+{
+  static constexpr uint32_t kMask = 0xffffffffu;
+  const uint8_t* base; /* chunk pointer rounded down to 16 bytes */
+  uint8_t* ring;
+  uint32_t vbeg, vend;
+  uint32_t lo, hi; /* resident range: everything (hi reaches into the zeroes behind the stream) */
+};
+
+struct Team
+{
+  uint8_t* buf;  /* kBufLds: output position p at buf[p + oa] */
+  uint8_t* tab;  /* this wave's jump tables */
+  uint32_t* cnt; /* granule counters, a byte each */
+  uint32_t* ctl;
+  uint8_t* out;  /* the chunk's output in HBM */
+  uint32_t oa;   /* out & 15 */
+  uint32_t w;    /* wave of the team */
+  Stream st;
+};
+
+__device__ __forceinline__ uint32_t ctl_read(const Team& t, uint32_t i)
+{
+  return wave::uniform(wave::lds_load_acquire(t.ctl + i));
+}
+
+/* all lanes of the team: chunk -> LDS, 16 bytes per lane and step, bytes outside the chunk never fetched (read as zero) */
+__device__ __forceinline__ void stage_stream(const Stream& st, uint32_t tid)
+{
+  const uint32_t nblocks = ((st.vend + 15u) >> 4) + 1u; /* + one block of zeroes */
+  for (uint32_t b = tid; b < nblocks; b += kThreads) {
+    const uint32_t v = 16u * b;
+    wave::u32x4 x = {0, 0, 0, 0};
+    if (v >= st.vbeg && v + 16 <= st.vend) {
+      x = wave::gload_u32x4_aligned(st.base + v);
+    } else if (v + 16 > st.vbeg && v < st.vend) {
+      uint32_t wd[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (uint32_t j = 0; j < 16; ++j) {
+        if (v + j >= st.vbeg && v + j < st.vend) {
+          wd[j >> 2] |= wave::gload_u8(st.base + v + j) << (8 * (j & 3));
+        }
+      }
+      x.x = wd[0], x.y = wd[1], x.z = wd[2], x.w = wd[3];
+    }
+    *(wave::u32x4*)(st.ring + v) = x;
+  }
+}
+
+/* all lanes of the team: output positions [from, to) -> HBM; 16-byte aligned lane stores, bytes around them */
+__device__ __forceinline__ void flush(const Team& t, uint32_t from, uint32_t to, uint32_t tid)
+{
+  if (to <= from) {
+    return;
+  }
+  const uint32_t a_from = from + t.oa, a_to = to + t.oa; /* buffer indices = address-congruent coordinates */
+  uint32_t body_lo = (a_from + 15u) & ~15u;
+  uint32_t body_hi = a_to & ~15u;
+  if (body_lo > body_hi) {
+    body_lo = a_to;
+    body_hi = a_to;
+  }
+  uint8_t* gout = t.out - t.oa;
+  if (tid < body_lo - a_from) {
+    wave::gstore_u8(gout + a_from + tid, t.buf[a_from + tid]);
+  }
+  for (uint32_t a = body_lo + 16u * tid; a < body_hi; a += 16u * kThreads) {
+    wave::gstore_u32x4_aligned(gout + a, *(const wave::u32x4*)(t.buf + a));
+  }
+  if (tid < a_to - body_hi) {
+    wave::gstore_u8(gout + body_hi + tid, t.buf[body_hi + tid]);
+  }
+}
+
+/* The token behind the last one of a window's chain (window offset `last`), from the deltas chase_build kept. */
+template <class Slow>
+__device__ __forceinline__ uint32_t exit_of(const lzw::Chase& c, const Stream& st, uint32_t last, bool speculative, Slow slow)
+{
+  const uint32_t pair = wave::read_lane((last & 2u) ? c.nx23 : c.nx01, last >> 2);
+  const uint32_t d = (last & 1u) ? pair >> 16 : pair & 0xffffu;
+  if (d != lzw::kNxUnknown) {
+    return c.wb + last + d;
+  }
+  return speculative ? kUnknownExit : slow(st, c.wb + last);
+}
+
+/* Speculation: the last token of the chain that starts at window offset 0, by descending the jump tables (uniform reads). */
+__device__ __forceinline__ uint32_t descend(const lzw::Chase& c)
+{
+  uint32_t pos = 0;
+  const uint32_t top = (lzw::kChaseLevels - 1) * lzw::kChaseWin;
+  for (uint32_t it = 0; it < 4; ++it) { /* at most 64 tokens: four jumps of 16 */
+    const uint32_t a = wave::uniform(c.tab[top + pos]);
+    if (a == 255u) {
+      break;
+    }
+    pos += a;
+  }
+#pragma unroll
+  for (int32_t i = (int32_t)lzw::kChaseLevels - 2; i >= 0; --i) {
+    const uint32_t a = wave::uniform(c.tab[(uint32_t)i * lzw::kChaseWin + pos]);
+    pos += a == 255u ? 0u : a;
+  }
+  return pos;
+}
+
+/* Lane n: the n-th token of the chain that enters the window at offset pos0 (lzw::chase_tokens' enumeration); returns the
+ * number of tokens (>= 1) and the window offset of the last one. */
+__device__ __forceinline__ uint32_t enumerate(const lzw::Chase& c, uint32_t pos0, uint32_t& seqpos, uint32_t& last)
+{
+  const uint32_t idx = (uint32_t)wave::fresh_lane_id();
+  const uint32_t top = (lzw::kChaseLevels - 1) * lzw::kChaseWin;
+  const uint32_t t1 = c.tab[top + pos0];
+  const uint32_t t2 = c.tab[top + ((pos0 + t1) & (lzw::kChaseWin - 1))];
+  const bool upper = (idx & 32u) != 0;
+  uint32_t pos = upper ? (pos0 + t1 + t2) & (lzw::kChaseWin - 1) : pos0;
+  uint32_t worst = upper ? (t1 > t2 ? t1 : t2) : 0u;
+#pragma unroll
+  for (uint32_t i = 0; i < lzw::kChaseLevels; ++i) {
+    const uint32_t a = c.tab[i * lzw::kChaseWin + pos];
+    const uint32_t adv = a & (uint32_t)(-(int32_t)((idx >> i) & 1u));
+    worst = adv > worst ? adv : worst;
+    pos = (pos + adv) & (lzw::kChaseWin - 1);
+  }
+  const uint32_t count = wave::popc64(wave::ballot(worst != 255u));
+  seqpos = idx < count ? c.wb + pos : 0u;
+  last = wave::read_lane(pos, count - 1);
+  return count;
+}
+
+/* granule counters: a byte each, four to a word */
+__device__ __forceinline__ void cnt_adjust(uint32_t* cnt, uint32_t ga, uint32_t n, bool add)
+{
+  /* n = 1..3 consecutive granules from ga on: one or two word updates */
+  const uint64_t inc = (uint64_t)(0x010101u >> (8u * (3u - n))) << (8u * (ga & 3u));
+  const uint32_t lo = (uint32_t)inc, hi = (uint32_t)(inc >> 32);
+  if (add) {
+    wave::lds_add(cnt + (ga >> 2), lo);
+    if (hi) {
+      wave::lds_add(cnt + (ga >> 2) + 1, hi);
+    }
+  } else {
+    wave::lds_sub(cnt + (ga >> 2), lo);
+    if (hi) {
+      wave::lds_sub(cnt + (ga >> 2) + 1, hi);
+    }
+  }
+}
+
+/* the whole wave: granules [ga, gb] of one long match */
+__device__ __forceinline__ void cnt_adjust_range(uint32_t* cnt, uint32_t ga, uint32_t gb, bool add)
+{
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
+  for (uint32_t g = ga + lane; g <= gb; g += 64) {
+    const uint32_t v = 1u << (8u * (g & 3u));
+    if (add) {
+      wave::lds_add(cnt + (g >> 2), v);
+    } else {
+      wave::lds_sub(cnt + (g >> 2), v);
+    }
+  }
+}
+
+/* the four counters from granule g on */
+__device__ __forceinline__ uint32_t cnt_read4(const uint32_t* cnt, uint32_t g)
+{
+  const uint32_t a = cnt[g >> 2], b = cnt[(g >> 2) + 1];
+  return wave::align_bytes(b, a, g & 3u);
+}
+
+/*
+ * Decode one chunk with the calling workgroup (kThreads lanes, all of them call). `lds` = kLds bytes, 16-byte aligned.
+ * FrontEnd supplies the format: kPositions, DeltaFn / SlowFn (the chase's distance functions) and parse_batch().
+ * Returns the bytes produced; err != 0 on a malformed chunk. Always validates (a team never writes outside its buffer).
+ */
+template <class FrontEnd, class Fallback>
+__device__ __forceinline__ uint32_t decode_chunk(
+    const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_cap, uint8_t* lds, uint32_t& err, Fallback fallback)
+{
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  Team t;
+  t.buf = lds;
+  t.w = wave::uniform(tid >> 6);
+  t.tab = lds + kBufLds + t.w * lzw::kChaseLds;
+  t.cnt = (uint32_t*)(lds + kBufLds + kWaves * lzw::kChaseLds);
+  t.ctl = (uint32_t*)(lds + kBufLds + kWaves * lzw::kChaseLds + kCntLds);
+  t.out = out;
+  t.oa = (uint32_t)((uintptr_t)out & 15u);
+  err = lz::kErrNone;
+  if (in_len == 0) {
+    return 0;
+  }
+  uint8_t* fb_scratch = lds + kBufLds;
+  if (out_cap > kMaxOut || in_len > kMaxIn) {
+    /* not a team's chunk: the one-wave decoder, by wave 0 */
+    uint32_t produced = 0;
+    if (t.w == 0) {
+      produced = fallback(in, in_len, out, out_cap, fb_scratch, err);
+      if (lane == 0) {
+        t.ctl[kCtlErr] = err;
+        t.ctl[kCtlTicket] = produced;
+      }
+    }
+    __syncthreads();
+    err = ctl_read(t, kCtlErr);
+    produced = ctl_read(t, kCtlTicket);
+    __syncthreads();
+    return produced;
+  }
+  const uint32_t ia = (uint32_t)((uintptr_t)in & 15u);
+  t.st.base = in - ia;
+  t.st.vbeg = ia;
+  t.st.vend = ia + in_len;
+  const uint32_t sb = (kBuf - t.st.vend) & ~15u; /* the stream ends at the end of the buffer, 16-byte congruent with HBM */
+  t.st.ring = lds + sb;
+  t.st.lo = 0;
+  t.st.hi = t.st.vend + 16;
+  const Stream& st = t.st;
+  if (tid < kCtlWords) {
+    t.ctl[tid] = 0;
+  }
+  for (uint32_t i = tid; i < kCntLds / 4; i += kThreads) {
+    t.cnt[i] = 0; /* (every match that registers here leaves again: the counters are zero between steps) */
+  }
+  stage_stream(st, tid);
+  __syncthreads();
+
+  lzw::Chase c;
+  c.tab = t.tab;
+  c.nx01 = 0, c.nx23 = 0, c.wb = 0, c.q = 0;
+  uint32_t q = st.vbeg; /* the next token */
+  uint32_t op = 0;      /* output produced (all of it final) */
+  uint32_t flushed = 0; /* output written to HBM */
+  bool give_up = false; /* in-place invariant broken: the one-wave decoder redoes the chunk */
+  typename FrontEnd::Delta delta;
+  typename FrontEnd::Slow slow;
+  while (q < st.vend) {
+    /* ---- 1. tables of this wave's window, speculated exit; HBM gets what the previous step finished ---- */
+    {
+      const uint32_t upto = ((op + t.oa) & ~15u) - t.oa; /* whole 16-byte blocks only (op + oa >= 16 or nothing to do) */
+      if ((op + t.oa) >= 16 && upto > flushed) {
+        flush(t, flushed, upto, tid);
+        flushed = upto;
+      }
+    }
+    LZT_TR("w%u step q=%u op=%u\n", t.w, q, op);
+    const uint32_t wb = q + FrontEnd::kPositions * t.w;
+    const bool have_window = wb < st.vend;
+    if (have_window) {
+      c.q = wb;
+      lzw::chase_build(c, st, delta, FrontEnd::kPositions);
+      if (t.w + 1 < kWaves) { /* (window 0 is entered at its first byte: its "speculation" is the truth; nobody enters behind the last window) */
+        const uint32_t x = exit_of(c, st, descend(c), true, slow);
+        if (lane == 0) {
+          t.ctl[kCtlSpec + t.w] = x;
+        }
+      }
+    } else if (lane == 0) {
+      t.ctl[kCtlSpec + t.w] = kUnknownExit;
+    }
+    LZT_TR("w%u A\n", t.w);
+    __syncthreads();
+    /* ---- 2. entry = the exit speculated by the window in front; enumerate, parse, sizes ---- */
+    const uint32_t entry = t.w == 0 ? q : ctl_read(t, kCtlSpec + t.w - 1);
+    uint32_t n = 0;
+    uint32_t my_exit = entry;
+    uint32_t seqpos = 0;
+    lz::Seq s;
+    s.lit_src = 0, s.lit_len = 0, s.match_off = 0, s.match_len = 0;
+    bool bad = false;
+    if (have_window && entry != kUnknownExit && entry - wb < FrontEnd::kPositions && entry < st.vend) {
+      uint32_t last;
+      n = enumerate(c, entry - wb, seqpos, last);
+      my_exit = exit_of(c, st, last, false, slow);
+      FrontEnd::parse_batch(st, seqpos, 0, n, s, bad);
+    }
+    const uint32_t len = s.lit_len + s.match_len;
+    const uint32_t incl = wave::scan_add_inclusive(len);
+    const uint32_t total = wave::read_lane(incl, 63);
+    const uint64_t bad_lanes = wave::ballot(bad);
+    LZT_TR("w%u B entry=%u n=%u exit=%u total=%u\n", t.w, entry, n, my_exit, total);
+    if (lane == 0) {
+      t.ctl[kCtlExit + t.w] = my_exit;
+      t.ctl[kCtlBytes + t.w] = total;
+      t.ctl[kCtlBad + t.w] = bad_lanes ? 1u : 0u;
+    }
+    __syncthreads();
+    /* ---- 3. which windows stand, where their output goes; literals; pending matches registered ---- */
+    /* lane j < kWaves looks at window j: it stands when every window in front of it stands and left through the exit
+     * that window j was entered by */
+    uint32_t sp = 0, ex = 0, by = 0, bd = 0;
+    if (lane < kWaves) {
+      sp = t.ctl[kCtlSpec + lane];
+      ex = t.ctl[kCtlExit + lane];
+      by = t.ctl[kCtlBytes + lane];
+      bd = t.ctl[kCtlBad + lane];
+    }
+    /* window j + 1 stands iff window j stands and exit[j] == spec[j] (what j + 1 entered by) */
+    const uint64_t chain_ok = wave::ballot(lane < kWaves && (lane + 1 == kWaves || ex == sp));
+    const uint32_t broken = wave::ctz64(~chain_ok);            /* first window whose exit was not the speculated one */
+    const uint32_t standing = broken + 1 < kWaves ? broken + 1 : kWaves; /* windows 0 .. standing - 1 stand */
+    const bool stands = t.w < standing;
+    const uint32_t by_ok = lane < standing ? by : 0u;
+    const uint32_t by_incl = wave::scan_add_inclusive(by_ok);
+    const uint32_t slot_end = op + by_incl; /* lane j: the end of slot j (slots behind `standing` are empty) */
+    const uint32_t step_bytes = wave::read_lane(by_incl, 63);
+    const uint32_t base = op + wave::read_lane(by_incl - by_ok, t.w);
+    const uint32_t next_q = wave::read_lane(ex, standing - 1);
+    const uint32_t any_bad = wave::ballot(lane < standing && bd != 0) ? 1u : 0u;
+    const uint32_t step_end = op + step_bytes;
+    if (any_bad || step_end > out_cap || next_q <= q) { /* (a step always consumes its first token) */
+      err |= any_bad || next_q <= q ? lz::kErrInput : lz::kErrOutput;
+      break;
+    }
+    if (step_end + t.oa > sb + next_q) { /* the output would reach into the stream the next step reads */
+      give_up = true;
+      break;
+    }
+    LZT_TR("w%u standing=%u base=%u step_end=%u next_q=%u\n", t.w, standing, base, step_end, next_q);
+    const bool hazard = step_end + t.oa > sb + q; /* this step's output overwrites stream bytes its own literals come from */
+    const uint32_t T0 = op & ~(kGran - 1);
+    const uint32_t lit_dst = base + incl - len;
+    const uint32_t match_dst = lit_dst + s.lit_len;
+    const uint32_t my_lit = stands ? s.lit_len : 0u;
+    const uint32_t my_match = stands ? s.match_len : 0u;
+    const uint32_t match_src = match_dst - s.match_off;
+    const uint64_t bad_off = wave::ballot(my_match != 0 && s.match_off - 1 >= match_dst);
+    if (bad_off && lane == 0) {
+      t.ctl[kCtlErr] = lz::kErrOffset;
+    }
+    const bool short_match = my_match - 4 <= lzw::kMatchShort - 4;
+    const bool lane_class = short_match && s.match_off >= 4;
+    const uint64_t lane_class_mask = wave::ballot(lane_class);
+    /* what must be final before this match may start: its source, up to its own first byte */
+    const uint32_t need_end = match_src + my_match < match_dst ? match_src + my_match : match_dst;
+    const uint32_t ga = (match_dst - T0) / kGran;
+    uint32_t gb = (match_dst + my_match - 1 - T0) / kGran;
+    gb = gb < kGranules ? gb : kGranules - 1;
+    const bool tracked = my_match != 0 && ga < kGranules;
+    if (!bad_off) {
+      /* literals */
+      uint8_t* dst = t.buf + t.oa + lit_dst;
+      const bool lit_own = my_lit - 1 < lzw::kLitShort;
+      if (wave::ballot(lit_own && my_lit >= 4)) {
+        const bool lit_lane = lit_own && my_lit >= 4;
+        const uint32_t steps = lzw::steps_for(lit_lane, my_lit);
+        if (lit_lane) {
+          const uint32_t lastd = my_lit - 4;
+          uint32_t data[8];
+#pragma unroll
+          for (uint32_t i = 0; i < 8; ++i) {
+            if (i < steps) {
+              const uint32_t o = 4 * i < lastd ? 4 * i : lastd;
+              data[i] = hazard ? wave::gload_u32(st.base + s.lit_src + o) : lzw::ld32(st.ring + s.lit_src + o);
+            }
+          }
+#pragma unroll
+          for (uint32_t i = 0; i < 8; ++i) {
+            if (i < steps) {
+              const uint32_t o = 4 * i < lastd ? 4 * i : lastd;
+              lz::st_u32(dst + o, data[i]);
+            }
+          }
+        }
+      }
+      if (wave::ballot(lit_own && my_lit < 4)) {
+        if (lit_own && my_lit < 4) {
+          uint32_t b0, b1 = 0, b2 = 0;
+          if (hazard) {
+            b0 = wave::gload_u8(st.base + s.lit_src);
+            b1 = my_lit > 1 ? wave::gload_u8(st.base + s.lit_src + 1) : 0u;
+            b2 = my_lit > 2 ? wave::gload_u8(st.base + s.lit_src + 2) : 0u;
+          } else {
+            b0 = st.ring[s.lit_src];
+            b1 = my_lit > 1 ? st.ring[s.lit_src + 1] : 0u;
+            b2 = my_lit > 2 ? st.ring[s.lit_src + 2] : 0u;
+          }
+          dst[0] = (uint8_t)b0;
+          if (my_lit > 1) {
+            dst[1] = (uint8_t)b1;
+          }
+          if (my_lit > 2) {
+            dst[2] = (uint8_t)b2;
+          }
+        }
+      }
+      for (uint64_t m = wave::ballot(my_lit != 0 && !lit_own); m; m &= m - 1) {
+        const uint32_t j = wave::ctz64(m);
+        /* long runs come from the chunk in HBM: nothing another wave writes can be in their way */
+        lzw::copy_to_lds(t.buf + t.oa + wave::read_lane(lit_dst, j), st.base + wave::read_lane(s.lit_src, j), wave::read_lane(my_lit, j));
+      }
+      /* pending matches: their destination granules */
+      if (tracked && short_match) {
+        cnt_adjust(t.cnt, ga, gb - ga + 1, true);
+      }
+      for (uint64_t m = wave::ballot(tracked && !short_match); m; m &= m - 1) {
+        const uint32_t j = wave::ctz64(m);
+        cnt_adjust_range(t.cnt, wave::read_lane(ga, j), wave::read_lane(gb, j), true);
+      }
+    }
+    uint64_t pending = bad_off ? 0ull : wave::ballot(my_match != 0);
+    const uint32_t my_end = wave::read_lane(slot_end, t.w);
+    const uint32_t first_pending = pending ? wave::read_lane(match_dst, wave::ctz64(pending)) : my_end;
+    if (lane == 0) {
+      wave::lds_store_release(t.ctl + kCtlProg + t.w, first_pending);
+    }
+    LZT_TR("w%u L pending=%llx\n", t.w, (unsigned long long)pending);
+    __syncthreads();
+    if (ctl_read(t, kCtlErr)) {
+      err |= lz::kErrOffset;
+      break;
+    }
+    /* ---- 4. matches, as their sources become final ---- */
+    while (pending) {
+      const uint32_t f = wave::ctz64(pending);
+      const uint32_t hw = wave::read_lane(match_dst, f);
+      if (lane == 0) {
+        wave::lds_store_release(t.ctl + kCtlProg + t.w, hw);
+      }
+      /* the step's frontier: the oldest pending match of the first slot that has one (every byte below it is final) */
+      uint32_t pg = 0xffffffffu;
+      if (lane < kWaves) {
+        pg = wave::lds_load_acquire(t.ctl + kCtlProg + lane);
+      }
+      const uint64_t open = wave::ballot(lane < kWaves && pg < slot_end);
+      const uint32_t frontier = open ? wave::read_lane(pg, wave::ctz64(open)) : step_end;
+      /* lane-class matches: granule counters of the source range (at most three granules), minus this match's own count
+       * where its destination starts in the granule its source ends in */
+      bool ready = false;
+      if (wave::lane_in(pending)) {
+        const bool below = need_end <= op;
+        bool counted = false;
+        if (!below && need_end <= T0 + kTrack) {
+          const uint32_t s0 = match_src > T0 ? match_src - T0 : 0u;
+          const uint32_t sa = s0 / kGran, sbg = (need_end - 1 - T0) / kGran;
+          const uint32_t c4 = cnt_read4(t.cnt, sa);
+          const uint32_t ng = sbg - sa + 1; /* 1 .. 3 for a lane-class match */
+          const uint32_t mask = ng >= 4 ? 0xffffffffu : (1u << (8u * ng)) - 1u;
+          const uint32_t self = (tracked && sbg == ga) ? 1u << (8u * (sbg - sa)) : 0u;
+          counted = ng <= 4 && (c4 & mask) == self;
+        }
+        ready = below || counted || need_end <= frontier || match_dst == frontier;
+      }
+      if (!((lane_class_mask >> f) & 1)) {
+        /* the wave's oldest pending match is long or has a period below 4: the whole wave copies it once everything
+         * in front of it is final */
+        const uint32_t f_need = wave::read_lane(need_end, f);
+        if (f_need <= frontier || f_need <= op || hw == frontier) {
+          lzw::lds_match_copy(t.buf + t.oa + hw, wave::read_lane(s.match_off, f), wave::read_lane(my_match, f));
+          if (wave::read_lane(tracked ? 1u : 0u, f)) {
+            if (wave::read_lane(short_match ? 1u : 0u, f)) {
+              if (lane == f) {
+                cnt_adjust(t.cnt, ga, gb - ga + 1, false);
+              }
+            } else {
+              cnt_adjust_range(t.cnt, wave::read_lane(ga, f), wave::read_lane(gb, f), false);
+            }
+          }
+          pending &= ~(1ull << f);
+          continue;
+        }
+      }
+      const bool go = ready && lane_class;
+      const uint64_t gone = wave::ballot(go);
+      if (gone) {
+        const uint32_t steps = lzw::steps_for(go, my_match);
+        if (go) {
+          const uint8_t* src = t.buf + t.oa + match_src;
+          uint8_t* dst = t.buf + t.oa + match_dst;
+          if (steps == 2) {
+            lzw::copy_dwords_clamped<2>(dst, src, my_match);
+          } else if (steps == 4) {
+            lzw::copy_dwords_clamped<4>(dst, src, my_match);
+          } else {
+            lzw::copy_dwords_clamped<8>(dst, src, my_match);
+          }
+        }
+        wave::sync();
+        if (go && tracked) {
+          cnt_adjust(t.cnt, ga, gb - ga + 1, false);
+        }
+        pending &= ~gone;
+      } else {
+        if (ctl_read(t, kCtlErr)) {
+          break;
+        }
+        wave::nap();
+      }
+    }
+    if (lane == 0) {
+      wave::lds_store_release(t.ctl + kCtlProg + t.w, my_end);
+    }
+    LZT_TR("w%u C\n", t.w);
+    __syncthreads();
+    op = step_end;
+    q = next_q;
+  }
+  /* every wave leaves the loop at the same point (the conditions are uniform across the team) */
+  __syncthreads();
+  if (give_up) {
+    uint32_t produced = 0;
+    if (t.w == 0) {
+      produced = fallback(in, in_len, out, out_cap, fb_scratch, err);
+      if (lane == 0) {
+        t.ctl[kCtlErr] = err;
+        t.ctl[kCtlTicket] = produced;
+      }
+    }
+    __syncthreads();
+    err = ctl_read(t, kCtlErr);
+    produced = ctl_read(t, kCtlTicket);
+    __syncthreads();
+    return produced;
+  }
+  if (err) {
+    return 0;
+  }
+  /* (a last token that claims more than the chunk holds was refused by the parser; the chase itself may report
+   * "behind the end" for a chunk's regular last sequence) */
+  flush(t, flushed, op, tid);
+  __syncthreads(); /* the buffer is free again */
+  return op;
+}
+
+} // namespace lzt

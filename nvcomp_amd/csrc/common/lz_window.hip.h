@@ -129,6 +129,7 @@ __device__ __forceinline__ void prof_end()
 
 struct InRing
 {
+  static constexpr uint32_t kMask = kInRing - 1; /* ring index of virtual position v = v & kMask */
   const uint8_t* base; /* chunk pointer rounded down to 16 bytes (uniform) */
   uint8_t* ring;       /* LDS, kInLds bytes, 16-byte aligned */
   uint32_t vbeg;       /* virtual position of the first chunk byte: chunk & 15 */
@@ -201,22 +202,26 @@ __device__ __forceinline__ void in_ensure(InRing& r, uint32_t q, uint32_t want_h
   }
 }
 
-__device__ __forceinline__ bool in_resident(const InRing& r, uint32_t v_lo, uint32_t v_hi)
+template <class R>
+__device__ __forceinline__ bool in_resident(const R& r, uint32_t v_lo, uint32_t v_hi)
 {
   return v_lo >= r.lo && v_hi <= r.hi;
 }
 
-/* Byte at virtual position v (per lane): LDS when resident, HBM otherwise. */
-__device__ __forceinline__ uint32_t in_byte(const InRing& r, uint32_t v)
+/* Byte at virtual position v (per lane): LDS when resident, HBM otherwise. The stream type R is lzw::InRing (a wave's
+ * ring over the chunk) or lzt::Stream (common/lz_team.hip.h: the whole chunk staged in LDS, kMask = all ones). */
+template <class R>
+__device__ __forceinline__ uint32_t in_byte(const R& r, uint32_t v)
 {
   if (v >= r.lo && v < r.hi) {
-    return r.ring[v & (kInRing - 1)];
+    return r.ring[v & R::kMask];
   }
   return wave::gload_u8(r.base + v);
 }
 
 /* Same for a wave-uniform position; the result is uniform. */
-__device__ __forceinline__ uint32_t in_byte_uniform(const InRing& r, uint32_t v)
+template <class R>
+__device__ __forceinline__ uint32_t in_byte_uniform(const R& r, uint32_t v)
 {
   return wave::uniform(in_byte(r, v));
 }
@@ -257,13 +262,15 @@ __device__ __forceinline__ void chase_init(Chase& c, uint32_t q, uint8_t* lds)
  * bytes come from two dword reads of the ring and their table entries are written as one dword.
  * A window is "interior" when every byte a delta may look at is resident and before the end of
  * the chunk; the format's `fast` delta then needs no bounds tests at all. */
-template <class Delta>
-__device__ __forceinline__ void chase_build(Chase& c, const InRing& r, Delta delta)
+template <class R, class Delta>
+__device__ __forceinline__ void chase_build(Chase& c, const R& r, Delta delta, uint32_t positions = kChaseWin)
 {
+  /* `positions` (<= kChaseWin, uniform): only the first that many window positions count as inside the window -- the
+   * workgroup-per-chunk decoder (common/lz_team.hip.h) cuts its windows where 64 lanes are sure to hold every token */
   const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   c.wb = c.q;
   const uint32_t room = r.vend - c.wb; /* c.q < vend */
-  const uint32_t limit = room < kChaseWin ? room : kChaseWin;
+  const uint32_t limit = room < positions ? room : positions;
   const uint32_t reach = c.wb + kChaseWin + Delta::kReach;
   const bool interior = c.wb >= r.lo && reach <= r.hi && reach <= r.vend;
   const uint32_t base = c.wb + 4 * lane;
@@ -271,9 +278,9 @@ __device__ __forceinline__ void chase_build(Chase& c, const InRing& r, Delta del
   if (interior) {
     /* 8 stream bytes from `base` on, from three aligned dwords (a misaligned ds_read_b32 costs 16x) */
     const uint32_t a0 = base & ~3u;
-    const uint32_t d0 = *(const uint32_t*)(r.ring + (a0 & (kInRing - 1)));
-    const uint32_t d1 = *(const uint32_t*)(r.ring + ((a0 + 4) & (kInRing - 1)));
-    const uint32_t d2 = *(const uint32_t*)(r.ring + ((a0 + 8) & (kInRing - 1)));
+    const uint32_t d0 = *(const uint32_t*)(r.ring + (a0 & R::kMask));
+    const uint32_t d1 = *(const uint32_t*)(r.ring + ((a0 + 4) & R::kMask));
+    const uint32_t d2 = *(const uint32_t*)(r.ring + ((a0 + 8) & R::kMask));
     const uint32_t w0 = wave::align_bytes(d1, d0, base & 3u);
     const uint32_t w1 = wave::align_bytes(d2, d1, base & 3u);
     const uint64_t w = ((uint64_t)w1 << 32) | w0;
@@ -326,9 +333,9 @@ __device__ __forceinline__ void chase_build(Chase& c, const InRing& r, Delta del
 
 /* Append token positions to seqpos lanes [k, 64); returns the new count. `slow(r, p)`
  * gives the successor of the token at p when its delta is kUnknownDelta. */
-template <class Delta, class Slow>
+template <class R, class Delta, class Slow>
 __device__ __forceinline__ uint32_t chase_tokens(
-    Chase& c, const InRing& r, uint32_t& seqpos, uint32_t k, Delta delta, Slow slow)
+    Chase& c, const R& r, uint32_t& seqpos, uint32_t k, Delta delta, Slow slow)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   while (k < 64 && c.q < r.vend) {

@@ -285,6 +285,16 @@ __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t bits)
   __hip_atomic_fetch_or(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+/* LDS word += / -= v, no return value (ds_add_u32 / ds_sub_u32): lanes of one instruction, and several waves, may hit the same word. */
+__device__ __forceinline__ void lds_add(uint32_t* p, uint32_t v)
+{
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_sub(uint32_t* p, uint32_t v)
+{
+  __hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 /* ---- two waves of one workgroup handing work to each other through LDS (producer / consumer) ----
  * A flag word is written after, and read before, the data it guards; both sides are single instruction streams whose
  * LDS operations are served in issue order, the release / acquire pair stops the compiler and drains the counters. */

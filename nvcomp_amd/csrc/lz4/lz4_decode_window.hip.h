@@ -23,9 +23,10 @@ constexpr uint32_t kUnknown = 1u << 28;
 
 /* The 8 (4) stream bytes at virtual position p -- those of them that are resident, the others are whatever the ring
  * holds there: three (two) aligned dword reads (a misaligned ds_read_b32 is served lane by lane) and a funnel shift. */
-__device__ __forceinline__ uint64_t ring_bytes8(const lzw::InRing& r, uint32_t p)
+template <class R>
+__device__ __forceinline__ uint64_t ring_bytes8(const R& r, uint32_t p)
 {
-  const uint32_t m = lzw::kInRing - 1;
+  const uint32_t m = R::kMask;
   const uint32_t a0 = p & ~3u;
   const uint32_t d0 = *(const uint32_t*)(r.ring + (a0 & m));
   const uint32_t d1 = *(const uint32_t*)(r.ring + ((a0 + 4) & m));
@@ -34,9 +35,10 @@ __device__ __forceinline__ uint64_t ring_bytes8(const lzw::InRing& r, uint32_t p
   const uint32_t hi = wave::align_bytes(d2, d1, p & 3u);
   return ((uint64_t)hi << 32) | lo;
 }
-__device__ __forceinline__ uint32_t ring_bytes4(const lzw::InRing& r, uint32_t p)
+template <class R>
+__device__ __forceinline__ uint32_t ring_bytes4(const R& r, uint32_t p)
 {
-  const uint32_t m = lzw::kInRing - 1;
+  const uint32_t m = R::kMask;
   const uint32_t a0 = p & ~3u;
   const uint32_t d0 = *(const uint32_t*)(r.ring + (a0 & m));
   const uint32_t d1 = *(const uint32_t*)(r.ring + ((a0 + 4) & m));
@@ -57,10 +59,11 @@ __device__ __forceinline__ uint32_t leading_255(uint64_t f)
  * is all matches of 170 .. 680 bytes, and with one extension byte every one of its tokens left the chase through the
  * scalar slow path, one enumeration per token (profiles/r03_pmc_mortgage.json: 155 scalar instructions per sequence).
  * Longer fields -> kUnknown -> chase_slow_next(). */
-__device__ __forceinline__ uint32_t token_delta(const lzw::InRing& r, uint32_t p)
+template <class R>
+__device__ __forceinline__ uint32_t token_delta(const R& r, uint32_t p)
 {
   const uint8_t* ring = r.ring;
-  const uint32_t m = lzw::kInRing - 1;
+  const uint32_t m = R::kMask;
   const uint32_t t = ring[p & m];
   const uint32_t e1 = ring[(p + 1) & m];
   const uint32_t e1b = ring[(p + 2) & m];
@@ -87,7 +90,8 @@ __device__ __forceinline__ uint32_t token_delta(const lzw::InRing& r, uint32_t p
  * arguments. A chunk that is ONE literal run or ONE match -- incompressible data, zeros -- spells its length in 257 such
  * bytes, and walking them one dependent LDS read at a time (twice: once for the chase, once for the parser) took a third
  * of such a chunk's time. */
-__device__ __forceinline__ uint32_t scan_length_bytes(const lzw::InRing& r, uint32_t pos, uint32_t& sum)
+template <class R>
+__device__ __forceinline__ uint32_t scan_length_bytes(const R& r, uint32_t pos, uint32_t& sum)
 {
   const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   for (;;) {
@@ -110,7 +114,8 @@ __device__ __forceinline__ uint32_t scan_length_bytes(const lzw::InRing& r, uint
 }
 
 /* Scalar walk over one token with multi-byte length extensions. */
-__device__ __forceinline__ uint32_t chase_slow_next(const lzw::InRing& r, uint32_t q)
+template <class R>
+__device__ __forceinline__ uint32_t chase_slow_next(const R& r, uint32_t q)
 {
   const uint32_t vend = r.vend;
   const uint32_t t = lzw::in_byte_uniform(r, q);
@@ -141,9 +146,11 @@ struct DeltaFn
 {
   /* a delta looks at most this far past its position: token, 2 length bytes, 15 + 254 literals, offset, 8 bytes of length */
   static constexpr uint32_t kReach = 288;
-  __device__ __forceinline__ uint32_t operator()(const lzw::InRing& r, uint32_t p) const { return token_delta(r, p); }
+  template <class R>
+  __device__ __forceinline__ uint32_t operator()(const R& r, uint32_t p) const { return token_delta(r, p); }
   /* interior window: `w` = the stream bytes from p on (token in bits 0-7, the byte behind it in 8-15) */
-  __device__ __forceinline__ uint32_t fast(const lzw::InRing& r, uint32_t p, uint64_t w) const
+  template <class R>
+  __device__ __forceinline__ uint32_t fast(const R& r, uint32_t p, uint64_t w) const
   {
     /* straight-line on purpose (no ||, no early exit): the byte a match-length extension would use is read whatever
      * the token says, so that the four positions of a lane compile to one instruction stream without exec-mask
@@ -154,7 +161,7 @@ struct DeltaFn
     const uint32_t lit_ext = lit_code == 15 ? 1u : 0u;
     const uint32_t d0 = 3 + lit_code + (lit_ext ? e1 + 1u : 0u); /* to the byte a match-length extension would use */
     const uint32_t m_ext = (t & 15u) == 15u ? 1u : 0u;
-    const uint32_t e2 = r.ring[(p + d0) & (lzw::kInRing - 1)];
+    const uint32_t e2 = r.ring[(p + d0) & R::kMask];
     const uint32_t unknown = (lit_ext & (e1 == 255 ? 1u : 0u)) | (m_ext & (e2 == 255 ? 1u : 0u));
     return unknown ? kUnknown : d0 + m_ext;
   }
@@ -162,7 +169,8 @@ struct DeltaFn
    * to six extension bytes -- 274 .. 1 548 bytes, every sequence of a sorted key column -- is resolved here; everything
    * longer stays with the scalar walk */
   static constexpr bool kSecondChance = true;
-  __device__ __forceinline__ uint32_t second(const lzw::InRing& r, uint32_t p, uint64_t w) const
+  template <class R>
+  __device__ __forceinline__ uint32_t second(const R& r, uint32_t p, uint64_t w) const
   {
     const uint32_t t = (uint32_t)w & 0xffu;
     const uint32_t e1 = (uint32_t)(w >> 8) & 0xffu;
@@ -176,13 +184,15 @@ struct DeltaFn
 };
 struct SlowFn
 {
-  __device__ __forceinline__ uint32_t operator()(const lzw::InRing& r, uint32_t p) const { return chase_slow_next(r, p); }
+  template <class R>
+  __device__ __forceinline__ uint32_t operator()(const R& r, uint32_t p) const { return chase_slow_next(r, p); }
 };
 
 /* Lane-parallel field decode of the sequence whose token is at virtual position p (the general parser: any length, any
  * residency, the chunk's last sequence). A lane reads the first byte of a length field itself; a field that goes on
  * behind a 255 is finished by the whole wave, one such lane after the other (scan_length_bytes). */
-__device__ __forceinline__ void parse(const lzw::InRing& r, uint32_t p, bool active, lz::Seq& s, bool& bad)
+template <class R>
+__device__ __forceinline__ void parse(const R& r, uint32_t p, bool active, lz::Seq& s, bool& bad)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   const uint32_t vend = r.vend;
@@ -280,7 +290,8 @@ __device__ __forceinline__ void parse(const lzw::InRing& r, uint32_t p, bool act
  * longer match -- go through parse() together afterwards. (Until the middle of round 3 ONE such lane sent the whole
  * batch to parse(), which finishes a field with a second extension byte one lane after the other: every batch of a
  * sorted key column -- matches of 170 .. 680 bytes -- and the last 40 sequences of every such chunk.) */
-__device__ __forceinline__ void parse_batch(const lzw::InRing& r, uint32_t p, uint32_t from, uint32_t to, lz::Seq& s, bool& bad)
+template <class R>
+__device__ __forceinline__ void parse_batch(const R& r, uint32_t p, uint32_t from, uint32_t to, lz::Seq& s, bool& bad)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   const bool active = lane - from < to - from;
@@ -320,6 +331,19 @@ __device__ __forceinline__ void parse_batch(const lzw::InRing& r, uint32_t p, ui
     }
   }
 }
+
+/* What the workgroup-per-chunk decoder (common/lz_team.hip.h) needs to know of the format. */
+struct TeamFrontEnd
+{
+  static constexpr uint32_t kPositions = 192; /* a sequence is at least 3 bytes (token + offset): 64 tokens at most */
+  using Delta = DeltaFn;
+  using Slow = SlowFn;
+  template <class R>
+  static __device__ __forceinline__ void parse_batch(const R& r, uint32_t p, uint32_t from, uint32_t to, lz::Seq& s, bool& bad)
+  {
+    lz4w::parse_batch(r, p, from, to, s, bad);
+  }
+};
 
 /* Decode one chunk with the calling wave; `lds` is this wave's kLdsPerWave bytes. */
 /* ABLATE (profiling builds only, results are wrong by construction): 1 = stop after the

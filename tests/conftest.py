@@ -75,7 +75,7 @@ _emu_path_libs = {}
 
 def emu_path_library(path):
     """The emulation build with one LZ decode path forced whatever the batch size ("chase": one persistent wave per
-    chunk, "pair": two waves per chunk). The product picks by batch size (common/lz_launch.hip.h); these are A/B builds
+    chunk, "pair": two waves per chunk, "team": a workgroup per chunk). The product picks by batch size (common/lz_launch.hip.h); these are A/B builds
     of the same sources with another compile-time threshold."""
     if path not in _emu_path_libs:
         from nvcomp_amd import _lib
@@ -127,7 +127,7 @@ def backend(request):
     return Backend(b.name, b.lib, b.dev)
 
 
-@pytest.fixture(params=["default", "chase", "pair"])
+@pytest.fixture(params=["default", "chase", "pair", "team"])
 def lz_path(request, backend):
     """All decode paths of nvcompBatched{LZ4,Snappy}DecompressAsync, whatever the batch size."""
     if request.param != "default":

@@ -196,6 +196,8 @@ inline uint32_t reduce_add(uint32_t v)
 inline void sync() { emu::wave_rendezvous(kSync, 0, 0); }
 
 inline void lds_or(uint32_t* p, uint32_t bits) { *p |= bits; }
+inline void lds_add(uint32_t* p, uint32_t v) { *p += v; }
+inline void lds_sub(uint32_t* p, uint32_t v) { *p -= v; }
 inline void lds_store_release(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }
 inline uint32_t lds_load_acquire(const uint32_t* p) { return *(const volatile uint32_t*)p; }
 inline void nap() { sync(); } /* a rendezvous is where the coroutine scheduler lets the other wave run */
