@@ -401,11 +401,12 @@ def run_case(args, ctx):
         },
     }
     if rank == 0:
-        traffic, traffic_source = replayed_traffic(args.algo, "decompress", args.dataset, n)
+        traffic, traffic_source = replayed_traffic(args.algo, "decompress_unchecked" if args.unchecked else "decompress",
+                                                   args.dataset, n)
         result["roofline"] = {
             "bound": "hbm",
             "kernel": (f"{args.algo}_decompress_kernel" if own_format or args.algo == "deflate"
-                       else f"{args.algo}_decompress_window_kernel"),
+                       else lz_decode_kernel(args.algo, n)),
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
@@ -566,11 +567,19 @@ def deflate_cpu_baseline(oracle, comp, chunks, threads, unique):
                       "from Python threads"}
 
 
+def lz_decode_kernel(algo, chunks):
+    """The kernel nvcompBatched{LZ4,Snappy}DecompressAsync launches for a batch of this size (compile-time thresholds of
+    common/lz_launch.hip.h: a workgroup per chunk / two waves per chunk / persistent waves)."""
+    if algo == "lz4" and chunks <= 512:
+        return "lz4_decompress_team_kernel"
+    return f"{algo}_decompress_pair_kernel" if chunks <= 3072 else f"{algo}_decompress_window_kernel"
+
+
 def replayed_traffic(algo, kind, dataset, chunks):
     """HBM traffic per launch is a PMC measurement (separate rocprofv3 --pmc passes, scripts/gpu_traffic.sh): it cannot be
     taken inside this run, so the committed counters are REPLAYED -- only for the same kernel, the same workload AND the same
     kernel sources; otherwise null. Returns (bytes or None, what it is)."""
-    path = os.path.join(REPO, "profiles", "pmc_traffic_r03.json")
+    path = os.path.join(REPO, "profiles", "pmc_traffic_r04.json")
     if not os.path.exists(path):
         return None, "no PMC record (scripts/gpu_traffic.sh)"
     try:
@@ -582,10 +591,10 @@ def replayed_traffic(algo, kind, dataset, chunks):
     for rec in records:
         if rec.get("algo") == algo and rec.get("kind") == kind and rec.get("dataset") == dataset and rec.get("chunks_per_gpu") == chunks:
             if rec.get("lib_source_digest") == digest:
-                return rec.get("hbm_bytes_per_launch"), "profiles/pmc_traffic_r03.json (replayed PMC counters of this library build)"
+                return rec.get("hbm_bytes_per_launch"), "profiles/pmc_traffic_r04.json (replayed PMC counters of this library build; FETCH_SIZE x 2: every L2 miss is a 128-byte request tallied at 64, profiles/r04_feasibility.json)"
             stale = True
     if stale:
-        return None, "profiles/pmc_traffic_r03.json was recorded for another build of the kernels (lib_source_digest differs): not replayed"
+        return None, "profiles/pmc_traffic_r04.json was recorded for another build of the kernels (lib_source_digest differs): not replayed"
     return None, "no PMC record for this workload (scripts/gpu_traffic.sh)"
 
 
@@ -888,6 +897,17 @@ def main():
         # ratio 38.9, A100 decompress 320.7 GB/s): long matches and runs -- the data that CAN approach the roofline
         result["extras"]["lz4_mortgage_like"] = rider(args, ctx, "lz4", dataset="mortgage_col0_like",
                                                       mib_per_gpu=min(args.mib_per_gpu, 1024), unique_mib=min(args.unique_mib, 64))
+        # The headline batch is the size where the tail of the last round of persistent waves vanishes; the reference's own
+        # programs run 1 ... 8 192 chunks (benchmarks/benchmark_lz4_synth.cpp:64-72) and 5 021 (doc/Benchmarks.md:88-95):
+        # the same mix, producer and checks at 16 384, 4 096 and 256 chunks (persistent waves / persistent waves / a
+        # workgroup per chunk) ...
+        if args.mib_per_gpu > 1024:
+            result["extras"]["lz4_16384"] = rider(args, ctx, "lz4", mib_per_gpu=1024)
+            result["extras"]["lz4_4096"] = rider(args, ctx, "lz4", mib_per_gpu=256)
+            result["extras"]["lz4_256"] = rider(args, ctx, "lz4", mib_per_gpu=16, unique_mib=min(args.unique_mib, 16))
+            # ... and the headline batch once more with statuses = NULL: the unchecked fast path, reported separately
+            # (doc/lowlevel_c_quickstart.md:140)
+            result["extras"]["lz4_unchecked"] = rider(args, ctx, "lz4", unchecked=True)
     if args.dry_run_emu and args.allgather:
         result["value"] = None
         result["data"] = "DRY RUN on the CPU emulation of the kernels: not a measurement"

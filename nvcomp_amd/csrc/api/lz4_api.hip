@@ -146,6 +146,9 @@ __global__ void __launch_bounds__(lzt::kThreads, 4) lz4_decompress_team_kernel(c
 {
   __shared__ __attribute__((aligned(16))) uint8_t lds[lzt::kLds];
   size_t chunk = blockIdx.x;
+#ifdef NVCOMP_LZW_PROF
+  lzw::prof_begin();
+#endif
   for (;;) {
     const auto* a = wave::kernel_args(launch);
     if (chunk >= a->b.batch_size) {
@@ -191,6 +194,9 @@ __global__ void __launch_bounds__(lzt::kThreads, 4) lz4_decompress_team_kernel(c
     chunk = a->first_dynamic + wave::uniform(*slot);
     __syncthreads();
   }
+#ifdef NVCOMP_LZW_PROF
+  lzw::prof_end();
+#endif
 }
 
 __global__ void __launch_bounds__(64 * kWavesPerBlock) lz4_decompress_size_kernel(

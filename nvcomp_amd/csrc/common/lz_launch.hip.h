@@ -29,7 +29,7 @@
 #define NVCOMP_LZ_PAIR_MAX_BATCH 3072 /* profiles/r02_pair_decode.json: two waves per chunk win up to ~3 000 chunks */
 #endif
 #ifndef NVCOMP_LZ_TEAM_MAX_BATCH
-#define NVCOMP_LZ_TEAM_MAX_BATCH 4096 /* a WORKGROUP per chunk up to this many chunks (common/lz_team.hip.h) */
+#define NVCOMP_LZ_TEAM_MAX_BATCH 512 /* a WORKGROUP per chunk up to this many chunks (common/lz_team.hip.h): 263 us per chunk against 467 (two waves) and 677 (one); from 1 024 chunks on two waves per chunk keep more chunks in flight (profiles/r04_team.jsonl) */
 #endif
 #ifndef NVCOMP_LZ_MAX_WG_PER_CU
 #define NVCOMP_LZ_MAX_WG_PER_CU 7 /* cap on the persistent workgroups (of four waves) per CU; 0 = as many as stay resident.

@@ -208,19 +208,15 @@ __device__ __forceinline__ uint32_t enumerate(const lzw::Chase& c, uint32_t pos0
 /* granule counters: a byte each, four to a word */
 __device__ __forceinline__ void cnt_adjust(uint32_t* cnt, uint32_t ga, uint32_t n, bool add)
 {
-  /* n = 1..3 consecutive granules from ga on: one or two word updates */
+  /* n = 1..3 consecutive granules from ga on: two word updates, the second of them often by zero (no branch on it) */
   const uint64_t inc = (uint64_t)(0x010101u >> (8u * (3u - n))) << (8u * (ga & 3u));
   const uint32_t lo = (uint32_t)inc, hi = (uint32_t)(inc >> 32);
   if (add) {
     wave::lds_add(cnt + (ga >> 2), lo);
-    if (hi) {
-      wave::lds_add(cnt + (ga >> 2) + 1, hi);
-    }
+    wave::lds_add(cnt + (ga >> 2) + 1, hi);
   } else {
     wave::lds_sub(cnt + (ga >> 2), lo);
-    if (hi) {
-      wave::lds_sub(cnt + (ga >> 2) + 1, hi);
-    }
+    wave::lds_sub(cnt + (ga >> 2) + 1, hi);
   }
 }
 
@@ -302,6 +298,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
   }
   stage_stream(st, tid);
   __syncthreads();
+  LZW_T(0);
 
   lzw::Chase c;
   c.tab = t.tab;
@@ -337,7 +334,9 @@ __device__ __forceinline__ uint32_t decode_chunk(
       t.ctl[kCtlSpec + t.w] = kUnknownExit;
     }
     LZT_TR("w%u A\n", t.w);
+    LZW_T(1);
     __syncthreads();
+    LZW_T(2);
     /* ---- 2. entry = the exit speculated by the window in front; enumerate, parse, sizes ---- */
     const uint32_t entry = t.w == 0 ? q : ctl_read(t, kCtlSpec + t.w - 1);
     uint32_t n = 0;
@@ -356,6 +355,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
     const uint32_t incl = wave::scan_add_inclusive(len);
     const uint32_t total = wave::read_lane(incl, 63);
     const uint64_t bad_lanes = wave::ballot(bad);
+    LZW_T(3);
     LZT_TR("w%u B entry=%u n=%u exit=%u total=%u\n", t.w, entry, n, my_exit, total);
     if (lane == 0) {
       t.ctl[kCtlExit + t.w] = my_exit;
@@ -363,6 +363,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
       t.ctl[kCtlBad + t.w] = bad_lanes ? 1u : 0u;
     }
     __syncthreads();
+    LZW_T(4);
     /* ---- 3. which windows stand, where their output goes; literals; pending matches registered ---- */
     /* lane j < kWaves looks at window j: it stands when every window in front of it stands and left through the exit
      * that window j was entered by */
@@ -400,7 +401,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
     const uint32_t lit_dst = base + incl - len;
     const uint32_t match_dst = lit_dst + s.lit_len;
     const uint32_t my_lit = stands ? s.lit_len : 0u;
-    const uint32_t my_match = stands ? s.match_len : 0u;
+    uint32_t my_match = stands ? s.match_len : 0u;
     const uint32_t match_src = match_dst - s.match_off;
     const uint64_t bad_off = wave::ballot(my_match != 0 && s.match_off - 1 >= match_dst);
     if (bad_off && lane == 0) {
@@ -414,7 +415,8 @@ __device__ __forceinline__ uint32_t decode_chunk(
     const uint32_t ga = (match_dst - T0) / kGran;
     uint32_t gb = (match_dst + my_match - 1 - T0) / kGran;
     gb = gb < kGranules ? gb : kGranules - 1;
-    const bool tracked = my_match != 0 && ga < kGranules;
+    bool tracked = my_match != 0 && ga < kGranules;
+    LZW_T(5);
     if (!bad_off) {
       /* literals */
       uint8_t* dst = t.buf + t.oa + lit_dst;
@@ -467,7 +469,34 @@ __device__ __forceinline__ uint32_t decode_chunk(
         /* long runs come from the chunk in HBM: nothing another wave writes can be in their way */
         lzw::copy_to_lds(t.buf + t.oa + wave::read_lane(lit_dst, j), st.base + wave::read_lane(s.lit_src, j), wave::read_lane(my_lit, j));
       }
-      /* pending matches: their destination granules */
+      LZW_T(6);
+      /* matches whose source lies in front of this step read final bytes: they go now, in front of the barrier, and
+       * never enter the counters (three quarters of the matches of text) */
+      {
+        const bool early = my_match != 0 && need_end <= op;
+        const bool go = early && lane_class;
+        if (wave::ballot(go)) {
+          const uint32_t steps = lzw::steps_for(go, my_match);
+          if (go) {
+            const uint8_t* src = t.buf + t.oa + match_src;
+            uint8_t* d = t.buf + t.oa + match_dst;
+            if (steps == 2) {
+              lzw::copy_dwords_clamped<2>(d, src, my_match);
+            } else if (steps == 4) {
+              lzw::copy_dwords_clamped<4>(d, src, my_match);
+            } else {
+              lzw::copy_dwords_clamped<8>(d, src, my_match);
+            }
+          }
+        }
+        for (uint64_t m = wave::ballot(early && !lane_class); m; m &= m - 1) {
+          const uint32_t j = wave::ctz64(m);
+          lzw::lds_match_copy(t.buf + t.oa + wave::read_lane(match_dst, j), wave::read_lane(s.match_off, j), wave::read_lane(my_match, j));
+        }
+        my_match = early ? 0u : my_match;
+      }
+      /* the others are pending: their destination granules */
+      tracked = tracked && my_match != 0;
       if (tracked && short_match) {
         cnt_adjust(t.cnt, ga, gb - ga + 1, true);
       }
@@ -479,97 +508,111 @@ __device__ __forceinline__ uint32_t decode_chunk(
     uint64_t pending = bad_off ? 0ull : wave::ballot(my_match != 0);
     const uint32_t my_end = wave::read_lane(slot_end, t.w);
     const uint32_t first_pending = pending ? wave::read_lane(match_dst, wave::ctz64(pending)) : my_end;
+    wave::sync();
     if (lane == 0) {
-      wave::lds_store_release(t.ctl + kCtlProg + t.w, first_pending);
+      wave::lds_store_relaxed(t.ctl + kCtlProg + t.w, first_pending);
     }
     LZT_TR("w%u L pending=%llx\n", t.w, (unsigned long long)pending);
+    LZW_T(7);
     __syncthreads();
+    LZW_T(8);
     if (ctl_read(t, kCtlErr)) {
       err |= lz::kErrOffset;
       break;
     }
-    /* ---- 4. matches, as their sources become final ---- */
+    /* ---- 4. the pending matches, as their sources become final ----
+     * A lane-class match (4 .. 32 bytes, distance >= 4) whose source lies inside the counted range asks the counters of
+     * its (at most three) source granules: zero -- apart from its own count where its destination starts in the granule
+     * its source ends in -- means no pending match writes there any more. Everything else (long matches, periods below
+     * 4, sources behind the counted range, granules shared with an unrelated pending match) waits for the step's
+     * FRONTIER, the oldest pending match of the first slot that has one: every byte below it is final, and that match
+     * itself is always free to go. The frontier costs two LDS round trips and is only worked out when the counters
+     * let nothing through. */
+    const bool in_track = lane_class && need_end > T0 && need_end <= T0 + kTrack;
+    const uint32_t src0 = match_src > T0 ? match_src - T0 : 0u;
+    const uint32_t sa = in_track ? src0 / kGran : 0u;
+    const uint32_t sbg = in_track ? (need_end - 1 - T0) / kGran : 0u;
+    const uint32_t ngran = sbg - sa + 1; /* 1 .. 3 */
+    const uint32_t cmask = ngran >= 4 ? 0xffffffffu : (1u << (8u * ngran)) - 1u;
+    const uint32_t cself = (tracked && sbg == ga) ? 1u << (8u * (sbg - sa)) : 0u;
     while (pending) {
-      const uint32_t f = wave::ctz64(pending);
-      const uint32_t hw = wave::read_lane(match_dst, f);
-      if (lane == 0) {
-        wave::lds_store_release(t.ctl + kCtlProg + t.w, hw);
-      }
-      /* the step's frontier: the oldest pending match of the first slot that has one (every byte below it is final) */
-      uint32_t pg = 0xffffffffu;
-      if (lane < kWaves) {
-        pg = wave::lds_load_acquire(t.ctl + kCtlProg + lane);
-      }
-      const uint64_t open = wave::ballot(lane < kWaves && pg < slot_end);
-      const uint32_t frontier = open ? wave::read_lane(pg, wave::ctz64(open)) : step_end;
-      /* lane-class matches: granule counters of the source range (at most three granules), minus this match's own count
-       * where its destination starts in the granule its source ends in */
-      bool ready = false;
-      if (wave::lane_in(pending)) {
-        const bool below = need_end <= op;
-        bool counted = false;
-        if (!below && need_end <= T0 + kTrack) {
-          const uint32_t s0 = match_src > T0 ? match_src - T0 : 0u;
-          const uint32_t sa = s0 / kGran, sbg = (need_end - 1 - T0) / kGran;
-          const uint32_t c4 = cnt_read4(t.cnt, sa);
-          const uint32_t ng = sbg - sa + 1; /* 1 .. 3 for a lane-class match */
-          const uint32_t mask = ng >= 4 ? 0xffffffffu : (1u << (8u * ng)) - 1u;
-          const uint32_t self = (tracked && sbg == ga) ? 1u << (8u * (sbg - sa)) : 0u;
-          counted = ng <= 4 && (c4 & mask) == self;
+      pending = wave::uniform64(pending); /* (it is: spelled out for the compiler) */
+      const bool mine = wave::lane_in(pending);
+      bool go = mine && in_track && (cnt_read4(t.cnt, sa) & cmask) == cself;
+      uint64_t gone = wave::ballot(go);
+      LZW_T(9);
+      if (!gone) {
+        const uint32_t f = wave::ctz64(pending);
+        const uint32_t hw = wave::read_lane(match_dst, f);
+        wave::sync();
+        if (lane == 0) {
+          wave::lds_store_relaxed(t.ctl + kCtlProg + t.w, hw);
         }
-        ready = below || counted || need_end <= frontier || match_dst == frontier;
-      }
-      if (!((lane_class_mask >> f) & 1)) {
-        /* the wave's oldest pending match is long or has a period below 4: the whole wave copies it once everything
-         * in front of it is final */
-        const uint32_t f_need = wave::read_lane(need_end, f);
-        if (f_need <= frontier || f_need <= op || hw == frontier) {
-          lzw::lds_match_copy(t.buf + t.oa + hw, wave::read_lane(s.match_off, f), wave::read_lane(my_match, f));
-          if (wave::read_lane(tracked ? 1u : 0u, f)) {
-            if (wave::read_lane(short_match ? 1u : 0u, f)) {
-              if (lane == f) {
-                cnt_adjust(t.cnt, ga, gb - ga + 1, false);
+        uint32_t pg = 0xffffffffu;
+        if (lane < kWaves) {
+          pg = wave::lds_load_relaxed(t.ctl + kCtlProg + lane);
+        }
+        wave::sync();
+        const uint64_t open = wave::ballot(lane < kWaves && pg < slot_end);
+        const uint32_t frontier = open ? wave::read_lane(pg, wave::ctz64(open)) : step_end;
+        if (!((lane_class_mask >> f) & 1)) {
+          /* the wave's oldest pending match is long or has a period below 4: the whole wave copies it once everything
+           * in front of it is final */
+          const uint32_t f_need = wave::read_lane(need_end, f);
+          if (f_need <= frontier || hw == frontier) {
+            lzw::lds_match_copy(t.buf + t.oa + hw, wave::read_lane(s.match_off, f), wave::read_lane(my_match, f));
+            if (wave::read_lane(tracked ? 1u : 0u, f)) {
+              if (wave::read_lane(short_match ? 1u : 0u, f)) {
+                if (lane == f) {
+                  cnt_adjust(t.cnt, ga, gb - ga + 1, false);
+                }
+              } else {
+                cnt_adjust_range(t.cnt, wave::read_lane(ga, f), wave::read_lane(gb, f), false);
               }
-            } else {
-              cnt_adjust_range(t.cnt, wave::read_lane(ga, f), wave::read_lane(gb, f), false);
             }
+            pending &= ~(1ull << f);
+            LZW_T(11);
+            continue;
           }
-          pending &= ~(1ull << f);
+        }
+        go = mine && lane_class && (need_end <= frontier || match_dst == frontier);
+        gone = wave::ballot(go);
+        if (!gone) {
+          if (ctl_read(t, kCtlErr)) {
+            break;
+          }
+          wave::nap();
+          LZW_T(12);
           continue;
         }
       }
-      const bool go = ready && lane_class;
-      const uint64_t gone = wave::ballot(go);
-      if (gone) {
-        const uint32_t steps = lzw::steps_for(go, my_match);
-        if (go) {
-          const uint8_t* src = t.buf + t.oa + match_src;
-          uint8_t* dst = t.buf + t.oa + match_dst;
-          if (steps == 2) {
-            lzw::copy_dwords_clamped<2>(dst, src, my_match);
-          } else if (steps == 4) {
-            lzw::copy_dwords_clamped<4>(dst, src, my_match);
-          } else {
-            lzw::copy_dwords_clamped<8>(dst, src, my_match);
-          }
+      const uint32_t steps = lzw::steps_for(go, my_match);
+      if (go) {
+        const uint8_t* src = t.buf + t.oa + match_src;
+        uint8_t* d = t.buf + t.oa + match_dst;
+        if (steps == 2) {
+          lzw::copy_dwords_clamped<2>(d, src, my_match);
+        } else if (steps == 4) {
+          lzw::copy_dwords_clamped<4>(d, src, my_match);
+        } else {
+          lzw::copy_dwords_clamped<8>(d, src, my_match);
         }
-        wave::sync();
-        if (go && tracked) {
-          cnt_adjust(t.cnt, ga, gb - ga + 1, false);
-        }
-        pending &= ~gone;
-      } else {
-        if (ctl_read(t, kCtlErr)) {
-          break;
-        }
-        wave::nap();
       }
+      wave::sync();
+      if (go && tracked) {
+        cnt_adjust(t.cnt, ga, gb - ga + 1, false);
+      }
+      pending &= ~gone;
+      LZW_T(10);
     }
+    wave::sync();
     if (lane == 0) {
-      wave::lds_store_release(t.ctl + kCtlProg + t.w, my_end);
+      wave::lds_store_relaxed(t.ctl + kCtlProg + t.w, my_end);
     }
     LZT_TR("w%u C\n", t.w);
+    LZW_T(9);
     __syncthreads();
+    LZW_T(13);
     op = step_end;
     q = next_q;
   }
@@ -597,6 +640,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
    * "behind the end" for a chunk's regular last sequence) */
   flush(t, flushed, op, tid);
   __syncthreads(); /* the buffer is free again */
+  LZW_T(14);
   return op;
 }
 

@@ -306,6 +306,17 @@ __device__ __forceinline__ uint32_t lds_load_acquire(const uint32_t* p)
 {
   return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+/* A flag word other waves of the workgroup poll, written / read without the memory-model ceremony: one wave's LDS
+ * operations are served in issue order, so data written in front of the flag is in LDS before it, and a reader that saw the
+ * flag reads the data behind it; wave::sync() around these keeps the compiler from reordering. */
+__device__ __forceinline__ void lds_store_relaxed(uint32_t* p, uint32_t v)
+{
+  *(volatile uint32_t*)p = v;
+}
+__device__ __forceinline__ uint32_t lds_load_relaxed(const uint32_t* p)
+{
+  return *(const volatile uint32_t*)p;
+}
 /* Give the SIMD to the other waves for a few hundred cycles while polling. */
 __device__ __forceinline__ void nap()
 {

@@ -19,6 +19,11 @@ KERNELS = {
     "deflate": [("deflate_decompress_kernel", "deflate", "decompress")],
     "cascaded": [("cascaded_decompress_kernel", "cascaded", "decompress")],
     "lz4_mortgage": [("lz4_decompress_window_kernel", "lz4", "decompress")],
+    # the batch-size riders of the driver's line and the unchecked fast path
+    "lz4_16384": [("lz4_decompress_window_kernel", "lz4", "decompress")],
+    "lz4_4096": [("lz4_decompress_window_kernel", "lz4", "decompress")],
+    "lz4_256": [("lz4_decompress_team_kernel", "lz4", "decompress")],
+    "lz4_unchecked": [("lz4_decompress_window_kernel", "lz4", "decompress_unchecked")],
     # the other codecs' own bench lines (python bench.py --algo X at its default size)
     "cascaded_line": [("cascaded_decompress_kernel", "cascaded", "decompress")],
     "bitcomp_line": [("bitcomp_decompress_kernel", "bitcomp", "decompress")],
@@ -63,21 +68,25 @@ def main():
                 continue
             fetch, write = vals["FETCH_SIZE"] * 1024, vals["WRITE_SIZE"] * 1024  # the counters are in KB
             comp, raw = cfg["compressed_bytes_per_gpu"], cfg["uncompressed_bytes_per_gpu"]
-            # gfx950: FETCH_SIZE reports half the bytes of a wide coalesced streaming read (the guide's correction). The
-            # streamed input of a decoder is the compressed data (16 B / lane), of a compressor the raw data (8 B / lane
-            # into the LDS image): that part is doubled; what exceeds it (far-match gathers, candidate probes: narrow,
-            # scattered) stays as counted.
-            streamed = comp if kind == "decompress" else raw
-            uncounted = min(fetch, streamed / 2)
+            # gfx950: FETCH_SIZE = TCC_EA0_RDREQ x 64, and every L2 miss is ONE 128-byte request whatever the access shape --
+            # calibrated in round 4 on known load counts (scripts/probes/gather_calib.hip, profiles/r04_feasibility.json:
+            # coalesced 16-byte lane loads 0.125 requests per load, lanes 64 bytes apart 0.5, lanes 128 bytes apart and random
+            # 16-byte loads 1.0, random byte-aligned 16-byte loads 1.115; TCC_EA0_RDREQ_32B = 0). The factor 2 the guide gives
+            # for wide coalesced reads therefore holds for ALL of FETCH_SIZE: the streamed input AND the far-match gathers /
+            # candidate probes (a 128-byte line for 4-32 useful bytes). WRITE_SIZE is as counted (it equals the output bytes
+            # of every bandwidth-shaped codec).
+            uncounted = fetch
             records.append({
                 "algo": algo, "kind": kind, "kernel": substr, "dataset": cfg["dataset"], "chunks_per_gpu": cfg["chunks_per_gpu"],
                 "lib_source_digest": bench.library_source_digest(algo),
                 "fetch_bytes_counted": int(fetch), "write_bytes_counted": int(write),
                 "hbm_bytes_per_launch": int(fetch + uncounted + write),
                 "algorithmic_bytes": int(comp + raw + (44 if kind == "decompress" else 40) * cfg["chunks_per_gpu"]),
-                "note": "FETCH_SIZE as counted + the uncounted half of the coalesced input stream (gfx950 tallies wide "
-                        "coalesced reads at 1/2: MI355X_MICROARCH.md, calibrated in round 1 by scripts/gpu_calib.sh) + "
-                        "WRITE_SIZE; separate rocprofv3 --pmc passes, KB units; Infinity-Cache hits are counted too",
+                "calibration": {"fetch_factor": 2.0, "basis": "profiles/r04_feasibility.json fetch_size_calibration: 128-byte "
+                                "requests tallied at 64 bytes for every access shape measured", "write_factor": 1.0},
+                "note": "2 x FETCH_SIZE + WRITE_SIZE (an ABSOLUTE byte count at the L2's fabric side since the round-4 "
+                        "calibration, no longer a lower bound); separate rocprofv3 --pmc passes, KB units; Infinity-Cache "
+                        "hits are fabric requests too and are counted",
             })
     print(json.dumps(records, indent=1))
 

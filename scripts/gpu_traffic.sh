@@ -2,7 +2,7 @@
 # HBM traffic of the kernels behind the driver's bench line (the headline, its riders, the compress leg): FETCH_SIZE and
 # WRITE_SIZE per launch, SEPARATE rocprofv3 --pmc passes of the same commands (MI355X_MICROARCH.md: FETCH_SIZE costs 3 TCC
 # slots, WRITE_SIZE 2; never together with trace domains). scripts/collect_traffic.py turns the CSVs into
-# profiles/pmc_traffic_r03.json, which bench.py replays for the same workload AND the same kernel sources only.
+# profiles/pmc_traffic_r04.json, which bench.py replays for the same workload AND the same kernel sources only.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
@@ -21,6 +21,10 @@ run snappy --algo snappy --no-extras
 run deflate --algo deflate --no-extras --mib-per-gpu 1024 --unique-mib 32
 run cascaded --algo cascaded --no-extras --dataset example_float_columns --mib-per-gpu 1024 --unique-mib 32
 run lz4_mortgage --no-extras --dataset mortgage_col0_like --mib-per-gpu 1024 --unique-mib 64
+run lz4_16384 --no-extras --mib-per-gpu 1024
+run lz4_4096 --no-extras --mib-per-gpu 256
+run lz4_256 --no-extras --mib-per-gpu 16 --unique-mib 16
+run lz4_unchecked --no-extras --unchecked
 if [ "${LINES:-1}" = 1 ]; then # the other codecs' own lines at their default sizes
   run cascaded_line --algo cascaded --no-extras
   run bitcomp_line --algo bitcomp --no-extras
@@ -28,4 +32,4 @@ if [ "${LINES:-1}" = 1 ]; then # the other codecs' own lines at their default si
   run deflate_line --algo deflate --no-extras
 fi
 find "$OUT" -name "*.csv" -size +16M -delete
-python scripts/collect_traffic.py "$OUT" > "$OUT/pmc_traffic_r03.json" && cat "$OUT/pmc_traffic_r03.json" | head -60
+python scripts/collect_traffic.py "$OUT" > "$OUT/pmc_traffic_r04.json" && cat "$OUT/pmc_traffic_r04.json" | head -60

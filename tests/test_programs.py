@@ -155,7 +155,8 @@ def test_bench_contract_on_gpu(algo):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--allgather"]], ids=["sharded", "allgather"])
+@pytest.mark.parametrize("extra", [[], ["--allgather"], ["--allgather", "--mib-per-gpu", "4096", "--unique-mib", "64"]],
+                         ids=["sharded", "allgather", "allgather_4gib"])
 def test_bench_under_launcher_with_rccl(extra):
     """The driver's N>1 launch line, with one rank (the box has one GPU) and RCCL forced up: process-group init on
     the device, barrier, max-over-ranks all-reduce, digest gather and (--allgather) the RCCL all-gathers all run
@@ -167,7 +168,8 @@ def test_bench_under_launcher_with_rccl(extra):
     env = dict(os.environ, NVCOMP_AMD_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29641", "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--mib-per-gpu", "64", "--unique-mib", "8", "--no-cpu-baseline", "--no-extras"] + extra
+           "--mib-per-gpu", "64", "--unique-mib", "8", "--no-cpu-baseline", "--no-extras"] + extra  # (later flags win:
+    # "allgather_4gib" runs the default 4 GiB-per-GPU buffer plan of the all-gather step once on hardware)
     r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-8000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
