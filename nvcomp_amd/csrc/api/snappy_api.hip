@@ -14,6 +14,7 @@
 #include "common/lz_launch.hip.h"
 #include "snappy/snappy_decode.hip.h"
 #include "snappy/snappy_decode_window.hip.h"
+#include "common/lz_team.hip.h"
 #include "snappy/snappy_encode.hip.h"
 
 namespace {
@@ -78,6 +79,60 @@ __global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_WAVES_PER_SIMD) sna
       break;
     }
     chunk = lzl::next_chunk(ticket, a->first_dynamic);
+  }
+}
+
+/* A workgroup per chunk (common/lz_team.hip.h): batches that cannot fill the card with one wave per chunk. Persistent
+ * workgroups when the caller's temp buffer holds a ticket counter, one workgroup per chunk otherwise. */
+template <bool CHECKED>
+__global__ void __launch_bounds__(lzt::kThreads, 4) snappy_decompress_team_kernel(const lzl::Launch launch)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t lds[lzt::kLds];
+  size_t chunk = blockIdx.x;
+  for (;;) {
+    const auto* a = wave::kernel_args(launch);
+    if (chunk >= a->b.batch_size) {
+      break;
+    }
+    const uint8_t* in = wave::uniform_ptr((const uint8_t*)a->b.comp_ptrs[chunk]);
+    uint8_t* out = wave::uniform_ptr((uint8_t*)a->b.out_ptrs[chunk]);
+    const size_t in_len64 = wave::uniform64(a->b.comp_bytes[chunk]);
+    size_t cap64 = wave::uniform64(a->b.out_caps[chunk]);
+    if (cap64 > kMaxOutCap) {
+      cap64 = kMaxOutCap;
+    }
+    uint32_t err = lz::kErrNone;
+    uint32_t produced = 0;
+    if (in_len64 > 0xffffffffull - 64) {
+      err = lz::kErrInput;
+    } else {
+      produced = lzt::decode_chunk<snappyw::TeamFrontEnd>(
+          in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err,
+          [](const uint8_t* i, uint32_t n, uint8_t* o, uint32_t cap, uint8_t* scratch, uint32_t& e) {
+            return snappyw::decode_chunk<true>(i, n, o, cap, scratch, e);
+          });
+    }
+    a = wave::kernel_args(launch);
+    if (threadIdx.x == 0) {
+      size_t* actual_bytes = a->b.actual_bytes;
+      if (actual_bytes != nullptr) {
+        actual_bytes[chunk] = err ? 0 : produced;
+      }
+      if (CHECKED) {
+        a->b.statuses[chunk] = err ? nvcompErrorCannotDecompress : nvcompSuccess;
+      }
+    }
+    uint32_t* ticket = a->ticket;
+    if (ticket == nullptr) {
+      break;
+    }
+    uint32_t* slot = (uint32_t*)(lds + lzt::kLds - 4 * lzt::kCtlWords) + lzt::kCtlTicket;
+    if (threadIdx.x == 0) {
+      *slot = atomicAdd(ticket, 1u);
+    }
+    __syncthreads();
+    chunk = a->first_dynamic + wave::uniform(*slot);
+    __syncthreads();
   }
 }
 
@@ -209,8 +264,9 @@ nvcompStatus_t nvcompBatchedSnappyDecompressGetTempSize(
   if (temp_bytes == nullptr) {
     return nvcompErrorInvalidValue;
   }
-  /* the persistent waves' ticket counter (common/lz_launch.hip.h); the decoder itself keeps all state in registers and LDS */
-  *temp_bytes = num_chunks > lzl::kPairMaxBatch ? lzl::kTicketBytes : 0;
+  /* the ticket counter of the persistent waves / workgroups (common/lz_launch.hip.h); the decoder itself keeps all state in
+   * registers and LDS */
+  *temp_bytes = num_chunks != 0 ? lzl::kTicketBytes : 0;
   return nvcompSuccess;
 }
 
@@ -246,7 +302,29 @@ nvcompStatus_t nvcompBatchedSnappyDecompressAsync(
   const bool checked = device_statuses != nullptr;
   const lzl::Batch b = {device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
                         device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, (int*)device_statuses};
-  /* Small batches cannot fill the card with one wave per chunk: two waves per chunk (producer / consumer). */
+  /* Small batches cannot fill the card with one wave per chunk: a workgroup per chunk (common/lz_team.hip.h), persistent
+   * when there are more chunks than workgroups stay resident and the caller's temp buffer holds the ticket counter. */
+  if (batch_size <= lzl::kTeamMaxBatch) {
+    unsigned groups = (unsigned)batch_size;
+    uint32_t* ticket = nullptr;
+    if (device_temp_ptr != nullptr && temp_bytes >= sizeof(uint32_t) && ((uintptr_t)device_temp_ptr & 3u) == 0) {
+      static lzl::ResidentCache resident[2]; /* per device ordinal */
+      const unsigned fit = checked ? resident[1].get(snappy_decompress_team_kernel<true>, lzt::kThreads, 0)
+                                   : resident[0].get(snappy_decompress_team_kernel<false>, lzt::kThreads, 0);
+      if (fit != 0 && fit < groups && hipMemsetAsync(device_temp_ptr, 0, sizeof(uint32_t), stream) == hipSuccess) {
+        ticket = (uint32_t*)device_temp_ptr;
+        groups = fit;
+      }
+    }
+    const lzl::Launch launch = {b, ticket, (size_t)groups};
+    if (checked) {
+      hipLaunchKernelGGL((snappy_decompress_team_kernel<true>), dim3(groups), dim3(lzt::kThreads), 0, stream, launch);
+    } else {
+      hipLaunchKernelGGL((snappy_decompress_team_kernel<false>), dim3(groups), dim3(lzt::kThreads), 0, stream, launch);
+    }
+    return launch_status();
+  }
+  /* (round 2's path for small batches: two waves per chunk, producer / consumer) */
   if (batch_size <= lzl::kPairMaxBatch) {
     const dim3 pgrid((unsigned)batch_size), pblock(128);
     if (checked) {

@@ -77,7 +77,7 @@ __device__ __forceinline__ uint64_t shuffle64(uint64_t v, uint32_t src)
 
 __device__ __forceinline__ uint64_t reduce_min64(uint64_t v)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   for (uint32_t m = 32; m >= 1; m >>= 1) {
     const uint64_t o = shuffle64(v, lane ^ m);
     v = o < v ? o : v;
@@ -87,7 +87,7 @@ __device__ __forceinline__ uint64_t reduce_min64(uint64_t v)
 
 __device__ __forceinline__ uint64_t reduce_max64(uint64_t v)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   for (uint32_t m = 32; m >= 1; m >>= 1) {
     const uint64_t o = shuffle64(v, lane ^ m);
     v = o > v ? o : v;
@@ -98,7 +98,7 @@ __device__ __forceinline__ uint64_t reduce_max64(uint64_t v)
 /* inclusive prefix sum of 64-bit values across the wave */
 __device__ __forceinline__ uint64_t scan_add64(uint64_t v)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   for (uint32_t d = 1; d < 64; d <<= 1) {
     const uint64_t o = shuffle64(v, (lane - d) & 63u);
     if (lane >= d) {
@@ -125,7 +125,7 @@ template <typename S>
 __device__ __forceinline__ void stream_range(const S& s, uint32_t count, uint32_t w, bool as_signed, uint64_t& mn_out,
                                              uint32_t& bits_out)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   if (count == 0) {
     mn_out = 0;
     bits_out = 0;
@@ -174,7 +174,7 @@ template <typename S>
 __device__ __forceinline__ uint32_t pack_stream(uint8_t* dst, const S& s, uint32_t count, uint32_t w, uint64_t mn,
                                                 uint32_t bits)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   uint32_t* out = (uint32_t*)dst;
   if (lane == 0) {
     out[0] = bits;
@@ -223,7 +223,7 @@ template <typename T>
 __device__ __forceinline__ bool unpack_stream(const uint8_t* src, uint32_t avail, T* dst, uint32_t count, uint32_t w,
                                               uint32_t& used)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   used = 0;
   if (avail < 12) {
     return false;
@@ -292,7 +292,7 @@ __device__ __forceinline__ bool unpack_stream(const uint8_t* src, uint32_t avail
 /* dst <- src, whole wave, non-overlapping: dwords when both sides are 4-byte aligned */
 __device__ __forceinline__ void copy_bytes(uint8_t* dst, const uint8_t* src, uint32_t bytes)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   uint32_t done = 0;
   if ((((uintptr_t)dst | (uintptr_t)src) & 3u) == 0) {
     const uint32_t words = bytes / 4;
@@ -314,7 +314,7 @@ constexpr uint32_t kRleOverflow = 0xffffffffu;
 template <typename T>
 __device__ __forceinline__ uint32_t count_heads(const T* A, uint32_t c)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   uint32_t m = 0;
   for (uint32_t base = 0; base < c; base += 64) {
     const uint32_t i = base + lane;
@@ -332,7 +332,7 @@ __device__ __forceinline__ uint32_t count_heads(const T* A, uint32_t c)
 template <typename T>
 __device__ __forceinline__ uint32_t rle_encode(const T* A, uint32_t c, T* B, uint16_t* runs, uint32_t cap, bool lengths_if_runs = false)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   uint32_t m = 0;
   /* pass 1: compact run starts; runs[] temporarily holds the start index of each run. 4 tiles per step: their
    * loads (the input may be HBM) are issued together, the compaction itself stays tile by tile. */
@@ -389,7 +389,7 @@ __device__ __forceinline__ uint32_t rle_encode(const T* A, uint32_t c, T* B, uin
 template <typename T>
 __device__ __forceinline__ void delta_encode(T* A, uint32_t c)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   const uint32_t tiles = (c + 63) / 64;
   for (uint32_t t = tiles; t-- > 0;) {
     const uint32_t i = t * 64 + lane;
@@ -427,7 +427,7 @@ __device__ __forceinline__ uint64_t last_lane_t(uint64_t v)
 template <typename T>
 __device__ __forceinline__ void delta_decode(T* A, uint32_t c)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   if (c <= 64) { /* a well-compressed layer: one element per lane, one scan */
     const uint64_t v = lane < c ? (uint64_t)A[lane] : 0;
     const uint64_t incl = scan_add_t<T>(sizeof(T) <= 4 ? (uint64_t)(uint32_t)v : v);
@@ -470,7 +470,7 @@ template <typename T>
 __device__ __forceinline__ bool rle_decode(const T* A, const uint16_t* runs, uint32_t c, T* B, uint32_t target,
                                            uint16_t* marks)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   for (uint32_t i = lane; i < (target + 1) / 2; i += 64) {
     ((uint32_t*)marks)[i] = 0;
   }
@@ -601,7 +601,7 @@ template <typename T>
 __device__ __forceinline__ bool rle_expand_direct(const T* A, const uint32_t* packed, uint32_t bits, uint32_t mn, uint32_t c,
                                                   T* out, uint32_t target)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   uint32_t carry = 0;
   bool bad = false;
   for (uint32_t base = 0; base < c; base += 256) {
@@ -628,7 +628,7 @@ template <typename T>
 __device__ __forceinline__ bool rle_expand_inplace(T* A, const uint32_t* packed, uint32_t bits, uint32_t mn, uint32_t c,
                                                    uint32_t target)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   uint32_t above = 0; /* elements produced by the tiles above */
   for (uint32_t t = (c + 255) / 256; t-- > 0;) {
     uint32_t r[4];
@@ -676,7 +676,7 @@ template <typename T>
 __device__ __forceinline__ uint32_t compress_sub(
     const uint8_t* src, uint32_t bytes, uint8_t* dst, const Params& p, uint8_t* lds, uint32_t budget)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   const uint32_t w = sizeof(T);
   const uint32_t n = bytes / w;
   const T* in = (const T*)src;
@@ -806,7 +806,7 @@ __device__ __forceinline__ uint32_t decompress_sub(
     const uint8_t* src, uint32_t avail, uint32_t head, uint8_t* dst, uint32_t bytes, uint32_t num_rles, uint32_t num_deltas,
     uint8_t* lds, uint32_t budget)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   const uint32_t w = sizeof(T);
   const uint32_t n = bytes / w;
   if (avail < 4) {

@@ -262,6 +262,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
   t.oa = (uint32_t)((uintptr_t)out & 15u);
   err = lz::kErrNone;
   if (in_len == 0) {
+    err = FrontEnd::kEmptyIsError ? lz::kErrInput : lz::kErrNone;
     return 0;
   }
   uint8_t* fb_scratch = lds + kBufLds;
@@ -304,6 +305,10 @@ __device__ __forceinline__ uint32_t decode_chunk(
   c.tab = t.tab;
   c.nx01 = 0, c.nx23 = 0, c.wb = 0, c.q = 0;
   uint32_t q = st.vbeg; /* the next token */
+  uint32_t limit = out_cap; /* the most the chunk may produce (Snappy: exactly what its preamble says) */
+  if (!FrontEnd::begin(st, out_cap, q, limit, err)) {
+    return 0; /* (uniform: every wave read the same preamble) */
+  }
   uint32_t op = 0;      /* output produced (all of it final) */
   uint32_t flushed = 0; /* output written to HBM */
   bool give_up = false; /* in-place invariant broken: the one-wave decoder redoes the chunk */
@@ -387,7 +392,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
     const uint32_t next_q = wave::read_lane(ex, standing - 1);
     const uint32_t any_bad = wave::ballot(lane < standing && bd != 0) ? 1u : 0u;
     const uint32_t step_end = op + step_bytes;
-    if (any_bad || step_end > out_cap || next_q <= q) { /* (a step always consumes its first token) */
+    if (any_bad || step_end > limit || next_q <= q) { /* (a step always consumes its first token) */
       err |= any_bad || next_q <= q ? lz::kErrInput : lz::kErrOutput;
       break;
     }
@@ -634,6 +639,10 @@ __device__ __forceinline__ uint32_t decode_chunk(
     return produced;
   }
   if (err) {
+    return 0;
+  }
+  if (!FrontEnd::finish_ok(op, q, st.vend, limit)) {
+    err |= lz::kErrInput;
     return 0;
   }
   /* (a last token that claims more than the chunk holds was refused by the parser; the chase itself may report

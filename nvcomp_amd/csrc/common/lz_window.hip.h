@@ -539,17 +539,18 @@ constexpr uint32_t kLdsPerChunk = lzw::kOutLds + 2 * lzw::kInLds + lzw::kChaseLd
 
 struct Shared
 {
-  uint8_t* slot[2];
+  uint8_t* slots;  /* two of kSlotBytes each: slot(k) -- not an array of two pointers: indexed by a run-time k, that array
+                    * lived in scratch memory (40 bytes per lane, a scratch load per hand-over) */
   uint32_t* state; /* [2]: 0 = empty, 1 = full */
   uint32_t* abort; /* the consumer gave up: the producer stops waiting */
+  __device__ __forceinline__ uint8_t* slot(uint32_t k) const { return slots + k * kSlotBytes; }
 };
 
 __device__ __forceinline__ Shared shared_at(uint8_t* lds)
 {
   uint8_t* q = lds + lzw::kOutLds + 2 * lzw::kInLds + lzw::kChaseLds;
   Shared sh;
-  sh.slot[0] = q;
-  sh.slot[1] = q + kSlotBytes;
+  sh.slots = q;
   sh.state = (uint32_t*)(q + 2 * kSlotBytes);
   sh.abort = sh.state + 2;
   return sh;

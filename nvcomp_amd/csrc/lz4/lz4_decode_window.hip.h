@@ -336,8 +336,17 @@ __device__ __forceinline__ void parse_batch(const R& r, uint32_t p, uint32_t fro
 struct TeamFrontEnd
 {
   static constexpr uint32_t kPositions = 192; /* a sequence is at least 3 bytes (token + offset): 64 tokens at most */
+  static constexpr bool kEmptyIsError = false; /* an empty block decodes to nothing */
   using Delta = DeltaFn;
   using Slow = SlowFn;
+  template <class R>
+  static __device__ __forceinline__ bool begin(const R& r, uint32_t out_cap, uint32_t& q, uint32_t& limit, uint32_t&)
+  {
+    q = r.vbeg;
+    limit = out_cap;
+    return true;
+  }
+  static __device__ __forceinline__ bool finish_ok(uint32_t, uint32_t, uint32_t, uint32_t) { return true; }
   template <class R>
   static __device__ __forceinline__ void parse_batch(const R& r, uint32_t p, uint32_t from, uint32_t to, lz::Seq& s, bool& bad)
   {
@@ -488,14 +497,14 @@ __device__ __forceinline__ void produce(const uint8_t* __restrict__ in, uint32_t
       }
       wave::nap();
     }
-    uint32_t* f = (uint32_t*)(sh.slot[k] + 16);
+    uint32_t* f = (uint32_t*)(sh.slot(k) + 16);
     f[lane] = s.lit_src;
     f[64 + lane] = s.lit_len;
     f[128 + lane] = s.match_off;
     f[192 + lane] = s.match_len;
     if (lane == 0) {
-      ((uint32_t*)sh.slot[k])[0] = count;
-      ((uint32_t*)sh.slot[k])[1] = flags;
+      ((uint32_t*)sh.slot(k))[0] = count;
+      ((uint32_t*)sh.slot(k))[1] = flags;
     }
     wave::sync();
     if (lane == 0) {
@@ -528,13 +537,13 @@ __device__ __forceinline__ uint32_t consume(
       while (poll(sh.state + k) != 1) {
         wave::nap();
       }
-      const uint32_t* f = (const uint32_t*)(sh.slot[k] + 16);
+      const uint32_t* f = (const uint32_t*)(sh.slot(k) + 16);
       s.lit_src = f[lane];
       s.lit_len = f[64 + lane];
       s.match_off = f[128 + lane];
       s.match_len = f[192 + lane];
-      const uint32_t n = wave::read_lane(((const uint32_t*)sh.slot[k])[0], 0);
-      const uint32_t flags = wave::read_lane(((const uint32_t*)sh.slot[k])[1], 0);
+      const uint32_t n = wave::read_lane(((const uint32_t*)sh.slot(k))[0], 0);
+      const uint32_t flags = wave::read_lane(((const uint32_t*)sh.slot(k))[1], 0);
       wave::sync();
       if (lane == 0) {
         wave::lds_store_release(sh.state + k, 0u);

@@ -31,10 +31,11 @@ __device__ __forceinline__ uint32_t copy_size(uint32_t kind) /* kind 1..3 */
 /* Distance from a (speculative) tag at virtual position p to the next tag; kUnknown = unknown.
  * Branch-free: the tag and the four bytes behind it (a literal's length field) are fetched
  * together; the ring's 16-byte mirror covers a dword that starts before the ring's end. */
-__device__ __forceinline__ uint32_t tag_delta(const lzw::InRing& r, uint32_t p)
+template <class R>
+__device__ __forceinline__ uint32_t tag_delta(const R& r, uint32_t p)
 {
   const uint8_t* ring = r.ring;
-  const uint32_t m = lzw::kInRing - 1;
+  const uint32_t m = R::kMask;
   const uint32_t t = ring[p & m];
   /* the 4 bytes behind the tag from two aligned dwords (a misaligned ds_read_b32 costs 16x) */
   const uint32_t fa = (p + 1) & ~3u;
@@ -64,7 +65,8 @@ __device__ __forceinline__ uint32_t tag_delta(const lzw::InRing& r, uint32_t p)
 
 
 /* Scalar fallback (tag not resolvable from the ring). */
-__device__ __forceinline__ uint32_t chase_slow_next(const lzw::InRing& r, uint32_t q)
+template <class R>
+__device__ __forceinline__ uint32_t chase_slow_next(const R& r, uint32_t q)
 {
   const uint32_t vend = r.vend;
   const uint32_t t = lzw::in_byte_uniform(r, q);
@@ -100,33 +102,38 @@ __device__ __forceinline__ uint32_t chase_slow_next(const lzw::InRing& r, uint32
 struct DeltaFn
 {
   static constexpr uint32_t kReach = 8 + kFuseMax + 8; /* tag + length field, and the tag behind a fusable literal */
-  __device__ __forceinline__ uint32_t operator()(const lzw::InRing& r, uint32_t p) const { return tag_delta(r, p); }
+  template <class R>
+  __device__ __forceinline__ uint32_t operator()(const R& r, uint32_t p) const { return tag_delta(r, p); }
   /* interior window: `w` = the stream bytes from p on (tag in bits 0-7). A literal element with explicit length bytes
    * (more than 60 bytes: one literal element in a thousand on the mix) is left to the scalar walk: the speculative pass
    * runs for four positions per lane per window, and resolving the 1-4 length bytes there cost more than twice as many
    * instructions per position as the rest of the rule (35 vs 15). The size of a copy element by kind -- 0, 2, 3, 5 --
    * is a nibble table in a constant. */
-  __device__ __forceinline__ uint32_t fast(const lzw::InRing& r, uint32_t p, uint64_t w) const
+  template <class R>
+  __device__ __forceinline__ uint32_t fast(const R& r, uint32_t p, uint64_t w) const
   {
     const uint32_t t = (uint32_t)w & 0xffu;
     const uint32_t kind = t & 3u;
     const uint32_t code = t >> 2;
     const uint32_t lit_delta = code + 2; /* tag + (code + 1) bytes */
-    const uint32_t k2 = r.ring[(p + lit_delta) & (lzw::kInRing - 1)] & 3u; /* harmless when not a literal */
+    const uint32_t k2 = r.ring[(p + lit_delta) & R::kMask] & 3u; /* harmless when not a literal */
     const uint32_t lit_total = code >= 60 ? kUnknown : lit_delta + ((0x5320u >> (4 * k2)) & 15u); /* kFuseMax >= 62: always fused */
     return kind == 0 ? lit_total : (0x5320u >> (4 * kind)) & 15u;
   }
   /* no second look at the positions fast() gave up on: one speculative position in 64 carries a literal tag with length
    * bytes, so nearly every window would take the branch */
   static constexpr bool kSecondChance = false;
-  __device__ __forceinline__ uint32_t second(const lzw::InRing&, uint32_t, uint64_t) const { return kUnknown; }
+  template <class R>
+  __device__ __forceinline__ uint32_t second(const R&, uint32_t, uint64_t) const { return kUnknown; }
 };
 struct SlowFn
 {
-  __device__ __forceinline__ uint32_t operator()(const lzw::InRing& r, uint32_t p) const { return chase_slow_next(r, p); }
+  template <class R>
+  __device__ __forceinline__ uint32_t operator()(const R& r, uint32_t p) const { return chase_slow_next(r, p); }
 };
 
-__device__ __forceinline__ void parse(const lzw::InRing& r, uint32_t p, bool active, lz::Seq& s, bool& bad)
+template <class R>
+__device__ __forceinline__ void parse(const R& r, uint32_t p, bool active, lz::Seq& s, bool& bad)
 {
   s.lit_src = 0;
   s.lit_len = 0;
@@ -195,9 +202,10 @@ __device__ __forceinline__ void parse(const lzw::InRing& r, uint32_t p, bool act
 
 /* The 8 stream bytes at virtual position p (resident, p + 11 below the end of residency): aligned dword reads and a
  * funnel shift (a misaligned ds_read_b32 is served lane by lane). */
-__device__ __forceinline__ uint64_t ring_bytes8(const lzw::InRing& r, uint32_t p)
+template <class R>
+__device__ __forceinline__ uint64_t ring_bytes8(const R& r, uint32_t p)
 {
-  const uint32_t m = lzw::kInRing - 1;
+  const uint32_t m = R::kMask;
   const uint32_t a0 = p & ~3u;
   const uint32_t d0 = *(const uint32_t*)(r.ring + (a0 & m));
   const uint32_t d1 = *(const uint32_t*)(r.ring + ((a0 + 4) & m));
@@ -214,8 +222,9 @@ __device__ __forceinline__ uint64_t ring_bytes8(const lzw::InRing& r, uint32_t p
  * and the lanes run straight-line code. Returns false (wave-uniform) when the general parser must do the batch. */
 constexpr uint32_t kFastSpan = 80;
 
+template <class R>
 __device__ __forceinline__ bool parse_fast(
-    const lzw::InRing& r, uint32_t p, uint32_t from, uint32_t to, lz::Seq& s, bool& bad)
+    const R& r, uint32_t p, uint32_t from, uint32_t to, lz::Seq& s, bool& bad)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   const uint32_t first = wave::read_lane(p, from);
@@ -254,7 +263,8 @@ __device__ __forceinline__ bool parse_fast(
 
 /* The varint32 preamble (uncompressed length) at the start of the stream, whose first block must be resident:
  * q = position of the first element. False: malformed. */
-__device__ __forceinline__ bool read_preamble(const lzw::InRing& ir, uint32_t& q, uint32_t& total)
+template <class R>
+__device__ __forceinline__ bool read_preamble(const R& ir, uint32_t& q, uint32_t& total)
 {
   q = ir.vbeg;
   total = 0;
@@ -295,6 +305,44 @@ __device__ __forceinline__ uint64_t merge_trains(lz::Seq& s, uint32_t count)
   }
   return train;
 }
+
+/* What the workgroup-per-chunk decoder (common/lz_team.hip.h) needs to know of the format. */
+struct TeamFrontEnd
+{
+  static constexpr uint32_t kPositions = 128; /* a token is at least 2 bytes (a copy element with a one-byte offset) */
+  static constexpr bool kEmptyIsError = true; /* no preamble */
+  using Delta = DeltaFn;
+  using Slow = SlowFn;
+  /* the preamble: first element, and the length the elements must produce exactly */
+  template <class R>
+  static __device__ __forceinline__ bool begin(const R& r, uint32_t out_cap, uint32_t& q, uint32_t& limit, uint32_t& err)
+  {
+    uint32_t total;
+    if (!read_preamble(r, q, total)) {
+      err |= lz::kErrInput;
+      return false;
+    }
+    if (total > out_cap) {
+      err |= lz::kErrOutput;
+      return false;
+    }
+    limit = total;
+    return true;
+  }
+  template <class R>
+  static __device__ __forceinline__ void parse_batch(const R& r, uint32_t p, uint32_t from, uint32_t to, lz::Seq& s, bool& bad)
+  {
+    if (to <= from || !parse_fast(r, p, from, to, s, bad)) {
+      const uint32_t lane = (uint32_t)wave::lane_id();
+      parse(r, p, lane - from < to - from, s, bad);
+    }
+    (void)merge_trains(s, to);
+  }
+  static __device__ __forceinline__ bool finish_ok(uint32_t op, uint32_t q, uint32_t vend, uint32_t limit)
+  {
+    return op == limit && q == vend;
+  }
+};
 
 template <bool CHECKED>
 __device__ __forceinline__ uint32_t decode_chunk(
@@ -345,7 +393,10 @@ __device__ __forceinline__ uint32_t decode_chunk(
       count = lzw::chase_tokens(c, ir, seqpos, count, DeltaFn(), SlowFn());
       lz::Seq fresh;
       bool bad;
+      LZ_STAT("sn_refills", 1);
+      LZ_STAT("sn_new_tokens", count - before);
       if (count <= before || !parse_fast(ir, seqpos, before, count, fresh, bad)) {
+        LZ_STAT("sn_parse_general", 1);
         parse(ir, seqpos, lane >= before && lane < count, fresh, bad);
       }
       if (lane >= before) {
@@ -357,6 +408,8 @@ __device__ __forceinline__ uint32_t decode_chunk(
       }
     }
     const uint64_t train = merge_trains(s, count);
+    LZ_STAT("sn_rounds", 1);
+    LZ_STAT("sn_rounds_with_train", train ? 1 : 0);
     bool big;
     uint32_t take = lzw::execute_window_batch<CHECKED>(ir, ow, limit, op, count, s, err, big);
     if (CHECKED && err) {
@@ -425,14 +478,14 @@ __device__ __forceinline__ void produce(const uint8_t* __restrict__ in, uint32_t
       }
       wave::nap();
     }
-    uint32_t* f = (uint32_t*)(sh.slot[k] + 16);
+    uint32_t* f = (uint32_t*)(sh.slot(k) + 16);
     f[lane] = s.lit_src;
     f[64 + lane] = s.lit_len;
     f[128 + lane] = s.match_off;
     f[192 + lane] = s.match_len;
     if (lane == 0) {
-      ((uint32_t*)sh.slot[k])[0] = count;
-      ((uint32_t*)sh.slot[k])[1] = flags;
+      ((uint32_t*)sh.slot(k))[0] = count;
+      ((uint32_t*)sh.slot(k))[1] = flags;
     }
     wave::sync();
     if (lane == 0) {
@@ -476,13 +529,13 @@ __device__ __forceinline__ uint32_t consume(
       while (poll(sh.state + k) != 1) {
         wave::nap();
       }
-      const uint32_t* f = (const uint32_t*)(sh.slot[k] + 16);
+      const uint32_t* f = (const uint32_t*)(sh.slot(k) + 16);
       s.lit_src = f[lane];
       s.lit_len = f[64 + lane];
       s.match_off = f[128 + lane];
       s.match_len = f[192 + lane];
-      const uint32_t n = wave::read_lane(((const uint32_t*)sh.slot[k])[0], 0);
-      const uint32_t flags = wave::read_lane(((const uint32_t*)sh.slot[k])[1], 0);
+      const uint32_t n = wave::read_lane(((const uint32_t*)sh.slot(k))[0], 0);
+      const uint32_t flags = wave::read_lane(((const uint32_t*)sh.slot(k))[1], 0);
       wave::sync();
       if (lane == 0) {
         wave::lds_store_release(sh.state + k, 0u);
