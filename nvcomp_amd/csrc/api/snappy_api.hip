@@ -84,10 +84,10 @@ __global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_WAVES_PER_SIMD) sna
 
 /* A workgroup per chunk (common/lz_team.hip.h): batches that cannot fill the card with one wave per chunk. Persistent
  * workgroups when the caller's temp buffer holds a ticket counter, one workgroup per chunk otherwise. */
-template <bool CHECKED>
-__global__ void __launch_bounds__(lzt::kThreads, 4) snappy_decompress_team_kernel(const lzl::Launch launch)
+template <bool CHECKED, uint32_t WAVES>
+__global__ void __launch_bounds__(64 * WAVES, 4) snappy_decompress_team_kernel(const lzl::Launch launch)
 {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[lzt::kLds];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[lzt::Geo<WAVES>::kLds];
   size_t chunk = blockIdx.x;
   for (;;) {
     const auto* a = wave::kernel_args(launch);
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(lzt::kThreads, 4) snappy_decompress_team_kerne
     if (in_len64 > 0xffffffffull - 64) {
       err = lz::kErrInput;
     } else {
-      produced = lzt::decode_chunk<snappyw::TeamFrontEnd>(
+      produced = lzt::decode_chunk<snappyw::TeamFrontEnd, WAVES>(
           in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err,
           [](const uint8_t* i, uint32_t n, uint8_t* o, uint32_t cap, uint8_t* scratch, uint32_t& e) {
             return snappyw::decode_chunk<true>(i, n, o, cap, scratch, e);
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(lzt::kThreads, 4) snappy_decompress_team_kerne
     if (ticket == nullptr) {
       break;
     }
-    uint32_t* slot = (uint32_t*)(lds + lzt::kLds - 4 * lzt::kCtlWords) + lzt::kCtlTicket;
+    uint32_t* slot = (uint32_t*)(lds + lzt::Geo<WAVES>::kLds - 4 * lzt::kCtlWords) + lzt::kCtlTicket;
     if (threadIdx.x == 0) {
       *slot = atomicAdd(ticket, 1u);
     }
@@ -307,10 +307,20 @@ nvcompStatus_t nvcompBatchedSnappyDecompressAsync(
   if (batch_size <= lzl::kTeamMaxBatch) {
     unsigned groups = (unsigned)batch_size;
     uint32_t* ticket = nullptr;
+    const lzl::Launch one_each = {b, nullptr, (size_t)groups};
+    if (batch_size <= lzl::kTeam16MaxBatch) {
+      /* at most one chunk per CU: sixteen waves a chunk (one team holds a whole CU's LDS budget for two) */
+      if (checked) {
+        hipLaunchKernelGGL((snappy_decompress_team_kernel<true, 16>), dim3(groups), dim3(1024), 0, stream, one_each);
+      } else {
+        hipLaunchKernelGGL((snappy_decompress_team_kernel<false, 16>), dim3(groups), dim3(1024), 0, stream, one_each);
+      }
+      return launch_status();
+    }
     if (device_temp_ptr != nullptr && temp_bytes >= sizeof(uint32_t) && ((uintptr_t)device_temp_ptr & 3u) == 0) {
       static lzl::ResidentCache resident[2]; /* per device ordinal */
-      const unsigned fit = checked ? resident[1].get(snappy_decompress_team_kernel<true>, lzt::kThreads, 0)
-                                   : resident[0].get(snappy_decompress_team_kernel<false>, lzt::kThreads, 0);
+      const unsigned fit = checked ? resident[1].get(snappy_decompress_team_kernel<true, 8>, 512, 0)
+                                   : resident[0].get(snappy_decompress_team_kernel<false, 8>, 512, 0);
       if (fit != 0 && fit < groups && hipMemsetAsync(device_temp_ptr, 0, sizeof(uint32_t), stream) == hipSuccess) {
         ticket = (uint32_t*)device_temp_ptr;
         groups = fit;
@@ -318,9 +328,9 @@ nvcompStatus_t nvcompBatchedSnappyDecompressAsync(
     }
     const lzl::Launch launch = {b, ticket, (size_t)groups};
     if (checked) {
-      hipLaunchKernelGGL((snappy_decompress_team_kernel<true>), dim3(groups), dim3(lzt::kThreads), 0, stream, launch);
+      hipLaunchKernelGGL((snappy_decompress_team_kernel<true, 8>), dim3(groups), dim3(512), 0, stream, launch);
     } else {
-      hipLaunchKernelGGL((snappy_decompress_team_kernel<false>), dim3(groups), dim3(lzt::kThreads), 0, stream, launch);
+      hipLaunchKernelGGL((snappy_decompress_team_kernel<false, 8>), dim3(groups), dim3(512), 0, stream, launch);
     }
     return launch_status();
   }

@@ -31,6 +31,9 @@
 #ifndef NVCOMP_LZ_TEAM_MAX_BATCH
 #define NVCOMP_LZ_TEAM_MAX_BATCH 512 /* a WORKGROUP per chunk up to this many chunks (common/lz_team.hip.h): 263 us per chunk against 467 (two waves) and 677 (one); from 1 024 chunks on two waves per chunk keep more chunks in flight (profiles/r04_team.jsonl) */
 #endif
+#ifndef NVCOMP_LZ_TEAM16_MAX_BATCH
+#define NVCOMP_LZ_TEAM16_MAX_BATCH 256 /* ... of which batches of at most one chunk per CU get teams of sixteen waves */
+#endif
 #ifndef NVCOMP_LZ_MAX_WG_PER_CU
 #define NVCOMP_LZ_MAX_WG_PER_CU 7 /* cap on the persistent workgroups (of four waves) per CU; 0 = as many as stay resident.
                                    * Measured on MI355X (profiles/r03_ab_g.jsonl): the decoders fit 8 waves/SIMD since they stopped
@@ -46,6 +49,7 @@ namespace lzl {
 
 constexpr size_t kPairMaxBatch = (size_t)(NVCOMP_LZ_PAIR_MAX_BATCH);
 constexpr size_t kTeamMaxBatch = (size_t)(NVCOMP_LZ_TEAM_MAX_BATCH);
+constexpr size_t kTeam16MaxBatch = (size_t)(NVCOMP_LZ_TEAM16_MAX_BATCH) < kTeamMaxBatch ? (size_t)(NVCOMP_LZ_TEAM16_MAX_BATCH) : kTeamMaxBatch;
 constexpr uint32_t kMaxOutCap = 1u << 26;
 constexpr size_t kTicketBytes = 16; /* what the temp-size queries ask for: one u32 counter, padded */
 

@@ -23,7 +23,8 @@
  *              3. a prefix sum over the waves' output sizes places every sequence; literals are copied;
  *              4. matches are copied as soon as their source bytes are final: per-granule counters of pending match
  *                 destinations (16 bytes a granule) tell, the oldest pending match of the step is always free to go.
- *            Four workgroup barriers a step.
+ *            Three workgroup barriers a step (the tables of step s + 1 are built in front of the barrier that ends step s:
+ *            whoever finishes its matches early has something to do).
  *
  * kPositions is the format's: the largest window that cannot hold more than 64 tokens (LZ4: 192 = 64 x 3 bytes), so a
  * wave's window is one batch, one sequence per lane.
@@ -43,8 +44,6 @@ namespace lzt {
 #ifndef NVCOMP_LZT_MARGIN
 #define NVCOMP_LZT_MARGIN 2560
 #endif
-constexpr uint32_t kWaves = 8;
-constexpr uint32_t kThreads = 64 * kWaves;
 constexpr uint32_t kMaxOut = 65536;              /* the largest chunk (output capacity) a team takes */
 constexpr uint32_t kMargin = NVCOMP_LZT_MARGIN;  /* room between the end of the output and the end of the stream */
 constexpr uint32_t kBuf = kMaxOut + kMargin + 32; /* + the two 16-byte alignment slacks (output front, stream back) */
@@ -54,10 +53,20 @@ constexpr uint32_t kGran = 16;                   /* bytes per readiness granule 
 constexpr uint32_t kTrack = 16384;               /* output bytes of a step the granule counters cover */
 constexpr uint32_t kGranules = kTrack / kGran;
 constexpr uint32_t kCntLds = kGranules + 16;     /* one byte a granule (+ what a 4-counter read may touch behind the last) */
-constexpr uint32_t kCtlWords = 48;
-constexpr uint32_t kLds = kBufLds + kWaves * lzw::kChaseLds + kCntLds + 4 * kCtlWords;
-static_assert(kLds <= 81920, "two workgroups per CU");
-static_assert(kWaves * lzw::kChaseLds >= lzw::kLdsPerWave, "the fallback decoder's scratch is the table area");
+constexpr uint32_t kCtlWords = 96;
+constexpr uint32_t kMaxWaves = 16;
+
+/* A team of WAVES waves (8: two teams per CU, 16: one -- a batch of at most one chunk per CU): threads and LDS. */
+template <uint32_t WAVES>
+struct Geo
+{
+  static_assert(WAVES == 8 || WAVES == 16, "teams of 8 or 16 waves");
+  static constexpr uint32_t kWaves = WAVES;
+  static constexpr uint32_t kThreads = 64 * WAVES;
+  static constexpr uint32_t kLds = kBufLds + WAVES * lzw::kChaseLds + kCntLds + 4 * kCtlWords;
+  static_assert(WAVES * lzw::kChaseLds >= lzw::kLdsPerWave, "the fallback decoder's scratch is the table area");
+  static_assert(kLds <= (WAVES == 8 ? 81920u : 163840u), "two workgroups of 8 waves per CU, or one of 16");
+};
 
 constexpr uint32_t kUnknownExit = 0xffffffffu;
 
@@ -66,11 +75,11 @@ enum : uint32_t {
   kCtlErr = 0,
   kCtlFallback = 1,
   kCtlTicket = 2,
-  kCtlSpec = 4,   /* [kWaves] speculated exit of window w */
-  kCtlExit = 12,  /* [kWaves] true exit */
-  kCtlBytes = 20, /* [kWaves] output bytes of window w's sequences */
-  kCtlProg = 28,  /* [kWaves] everything of slot w below this output position is final */
-  kCtlBad = 36,   /* [kWaves] parse error */
+  kCtlSpec = 4,   /* [kMaxWaves] speculated exit of window w */
+  kCtlExit = 20,  /* [kMaxWaves] true exit */
+  kCtlBytes = 36, /* [kMaxWaves] output bytes of window w's sequences */
+  kCtlProg = 52,  /* [kMaxWaves] everything of slot w below this output position is final */
+  kCtlBad = 68,   /* [kMaxWaves] parse error */
 };
 
 /* The whole chunk's stream, staged in LDS: ring[v] is the byte at virtual position v (v = chunk offset + (chunk & 15)),
@@ -102,6 +111,7 @@ __device__ __forceinline__ uint32_t ctl_read(const Team& t, uint32_t i)
 }
 
 /* all lanes of the team: chunk -> LDS, 16 bytes per lane and step, bytes outside the chunk never fetched (read as zero) */
+template <uint32_t kThreads>
 __device__ __forceinline__ void stage_stream(const Stream& st, uint32_t tid)
 {
   const uint32_t nblocks = ((st.vend + 15u) >> 4) + 1u; /* + one block of zeroes */
@@ -125,6 +135,7 @@ __device__ __forceinline__ void stage_stream(const Stream& st, uint32_t tid)
 }
 
 /* all lanes of the team: output positions [from, to) -> HBM; 16-byte aligned lane stores, bytes around them */
+template <uint32_t kThreads>
 __device__ __forceinline__ void flush(const Team& t, uint32_t from, uint32_t to, uint32_t tid)
 {
   if (to <= from) {
@@ -242,14 +253,15 @@ __device__ __forceinline__ uint32_t cnt_read4(const uint32_t* cnt, uint32_t g)
 }
 
 /*
- * Decode one chunk with the calling workgroup (kThreads lanes, all of them call). `lds` = kLds bytes, 16-byte aligned.
+ * Decode one chunk with the calling workgroup (64 x WAVES lanes, all of them call). `lds` = Geo<WAVES>::kLds bytes, 16-byte aligned.
  * FrontEnd supplies the format: kPositions, DeltaFn / SlowFn (the chase's distance functions) and parse_batch().
  * Returns the bytes produced; err != 0 on a malformed chunk. Always validates (a team never writes outside its buffer).
  */
-template <class FrontEnd, class Fallback>
+template <class FrontEnd, uint32_t WAVES, class Fallback>
 __device__ __forceinline__ uint32_t decode_chunk(
     const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_cap, uint8_t* lds, uint32_t& err, Fallback fallback)
 {
+  constexpr uint32_t kWaves = WAVES, kThreads = 64 * WAVES;
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = (uint32_t)wave::lane_id();
   Team t;
@@ -297,7 +309,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
   for (uint32_t i = tid; i < kCntLds / 4; i += kThreads) {
     t.cnt[i] = 0; /* (every match that registers here leaves again: the counters are zero between steps) */
   }
-  stage_stream(st, tid);
+  stage_stream<kThreads>(st, tid);
   __syncthreads();
   LZW_T(0);
 
@@ -314,20 +326,11 @@ __device__ __forceinline__ uint32_t decode_chunk(
   bool give_up = false; /* in-place invariant broken: the one-wave decoder redoes the chunk */
   typename FrontEnd::Delta delta;
   typename FrontEnd::Slow slow;
-  while (q < st.vend) {
-    /* ---- 1. tables of this wave's window, speculated exit; HBM gets what the previous step finished ---- */
-    {
-      const uint32_t upto = ((op + t.oa) & ~15u) - t.oa; /* whole 16-byte blocks only (op + oa >= 16 or nothing to do) */
-      if ((op + t.oa) >= 16 && upto > flushed) {
-        flush(t, flushed, upto, tid);
-        flushed = upto;
-      }
-    }
-    LZT_TR("w%u step q=%u op=%u\n", t.w, q, op);
-    const uint32_t wb = q + FrontEnd::kPositions * t.w;
-    const bool have_window = wb < st.vend;
-    if (have_window) {
-      c.q = wb;
+  /* ---- 1. tables of this wave's window of the step that starts at q_, speculated exit ---- */
+  auto build_step = [&](uint32_t q_) {
+    const uint32_t wb_ = q_ + FrontEnd::kPositions * t.w;
+    if (wb_ < st.vend) {
+      c.q = wb_;
       lzw::chase_build(c, st, delta, FrontEnd::kPositions);
       if (t.w + 1 < kWaves) { /* (window 0 is entered at its first byte: its "speculation" is the truth; nobody enters behind the last window) */
         const uint32_t x = exit_of(c, st, descend(c), true, slow);
@@ -338,10 +341,17 @@ __device__ __forceinline__ uint32_t decode_chunk(
     } else if (lane == 0) {
       t.ctl[kCtlSpec + t.w] = kUnknownExit;
     }
-    LZT_TR("w%u A\n", t.w);
-    LZW_T(1);
-    __syncthreads();
-    LZW_T(2);
+  };
+  if (q < st.vend) {
+    build_step(q);
+  }
+  LZW_T(1);
+  __syncthreads();
+  LZW_T(2);
+  while (q < st.vend) {
+    LZT_TR("w%u step q=%u op=%u\n", t.w, q, op);
+    const uint32_t wb = q + FrontEnd::kPositions * t.w;
+    const bool have_window = wb < st.vend;
     /* ---- 2. entry = the exit speculated by the window in front; enumerate, parse, sizes ---- */
     const uint32_t entry = t.w == 0 ? q : ctl_read(t, kCtlSpec + t.w - 1);
     uint32_t n = 0;
@@ -616,10 +626,25 @@ __device__ __forceinline__ uint32_t decode_chunk(
     }
     LZT_TR("w%u C\n", t.w);
     LZW_T(9);
+    /* a wave that is through with its matches builds the tables of the NEXT step while the others finish theirs (they depend
+     * on the stream only, and the stream from next_q on is out of this step's reach: the in-place test above); the barrier
+     * that ends this step is the one the next step's enumeration waits for */
+    if (next_q < st.vend) {
+      build_step(next_q);
+    }
+    LZW_T(1);
     __syncthreads();
     LZW_T(13);
     op = step_end;
     q = next_q;
+    {
+      /* HBM gets what the step finished: whole 16-byte blocks only, the rest waits */
+      const uint32_t upto = ((op + t.oa) & ~15u) - t.oa;
+      if ((op + t.oa) >= 16 && upto > flushed) {
+        flush<kThreads>(t, flushed, upto, tid);
+        flushed = upto;
+      }
+    }
   }
   /* every wave leaves the loop at the same point (the conditions are uniform across the team) */
   __syncthreads();
@@ -647,7 +672,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
   }
   /* (a last token that claims more than the chunk holds was refused by the parser; the chase itself may report
    * "behind the end" for a chunk's regular last sequence) */
-  flush(t, flushed, op, tid);
+  flush<kThreads>(t, flushed, op, tid);
   __syncthreads(); /* the buffer is free again */
   LZW_T(14);
   return op;

@@ -29,6 +29,11 @@ CASES = {
     "mix512m": ("LZ4", "silesia_style", "hc", 64, 512),
     "snappy256m": ("Snappy", "silesia_style", "snappy", 64, 256),
     "snappy64m": ("Snappy", "silesia_style", "snappy", 64, 64),
+    "snappy16m": ("Snappy", "silesia_style", "snappy", 16, 16),
+    "snappy32m": ("Snappy", "silesia_style", "snappy", 32, 32),
+    "mix32m": ("LZ4", "silesia_style", "hc", 32, 32),
+    "mix4m": ("LZ4", "silesia_style", "hc", 4, 4),
+    "mix1m": ("LZ4", "silesia_style", "hc", 1, 1),
     "snappy_mix": ("Snappy", "silesia_style", "snappy", 64, None),
     "mortgage": ("LZ4", "mortgage_col0_like", "fast", 64, 1024),
     "mortgage5k": ("LZ4", "mortgage_col0_like", "fast", 64, 314),

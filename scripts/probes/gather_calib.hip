@@ -60,8 +60,9 @@ __global__ void __launch_bounds__(256) probe(const uint8_t* __restrict__ buf, ui
 
 int main(int argc, char** argv)
 {
-  const uint64_t bytes = 2ull << 30;
   const uint32_t per_lane = argc > 1 ? (uint32_t)atoi(argv[1]) : 32;
+  /* footprint in MiB (default 2 GiB = eight times the Infinity Cache; 128 = inside it: the rate of requests it serves) */
+  const uint64_t bytes = (argc > 2 ? (uint64_t)atoi(argv[2]) : 2048ull) << 20;
   uint8_t* buf = nullptr;
   uint32_t* sink = nullptr;
   if (hipMalloc(&buf, bytes) != hipSuccess || hipMalloc(&sink, 1024) != hipSuccess) {
@@ -92,8 +93,8 @@ int main(int argc, char** argv)
       best = ms < best ? ms : best;
     }
     const uint64_t loads = lanes * per_lane;
-    printf("{\"probe\": \"%s\", \"mode\": %d, \"loads\": %llu, \"bytes_asked\": %llu, \"ms\": %.3f, \"Gloads_per_s\": %.2f, \"launches\": 3}\n",
-           names[mode], mode, (unsigned long long)loads, (unsigned long long)(loads * 16), best, loads / best / 1e6);
+    printf("{\"probe\": \"%s\", \"footprint_MiB\": %llu, \"mode\": %d, \"loads\": %llu, \"bytes_asked\": %llu, \"ms\": %.3f, \"Gloads_per_s\": %.2f, \"launches\": 3}\n",
+           names[mode], (unsigned long long)(bytes >> 20), mode, (unsigned long long)loads, (unsigned long long)(loads * 16), best, loads / best / 1e6);
   }
   hipFree(buf), hipFree(sink);
   return 0;
