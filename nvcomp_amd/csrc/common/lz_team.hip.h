@@ -55,6 +55,7 @@ constexpr uint32_t kGranules = kTrack / kGran;
 constexpr uint32_t kCntLds = kGranules + 16;     /* one byte a granule (+ what a 4-counter read may touch behind the last) */
 constexpr uint32_t kCtlWords = 96;
 constexpr uint32_t kMaxWaves = 16;
+constexpr uint32_t kSpinLimit = 1u << 18;       /* polls of a waiting wave (tens of milliseconds) before the chunk is given up */
 
 /* A team of WAVES waves (8: two teams per CU, 16: one -- a batch of at most one chunk per CU): threads and LDS. */
 template <uint32_t WAVES>
@@ -550,6 +551,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
     const uint32_t ngran = sbg - sa + 1; /* 1 .. 3 */
     const uint32_t cmask = ngran >= 4 ? 0xffffffffu : (1u << (8u * ngran)) - 1u;
     const uint32_t cself = (tracked && sbg == ga) ? 1u << (8u * (sbg - sa)) : 0u;
+    uint32_t spins = 0;
     while (pending) {
       pending = wave::uniform64(pending); /* (it is: spelled out for the compiler) */
       const bool mine = wave::lane_in(pending);
@@ -596,6 +598,14 @@ __device__ __forceinline__ uint32_t decode_chunk(
           if (ctl_read(t, kCtlErr)) {
             break;
           }
+          /* waiting for another wave's matches. The wait is bounded by construction (the step's oldest pending match is
+           * always free to go); the counter turns a logic error into a failed chunk instead of a hung card */
+          if (++spins > kSpinLimit) {
+            if (lane == 0) {
+              t.ctl[kCtlErr] = lz::kErrInput;
+            }
+            break;
+          }
           wave::nap();
           LZW_T(12);
           continue;
@@ -635,6 +645,10 @@ __device__ __forceinline__ uint32_t decode_chunk(
     LZW_T(1);
     __syncthreads();
     LZW_T(13);
+    if (ctl_read(t, kCtlErr)) { /* a wave gave the step up */
+      err |= lz::kErrInput;
+      break;
+    }
     op = step_end;
     q = next_q;
     {
