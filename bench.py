@@ -796,10 +796,21 @@ def run_allgather_case(args, ctx):
         st = statuses[:m].cpu().numpy()
         assert (st == 0).all(), f"{int((st != 0).sum())} remote chunks failed"
     # every rank must now hold every shard: compare fingerprints with the owners'
-    weights = (torch.arange(shard_bytes, device=sizes.device) % 65521).to(torch.int64)
-    prints = torch.stack([(out[r * shard_bytes: (r + 1) * shard_bytes].to(torch.int64) * weights).sum() for r in range(world)])
+    # (position-weighted byte sums, 64 MiB at a time: a 4 GiB shard as ONE int64 tensor is 32 GB and a launch the runtime
+    # refuses -- found by tests/test_programs.py::test_bench_under_launcher_with_rccl[allgather_4gib] in round 4)
+    piece = 64 << 20
+    weights = (torch.arange(min(piece, shard_bytes), device=sizes.device) % 65521).to(torch.int64)
+
+    def fingerprint(buf):
+        acc = torch.zeros((), dtype=torch.int64, device=sizes.device)
+        for at in range(0, shard_bytes, piece):
+            part = buf[at: at + piece].to(torch.int64)
+            acc += (part * weights[: part.numel()]).sum() * (1 + at // piece)
+        return acc
+
+    prints = torch.stack([fingerprint(out[r * shard_bytes: (r + 1) * shard_bytes]) for r in range(world)])
     owner = torch.zeros(world, dtype=torch.int64, device=sizes.device)
-    own = (raw.to(torch.int64) * weights).sum().reshape(1)
+    own = fingerprint(raw).reshape(1)
     dist.all_gather_into_tensor(owner, own)
     assert torch.equal(prints, owner), "a rank holds wrong data after the all-gather"
     total = shard_bytes * world
