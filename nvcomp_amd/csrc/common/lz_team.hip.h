@@ -407,6 +407,13 @@ __device__ __forceinline__ uint32_t decode_chunk(
       err |= any_bad || next_q <= q ? lz::kErrInput : lz::kErrOutput;
       break;
     }
+    if (t.w == 0) {
+      LZ_STAT("team_steps", 1);
+      LZ_STAT("team_windows_standing", standing);
+      LZ_STAT("team_steps_cut_short", standing < kWaves && next_q < st.vend ? 1 : 0);
+      LZ_STAT("team_gave_up", step_end + t.oa > sb + next_q ? 1 : 0);
+      LZ_STAT("team_steps_literals_from_hbm", step_end + t.oa > sb + q ? 1 : 0);
+    }
     if (step_end + t.oa > sb + next_q) { /* the output would reach into the stream the next step reads */
       give_up = true;
       break;

@@ -271,3 +271,59 @@ def test_roundtrip_ragged(backend, lz_path, oracle):
     assert (status == 0).all() and actual.tolist() == [c.size for c in chunks]
     for o, c in zip(outs, chunks):
         assert np.array_equal(o, c)
+
+
+def _varint(n):
+    out = bytearray()
+    while n >= 128:
+        out.append((n & 127) | 128)
+        n >>= 7
+    out.append(n)
+    return bytes(out)
+
+
+def test_stream_that_grows_behind_a_compressible_front(backend, lz_path, oracle):
+    """A legal stream libsnappy never writes: 40 KiB of one byte as 64-byte copy elements (3 stream bytes each), then
+    25.5 KiB of one-byte literal elements (2 stream bytes each). Its total size is below a chunk's, but behind the run
+    the stream is TWICE the output that is left -- the workgroup-per-chunk decoder keeps output and stream in one LDS
+    buffer ("in place", common/lz_team.hip.h) and must notice that this chunk's output would overrun its unread stream
+    and hand it to the one-wave decoder; every other path just decodes it. Plus the same shape with the expanding part in
+    front (no conflict) and a chunk of nothing but one-byte literals (larger than a team takes: refused by size)."""
+    rng = np.random.default_rng(5)
+
+    def build(front_run, lits):
+        body = bytearray()
+        out = bytearray()
+        if front_run:
+            body += bytes([0 << 2 | 0, 0x41])  # literal "A"
+            out += b"A"
+            while len(out) < front_run:
+                n = min(64, front_run - len(out))
+                body += bytes([((n - 1) << 2) | 2, 1, 0])  # copy-2: length n, offset 1
+                out += b"A" * n
+        for v in lits:
+            body += bytes([0, v])  # literal element of one byte
+            out.append(v)
+        return out, body
+
+    cases = []
+    out, body = build(40 * 1024, rng.integers(0, 256, 65536 - 40 * 1024, dtype=np.uint8).tolist())
+    cases.append((out, body))
+    lits = rng.integers(0, 256, 12 * 1024, dtype=np.uint8).tolist()
+    o2, b2 = build(0, lits)
+    tail_out = bytearray(o2)
+    tail_body = bytearray(b2)
+    while len(tail_out) < 65536:  # expanding part first, the run behind it
+        n = min(64, 65536 - len(tail_out))
+        tail_body += bytes([((n - 1) << 2) | 2, 1, 0])
+        tail_out += bytes([tail_out[-1]]) * n
+    cases.append((tail_out, tail_body))
+    cases.append(build(0, rng.integers(0, 256, 40000, dtype=np.uint8).tolist()))
+    chunks = [np.frombuffer(bytes(o), dtype=np.uint8) for o, _ in cases]
+    comp = [np.frombuffer(_varint(len(o)) + bytes(b), dtype=np.uint8) for o, b in cases]
+    assert comp[0].size < 65536 + 512  # small enough for a team to take it
+    for c, cc in zip(chunks, comp):
+        if oracle.have_ref():
+            rc, ref = oracle.ref_snappy_decompress(cc, c.size)
+            assert rc == 0 and np.array_equal(ref, c)  # libsnappy reads it
+    check_decode(backend, oracle, chunks, comp)
