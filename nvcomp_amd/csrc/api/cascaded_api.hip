@@ -34,6 +34,10 @@ constexpr uint32_t kHeaderBytes = 20;
 #define NVCOMP_CASC_COMP_WGS 6
 #endif
 constexpr uint32_t kCompSmallBudget = NVCOMP_CASC_COMP_SMALL;
+#ifndef NVCOMP_CASC_DEC_TEAM_MAX_BATCH
+#define NVCOMP_CASC_DEC_TEAM_MAX_BATCH 4096
+#endif
+constexpr size_t kDecTeamMaxBatch = NVCOMP_CASC_DEC_TEAM_MAX_BATCH;
 #ifndef NVCOMP_CASC_DEC_SMALL
 #define NVCOMP_CASC_DEC_SMALL (5 * 1024)
 #endif
@@ -153,7 +157,14 @@ __global__ void __launch_bounds__(256, NVCOMP_CASC_COMP_WGS) cascaded_compress_k
 }
 
 /* pass p decodes the chunks with todo == p (pass 0: all) whose streams fit its LDS budget and hands the others
- * on by setting todo = p + 1. */
+ * on by setting todo = p + 1.
+ * `team` (round 4, batches of up to kDecTeamMaxBatch chunks): a WORKGROUP per chunk. The sub-chunks of a chunk are independent
+ * streams (their ends are in the chunk's table), so the workgroup's four waves take them in turn -- wave v the sub-chunks
+ * v, v + 4, ... -- instead of one wave walking all sixteen: a quarter of a chunk's latency and four times the waves for
+ * batches that cannot fill the card (1 024 chunks of the float columns: 401 -> 906 GB/s, 256 chunks: 108 -> 280). The
+ * waves' verdicts (error, "needs the next pass") meet in two LDS words. Large batches keep a chunk per wave: with the
+ * card full, four waves each paying a chunk's header round trips for four sub-chunks are slower than one paying them for
+ * sixteen (16 384 chunks: 1 426 against 1 673; profiles/r04_cascaded_ab.jsonl). */
 __global__ void __launch_bounds__(256, NVCOMP_CASC_DEC_WGS) cascaded_decompress_kernel(
     const void* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes,
@@ -165,17 +176,26 @@ __global__ void __launch_bounds__(256, NVCOMP_CASC_DEC_WGS) cascaded_decompress_
     uint32_t* todo,
     uint32_t pass,
     uint32_t lds_per_wave,
-    uint32_t waves_per_block)
+    uint32_t waves_per_block,
+    uint32_t team) /* 1: the workgroup's waves share ONE chunk; 0: a chunk per wave */
 {
   WAVE_DYNAMIC_LDS(lds);
+  __shared__ uint32_t verdict[2]; /* err bits of the chunk's waves | any wave deferred */
   const uint32_t wv = wave::uniform(threadIdx.x >> 6);
-  const size_t chunk = (size_t)blockIdx.x * waves_per_block + wv;
+  const size_t chunk = team ? (size_t)blockIdx.x : (size_t)blockIdx.x * waves_per_block + wv;
   if (chunk >= batch_size) {
     return;
   }
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   if (pass != 0 && wave::uniform(todo[chunk]) != pass) {
-    return;
+    return; /* (team: the whole workgroup) */
+  }
+  const uint32_t first_sub = team ? wv : 0u, sub_stride = team ? waves_per_block : 1u;
+  if (team) {
+    if (threadIdx.x < 2) {
+      verdict[threadIdx.x] = 0;
+    }
+    __syncthreads();
   }
   const uint8_t* src = wave::uniform_ptr((const uint8_t*)comp_ptrs[chunk]);
   uint8_t* dst = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
@@ -223,30 +243,38 @@ __global__ void __launch_bounds__(256, NVCOMP_CASC_DEC_WGS) cascaded_decompress_
     const uint32_t pay_len = (uint32_t)(src_len - kHeaderBytes - 4 * (size_t)num_sub);
     uint8_t* slice = lds + (size_t)wv * lds_per_wave;
     /* The sub-chunk table is read 64 entries at a time (one coalesced load, then v_readlane), and the first
-     * 256 bytes of the NEXT sub-chunk -- all of its header words -- are requested before the current one is
+     * 256 bytes of the wave's NEXT sub-chunk -- all of its header words -- are requested before the current one is
      * decoded: per sub-chunk one memory round trip is exposed (the packed words) instead of three. */
-    uint32_t tab = 0;
+    uint32_t tab = 0, tab_base = 0xffffffffu;
+    auto table_at = [&](uint32_t i) -> uint32_t { /* table[i], i < num_sub (uniform) */
+      if ((i & ~63u) != tab_base) {
+        tab_base = i & ~63u;
+        tab = tab_base + lane < num_sub ? table[tab_base + lane] : 0u;
+      }
+      return wave::read_lane(tab, i & 63u);
+    };
     auto load_head = [&](uint32_t b, uint32_t e) -> uint32_t {
       const uint32_t lim = e < pay_len ? e : pay_len;
       return (b <= lim && 4 * lane + 4 <= lim - b) ? *(const uint32_t*)(payload + b + 4 * lane) : 0u;
     };
     uint32_t begin = 0, end = 0, head = 0;
-    for (uint32_t s = 0; s < num_sub && !err && !deferred; ++s) {
-      if ((s & 63u) == 0) {
-        tab = s + lane < num_sub ? table[s + lane] : 0u;
-        end = wave::read_lane(tab, 0);
-        head = load_head(begin, end);
-      }
+    if (first_sub < num_sub) {
+      begin = first_sub ? table_at(first_sub - 1) : 0u;
+      end = table_at(first_sub);
+      head = load_head(begin, end);
+    }
+    for (uint32_t s = first_sub; s < num_sub && !err && !deferred; s += sub_stride) {
       const uint32_t off = s * sub;
       const uint32_t bytes = n_bytes - off < sub ? n_bytes - off : sub;
       if (end < begin || end > pay_len || end - begin < 4) {
         err = casc::kErrInput;
         break;
       }
-      uint32_t next_end = 0, next_head = 0;
-      if (s + 1 < num_sub && ((s + 1) & 63u) != 0) {
-        next_end = wave::read_lane(tab, (s + 1) & 63u);
-        next_head = load_head(end, next_end);
+      uint32_t next_begin = 0, next_end = 0, next_head = 0;
+      if (s + sub_stride < num_sub) {
+        next_begin = table_at(s + sub_stride - 1);
+        next_end = table_at(s + sub_stride);
+        next_head = load_head(next_begin, next_end);
       }
       uint32_t rc;
       switch (w) {
@@ -274,25 +302,34 @@ __global__ void __launch_bounds__(256, NVCOMP_CASC_DEC_WGS) cascaded_decompress_
       } else if (rc != casc::kSubOk) {
         err = casc::kErrInput;
       }
-      begin = end;
+      begin = next_begin;
       end = next_end;
       head = next_head;
       wave::sync();
     }
     produced = n_bytes;
   } while (false);
-  if (lane == 0) {
-    if (pass == 0 || deferred) {
-      todo[chunk] = deferred ? pass + 1 : 0u;
+  if (team) {
+    if (lane == 0 && (err || deferred)) {
+      atomicOr(&verdict[0], err);
+      atomicOr(&verdict[1], deferred ? 1u : 0u);
     }
-    if (!deferred) {
+    __syncthreads();
+  }
+  if (team ? threadIdx.x == 0 : lane == 0) {
+    const uint32_t all_err = team ? verdict[0] : err;
+    const bool any_deferred = (team ? verdict[1] != 0 : deferred) && all_err == 0; /* (an error is final whatever the other waves wanted) */
+    if (pass == 0 || any_deferred) {
+      todo[chunk] = any_deferred ? pass + 1 : 0u;
+    }
+    if (!any_deferred) {
       if (actual_bytes != nullptr) {
-        actual_bytes[chunk] = err ? 0 : produced;
+        actual_bytes[chunk] = all_err ? 0 : produced;
       }
       if (statuses != nullptr) {
-        statuses[chunk] = err == casc::kOk ? nvcompSuccess
-                          : (err & casc::kErrAlign) ? nvcompErrorAlignment
-                                                    : nvcompErrorCannotDecompress;
+        statuses[chunk] = all_err == casc::kOk ? nvcompSuccess
+                          : (all_err & casc::kErrAlign) ? nvcompErrorAlignment
+                                                        : nvcompErrorCannotDecompress;
       }
     }
   }
@@ -449,18 +486,20 @@ nvcompStatus_t nvcompBatchedCascadedDecompressAsync(
   }
   uint32_t* todo = (uint32_t*)device_temp_ptr;
   clear_stale_error();
-  hipLaunchKernelGGL(cascaded_decompress_kernel, dim3((unsigned)((batch_size + 3) / 4)), dim3(256), 4 * kDecSmallBudget,
+  const uint32_t team = batch_size <= kDecTeamMaxBatch ? 1u : 0u;
+  const dim3 grid4(team ? (unsigned)batch_size : (unsigned)((batch_size + 3) / 4));
+  hipLaunchKernelGGL(cascaded_decompress_kernel, grid4, dim3(256), 4 * kDecSmallBudget,
                      stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
                      device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 0u,
-                     kDecSmallBudget, 4u);
-  hipLaunchKernelGGL(cascaded_decompress_kernel, dim3((unsigned)((batch_size + 3) / 4)), dim3(256), 4 * kFastBudget,
+                     kDecSmallBudget, 4u, team);
+  hipLaunchKernelGGL(cascaded_decompress_kernel, grid4, dim3(256), 4 * kFastBudget,
                      stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
                      device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 1u,
-                     kFastBudget, 4u);
+                     kFastBudget, 4u, team);
   hipLaunchKernelGGL(cascaded_decompress_kernel, dim3((unsigned)batch_size), dim3(64), kBigBudget, stream,
                      device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
                      device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 2u,
-                     kBigBudget, 1u);
+                     kBigBudget, 1u, 0u);
   return launch_status();
 }
 

@@ -100,7 +100,9 @@ def test_benchmark_all_algorithms_sh_runs_unchanged(emu_bench_dir, tmp_path):
     for algo in ("lz4", "snappy", "cascaded", "bitcomp-default", "bitcomp-sparse", "deflate", "ans"):
         assert len(by_algo.get(algo, [])) == 4, (algo, by_algo.keys())
         for row in by_algo[algo]:
-            assert float(row[2]) > 0.5 and float(row[3]) > 0 and float(row[4]) > 0, row
+            # (the throughputs are those of the host EMULATION, printed with four decimals: a workgroup-per-chunk decode of
+            # 512 - 1 024 coroutines can round to 0.0000 GB/s -- the columns must parse, not impress)
+            assert float(row[2]) > 0.5 and float(row[3]) >= 0 and float(row[4]) >= 0, row
     # the commands the script composed are echoed: the typed LZ4 run and the cascaded scheme reached our programs
     assert "benchmark_lz4_chunked -f" in r.stdout and "-t int" in r.stdout
     assert "benchmark_cascaded_chunked -f" in r.stdout and "-r 1 -d 0 -b 1 -t longlong" in r.stdout
