@@ -15,11 +15,12 @@
  *            no far-match gathers, HBM traffic = stream in + output out.
  *   step     per step the eight waves look at eight consecutive windows of kPositions stream positions, one each:
  *              1. every wave builds the jump tables of its window (lzw::chase_build: they do not depend on where the
- *                 token chain enters the window) and -- speculatively -- the exit of the chain that starts at the
- *                 window's first byte; chains merge within a few tokens, so that exit is almost always the true one;
- *              2. with the exits of the windows in front of it as its entry a wave enumerates and parses its own
- *                 tokens; a window whose true exit differs from the speculated one ends the step there (the waves
- *                 behind it did useless work and repeat it in the next step);
+ *                 token chain enters the window) and tabulates the window's EXIT for a chain that enters at each of its
+ *                 first 16 offsets (a lane-parallel descent of the tables);
+ *              2. a wave finds its entry by walking the exit tables of the windows in front of it (exact for entries at
+ *                 those offsets, a guess -- offset 0's exit: chains merge within a few tokens -- for the rare entry further
+ *                 in), enumerates and parses its own tokens; a window that was entered by something else than the true
+ *                 exit of the window in front ends the step there (the waves behind it repeat their work in the next step);
  *              3. a prefix sum over the waves' output sizes places every sequence; literals are copied;
  *              4. matches are copied as soon as their source bytes are final: per-granule counters of pending match
  *                 destinations (16 bytes a granule) tell, the oldest pending match of the step is always free to go.
@@ -53,7 +54,8 @@ constexpr uint32_t kGran = 16;                   /* bytes per readiness granule 
 constexpr uint32_t kTrack = 16384;               /* output bytes of a step the granule counters cover */
 constexpr uint32_t kGranules = kTrack / kGran;
 constexpr uint32_t kCntLds = kGranules + 16;     /* one byte a granule (+ what a 4-counter read may touch behind the last) */
-constexpr uint32_t kCtlWords = 96;
+constexpr uint32_t kCtlWords = 352;
+constexpr uint32_t kEntries = 16;               /* entry offsets of a window whose exits are tabulated */
 constexpr uint32_t kMaxWaves = 16;
 constexpr uint32_t kSpinLimit = 1u << 18;       /* polls of a waiting wave (tens of milliseconds) before the chunk is given up */
 
@@ -76,11 +78,12 @@ enum : uint32_t {
   kCtlErr = 0,
   kCtlFallback = 1,
   kCtlTicket = 2,
-  kCtlSpec = 4,   /* [kMaxWaves] speculated exit of window w */
-  kCtlExit = 20,  /* [kMaxWaves] true exit */
-  kCtlBytes = 36, /* [kMaxWaves] output bytes of window w's sequences */
-  kCtlProg = 52,  /* [kMaxWaves] everything of slot w below this output position is final */
-  kCtlBad = 68,   /* [kMaxWaves] parse error */
+  kCtlExit = 4,   /* [kMaxWaves] true exit of window w */
+  kCtlBytes = 20, /* [kMaxWaves] output bytes of window w's sequences */
+  kCtlProg = 36,  /* [kMaxWaves] everything of slot w below this output position is final */
+  kCtlBad = 52,   /* [kMaxWaves] parse error */
+  kCtlUsed = 68,  /* [kMaxWaves] the entry window w was enumerated from */
+  kCtlSpec = 84,  /* [kMaxWaves][kEntries] exit of window w for a chain that enters it at offset 0 .. kEntries - 1 */
 };
 
 /* The whole chunk's stream, staged in LDS: ring[v] is the byte at virtual position v (v = chunk offset + (chunk & 15)),
@@ -173,24 +176,28 @@ __device__ __forceinline__ uint32_t exit_of(const lzw::Chase& c, const Stream& s
   return speculative ? kUnknownExit : slow(st, c.wb + last);
 }
 
-/* Speculation: the last token of the chain that starts at window offset 0, by descending the jump tables (uniform reads). */
-__device__ __forceinline__ uint32_t descend(const lzw::Chase& c)
+/* The exit of the window for a chain that enters it at offset `start` (per lane): descend the jump tables to the chain's
+ * last token -- at most 64 tokens: four jumps of 16, then 8, 4, 2, 1 -- and leave through that token's own delta. */
+__device__ __forceinline__ uint32_t exit_from(const lzw::Chase& c, uint32_t start)
 {
-  uint32_t pos = 0;
+  uint32_t pos = start;
   const uint32_t top = (lzw::kChaseLevels - 1) * lzw::kChaseWin;
-  for (uint32_t it = 0; it < 4; ++it) { /* at most 64 tokens: four jumps of 16 */
-    const uint32_t a = wave::uniform(c.tab[top + pos]);
-    if (a == 255u) {
-      break;
-    }
-    pos += a;
+  bool go = true;
+#pragma unroll
+  for (uint32_t it = 0; it < 4; ++it) {
+    const uint32_t a = c.tab[top + pos];
+    go = go && a != 255u;
+    pos += go ? a : 0u;
   }
 #pragma unroll
   for (int32_t i = (int32_t)lzw::kChaseLevels - 2; i >= 0; --i) {
-    const uint32_t a = wave::uniform(c.tab[(uint32_t)i * lzw::kChaseWin + pos]);
+    const uint32_t a = c.tab[(uint32_t)i * lzw::kChaseWin + pos];
     pos += a == 255u ? 0u : a;
   }
-  return pos;
+  const uint32_t p01 = wave::shuffle(c.nx01, pos >> 2), p23 = wave::shuffle(c.nx23, pos >> 2);
+  const uint32_t pair = (pos & 2u) ? p23 : p01;
+  const uint32_t d = (pos & 1u) ? pair >> 16 : pair & 0xffffu;
+  return d == lzw::kNxUnknown ? kUnknownExit : c.wb + pos + d;
 }
 
 /* Lane n: the n-th token of the chain that enters the window at offset pos0 (lzw::chase_tokens' enumeration); returns the
@@ -333,14 +340,14 @@ __device__ __forceinline__ uint32_t decode_chunk(
     if (wb_ < st.vend) {
       c.q = wb_;
       lzw::chase_build(c, st, delta, FrontEnd::kPositions);
-      if (t.w + 1 < kWaves) { /* (window 0 is entered at its first byte: its "speculation" is the truth; nobody enters behind the last window) */
-        const uint32_t x = exit_of(c, st, descend(c), true, slow);
-        if (lane == 0) {
-          t.ctl[kCtlSpec + t.w] = x;
+      if (t.w + 1 < kWaves) { /* (nobody enters behind the last window) */
+        const uint32_t x = exit_from(c, lane & (kEntries - 1));
+        if (lane < kEntries) {
+          t.ctl[kCtlSpec + kEntries * t.w + lane] = x;
         }
       }
-    } else if (lane == 0) {
-      t.ctl[kCtlSpec + t.w] = kUnknownExit;
+    } else if (lane < kEntries) {
+      t.ctl[kCtlSpec + kEntries * t.w + lane] = kUnknownExit;
     }
   };
   if (q < st.vend) {
@@ -353,8 +360,19 @@ __device__ __forceinline__ uint32_t decode_chunk(
     LZT_TR("w%u step q=%u op=%u\n", t.w, q, op);
     const uint32_t wb = q + FrontEnd::kPositions * t.w;
     const bool have_window = wb < st.vend;
-    /* ---- 2. entry = the exit speculated by the window in front; enumerate, parse, sizes ---- */
-    const uint32_t entry = t.w == 0 ? q : ctl_read(t, kCtlSpec + t.w - 1);
+    /* ---- 2. the entry of this wave's window, through the tabulated exits of the windows in front; enumerate, parse, sizes.
+     * An entry at one of a window's first kEntries offsets has its exit in the table -- exact; one further in (a token
+     * with a long literal run reached over from the window before) borrows offset 0's exit: chains merge within a few
+     * tokens, and step 3 compares what every window was entered by with the true exit of the window in front. (One exit
+     * per window, speculated from offset 0, was wrong for 2.2 % of the windows of text: a step of 16 windows in four
+     * was cut short.) */
+    uint32_t entry = q;
+    for (uint32_t j = 0; j < t.w && entry != kUnknownExit; ++j) {
+      const uint32_t off = entry - (q + FrontEnd::kPositions * j);
+      if (off < FrontEnd::kPositions) { /* (else the chain jumps over window j altogether) */
+        entry = ctl_read(t, kCtlSpec + kEntries * j + (off < kEntries ? off : 0u));
+      }
+    }
     uint32_t n = 0;
     uint32_t my_exit = entry;
     uint32_t seqpos = 0;
@@ -374,6 +392,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
     LZW_T(3);
     LZT_TR("w%u B entry=%u n=%u exit=%u total=%u\n", t.w, entry, n, my_exit, total);
     if (lane == 0) {
+      t.ctl[kCtlUsed + t.w] = entry;
       t.ctl[kCtlExit + t.w] = my_exit;
       t.ctl[kCtlBytes + t.w] = total;
       t.ctl[kCtlBad + t.w] = bad_lanes ? 1u : 0u;
@@ -385,12 +404,12 @@ __device__ __forceinline__ uint32_t decode_chunk(
      * that window j was entered by */
     uint32_t sp = 0, ex = 0, by = 0, bd = 0;
     if (lane < kWaves) {
-      sp = t.ctl[kCtlSpec + lane];
+      sp = lane + 1 < kWaves ? t.ctl[kCtlUsed + lane + 1] : 0u; /* what the window behind was entered by */
       ex = t.ctl[kCtlExit + lane];
       by = t.ctl[kCtlBytes + lane];
       bd = t.ctl[kCtlBad + lane];
     }
-    /* window j + 1 stands iff window j stands and exit[j] == spec[j] (what j + 1 entered by) */
+    /* window j + 1 stands iff window j stands and its true exit is what j + 1 was entered by */
     const uint64_t chain_ok = wave::ballot(lane < kWaves && (lane + 1 == kWaves || ex == sp));
     const uint32_t broken = wave::ctz64(~chain_ok);            /* first window whose exit was not the speculated one */
     const uint32_t standing = broken + 1 < kWaves ? broken + 1 : kWaves; /* windows 0 .. standing - 1 stand */
