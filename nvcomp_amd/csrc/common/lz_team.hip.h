@@ -367,10 +367,19 @@ __device__ __forceinline__ uint32_t decode_chunk(
      * per window, speculated from offset 0, was wrong for 2.2 % of the windows of text: a step of 16 windows in four
      * was cut short.) */
     uint32_t entry = q;
-    for (uint32_t j = 0; j < t.w && entry != kUnknownExit; ++j) {
-      const uint32_t off = entry - (q + FrontEnd::kPositions * j);
-      if (off < FrontEnd::kPositions) { /* (else the chain jumps over window j altogether) */
-        entry = ctl_read(t, kCtlSpec + kEntries * j + (off < kEntries ? off : 0u));
+    if (t.w != 0) {
+      /* the whole table in registers (four words a lane), the walk with v_readlane: a dependent LDS round trip per window
+       * in front made the last wave of sixteen wait 3 000 cycles for its entry */
+      const wave::u32x4 sp4 = *(const wave::u32x4*)(t.ctl + kCtlSpec + 4 * lane);
+      for (uint32_t j = 0; j < t.w && entry != kUnknownExit; ++j) {
+        const uint32_t off = entry - (q + FrontEnd::kPositions * j);
+        if (off < FrontEnd::kPositions) { /* (else the chain jumps over window j altogether) */
+          const uint32_t o = off < kEntries ? off : 0u;
+          const uint32_t from = (kEntries * j + o) >> 2;
+          const uint32_t x0 = wave::read_lane(sp4.x, from), x1 = wave::read_lane(sp4.y, from);
+          const uint32_t x2 = wave::read_lane(sp4.z, from), x3 = wave::read_lane(sp4.w, from);
+          entry = (o & 2u) ? ((o & 1u) ? x3 : x2) : ((o & 1u) ? x1 : x0);
+        }
       }
     }
     uint32_t n = 0;
@@ -583,6 +592,8 @@ __device__ __forceinline__ uint32_t decode_chunk(
       const bool mine = wave::lane_in(pending);
       bool go = mine && in_track && (cnt_read4(t.cnt, sa) & cmask) == cself;
       uint64_t gone = wave::ballot(go);
+      /* (looking again a few times before working out the frontier -- two LDS reads and a ballot a look -- was measured
+       * SLOWER: 72 -> 66 GB/s at 256 chunks; the polls compete with the waves that do the copying) */
       LZW_T(9);
       if (!gone) {
         const uint32_t f = wave::ctz64(pending);

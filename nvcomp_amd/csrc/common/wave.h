@@ -322,6 +322,11 @@ __device__ __forceinline__ void nap()
 {
   __builtin_amdgcn_s_sleep(4);
 }
+/* ... for 64 cycles */
+__device__ __forceinline__ void nap_short()
+{
+  __builtin_amdgcn_s_sleep(1);
+}
 
 /* Trailing-zero / popcount helpers on ballots. */
 __device__ __forceinline__ uint32_t ctz64(uint64_t m)

@@ -202,7 +202,8 @@ inline void lds_store_release(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p 
 inline uint32_t lds_load_acquire(const uint32_t* p) { return *(const volatile uint32_t*)p; }
 inline void lds_store_relaxed(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }
 inline uint32_t lds_load_relaxed(const uint32_t* p) { return *(const volatile uint32_t*)p; }
-inline void nap() { sync(); } /* a rendezvous is where the coroutine scheduler lets the other wave run */
+inline void nap() { sync(); }
+inline void nap_short() { sync(); } /* a rendezvous is where the coroutine scheduler lets the other wave run */
 
 inline uint32_t ctz64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
 inline uint32_t popc64(uint64_t m) { return (uint32_t)__builtin_popcountll(m); }
