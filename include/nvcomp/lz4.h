@@ -102,8 +102,9 @@ nvcompStatus_t nvcompBatchedLZ4DecompressGetTempSizeEx(
 /* reference call site: benchmarks/benchmark_template_chunked.cuh:520-530 ;
  * examples/lz4_cpu_compression.cu:121-131 ; doc/lowlevel_c_quickstart.md:127-140.
  * device_actual_uncompressed_bytes and device_statuses may each be NULL;
- * with device_statuses == NULL no per-chunk bounds checking is performed: pass NULL for TRUSTED streams only (a
- * corrupt stream may then write past its output slot; sequences of 4 KiB and more are checked either way).
+ * with device_statuses == NULL nobody is told which chunks failed (a failed chunk still reads 0 in
+ * device_actual_uncompressed_bytes); bounds are checked either way -- no stream, however corrupt, writes past its
+ * output slot (the reference skips the checks with NULL statuses; here the checked kernels are the faster ones).
  *
  * device_temp_ptr holds working state of the launch (the persistent waves' chunk counter): ONE TEMP BUFFER PER
  * IN-FLIGHT CALL. Two *Async calls that may overlap -- on different streams, or from different host threads -- must
