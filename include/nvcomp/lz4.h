@@ -104,7 +104,7 @@ nvcompStatus_t nvcompBatchedLZ4DecompressGetTempSizeEx(
  * device_actual_uncompressed_bytes and device_statuses may each be NULL;
  * with device_statuses == NULL nobody is told which chunks failed (a failed chunk still reads 0 in
  * device_actual_uncompressed_bytes); bounds are checked either way -- no stream, however corrupt, writes past its
- * output slot (the reference skips the checks with NULL statuses; here the checked kernels are the faster ones).
+ * output slot (the reference skips the checks with NULL statuses; here skipping them bought nothing measurable).
  *
  * device_temp_ptr holds working state of the launch (the persistent waves' chunk counter): ONE TEMP BUFFER PER
  * IN-FLIGHT CALL. Two *Async calls that may overlap -- on different streams, or from different host threads -- must

@@ -180,7 +180,10 @@ __global__ void __launch_bounds__(256, NVCOMP_CASC_DEC_WGS) cascaded_decompress_
     uint32_t team) /* 1: the workgroup's waves share ONE chunk; 0: a chunk per wave */
 {
   WAVE_DYNAMIC_LDS(lds);
-  __shared__ uint32_t verdict[2]; /* err bits of the chunk's waves | any wave deferred */
+  /* team: err bits of the chunk's waves | any wave deferred, BEHIND the waves' slices (the launch adds 16 bytes for them: as
+   * a static array they cost the chunk-per-wave launch its eighth workgroup per CU -- 8 x (4 x 5 KiB + 16 B) > 160 KiB --
+   * and 8 % of its speed) */
+  uint32_t* verdict = (uint32_t*)(lds + (size_t)waves_per_block * lds_per_wave);
   const uint32_t wv = wave::uniform(threadIdx.x >> 6);
   const size_t chunk = team ? (size_t)blockIdx.x : (size_t)blockIdx.x * waves_per_block + wv;
   if (chunk >= batch_size) {
@@ -311,8 +314,8 @@ __global__ void __launch_bounds__(256, NVCOMP_CASC_DEC_WGS) cascaded_decompress_
   } while (false);
   if (team) {
     if (lane == 0 && (err || deferred)) {
-      atomicOr(&verdict[0], err);
-      atomicOr(&verdict[1], deferred ? 1u : 0u);
+      atomicOr(verdict + 0, err);
+      atomicOr(verdict + 1, deferred ? 1u : 0u);
     }
     __syncthreads();
   }
@@ -488,11 +491,12 @@ nvcompStatus_t nvcompBatchedCascadedDecompressAsync(
   clear_stale_error();
   const uint32_t team = batch_size <= kDecTeamMaxBatch ? 1u : 0u;
   const dim3 grid4(team ? (unsigned)batch_size : (unsigned)((batch_size + 3) / 4));
-  hipLaunchKernelGGL(cascaded_decompress_kernel, grid4, dim3(256), 4 * kDecSmallBudget,
+  const unsigned extra = team ? 16u : 0u; /* the team's two verdict words */
+  hipLaunchKernelGGL(cascaded_decompress_kernel, grid4, dim3(256), 4 * kDecSmallBudget + extra,
                      stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
                      device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 0u,
                      kDecSmallBudget, 4u, team);
-  hipLaunchKernelGGL(cascaded_decompress_kernel, grid4, dim3(256), 4 * kFastBudget,
+  hipLaunchKernelGGL(cascaded_decompress_kernel, grid4, dim3(256), 4 * kFastBudget + extra,
                      stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
                      device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 1u,
                      kFastBudget, 4u, team);

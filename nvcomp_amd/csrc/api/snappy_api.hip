@@ -299,10 +299,11 @@ nvcompStatus_t nvcompBatchedSnappyDecompressAsync(
     return nvcompErrorInvalidValue;
   }
   clear_stale_error();
-  /* Bounds are checked whether or not the caller asked for statuses (round 4): the kernels without the checks measured
-   * 1-3 % SLOWER than the ones with them (675 against 655-668 GB/s on the headline batch -- register allocation, not
-   * work), and a corrupt stream decoded with statuses == NULL could write past its output slot. A NULL status array now
-   * only means that nobody is told: a failed chunk still reads 0 in device_actual_uncompressed_bytes. */
+  /* Bounds are checked whether or not the caller asked for statuses (round 4): the kernels without the checks were no
+   * faster (655-668 against 675 GB/s on the headline batch over three evidence runs: the checks are a handful of
+   * wave-uniform tests per batch), and a corrupt stream decoded with statuses == NULL could write past its output slot.
+   * A NULL status array now only means that nobody is told: a failed chunk still reads 0 in
+   * device_actual_uncompressed_bytes. */
   (void)device_statuses; /* (only the kernels look at it) */
   const lzl::Batch b = {device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
                         device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, (int*)device_statuses};
