@@ -165,6 +165,7 @@ __global__ void __launch_bounds__(256, NVCOMP_CASC_COMP_WGS) cascaded_compress_k
  * waves' verdicts (error, "needs the next pass") meet in two LDS words. Large batches keep a chunk per wave: with the
  * card full, four waves each paying a chunk's header round trips for four sub-chunks are slower than one paying them for
  * sixteen (16 384 chunks: 1 426 against 1 673; profiles/r04_cascaded_ab.jsonl). */
+template <bool team> /* true: the workgroup's waves share ONE chunk; false: a chunk per wave */
 __global__ void __launch_bounds__(256, NVCOMP_CASC_DEC_WGS) cascaded_decompress_kernel(
     const void* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes,
@@ -176,8 +177,7 @@ __global__ void __launch_bounds__(256, NVCOMP_CASC_DEC_WGS) cascaded_decompress_
     uint32_t* todo,
     uint32_t pass,
     uint32_t lds_per_wave,
-    uint32_t waves_per_block,
-    uint32_t team) /* 1: the workgroup's waves share ONE chunk; 0: a chunk per wave */
+    uint32_t waves_per_block)
 {
   WAVE_DYNAMIC_LDS(lds);
   /* team: err bits of the chunk's waves | any wave deferred, BEHIND the waves' slices (the launch adds 16 bytes for them: as
@@ -489,21 +489,32 @@ nvcompStatus_t nvcompBatchedCascadedDecompressAsync(
   }
   uint32_t* todo = (uint32_t*)device_temp_ptr;
   clear_stale_error();
-  const uint32_t team = batch_size <= kDecTeamMaxBatch ? 1u : 0u;
-  const dim3 grid4(team ? (unsigned)batch_size : (unsigned)((batch_size + 3) / 4));
-  const unsigned extra = team ? 16u : 0u; /* the team's two verdict words */
-  hipLaunchKernelGGL(cascaded_decompress_kernel, grid4, dim3(256), 4 * kDecSmallBudget + extra,
-                     stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
-                     device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 0u,
-                     kDecSmallBudget, 4u, team);
-  hipLaunchKernelGGL(cascaded_decompress_kernel, grid4, dim3(256), 4 * kFastBudget + extra,
-                     stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
-                     device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 1u,
-                     kFastBudget, 4u, team);
-  hipLaunchKernelGGL(cascaded_decompress_kernel, dim3((unsigned)batch_size), dim3(64), kBigBudget, stream,
+  if (batch_size <= kDecTeamMaxBatch) {
+    const dim3 grid((unsigned)batch_size);
+    const unsigned extra = 16; /* the team's two verdict words */
+    hipLaunchKernelGGL(cascaded_decompress_kernel<true>, grid, dim3(256), 4 * kDecSmallBudget + extra,
+                       stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
+                       device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 0u,
+                       kDecSmallBudget, 4u);
+    hipLaunchKernelGGL(cascaded_decompress_kernel<true>, grid, dim3(256), 4 * kFastBudget + extra,
+                       stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
+                       device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 1u,
+                       kFastBudget, 4u);
+  } else {
+    const dim3 grid((unsigned)((batch_size + 3) / 4));
+    hipLaunchKernelGGL(cascaded_decompress_kernel<false>, grid, dim3(256), 4 * kDecSmallBudget,
+                       stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
+                       device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 0u,
+                       kDecSmallBudget, 4u);
+    hipLaunchKernelGGL(cascaded_decompress_kernel<false>, grid, dim3(256), 4 * kFastBudget,
+                       stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
+                       device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 1u,
+                       kFastBudget, 4u);
+  }
+  hipLaunchKernelGGL(cascaded_decompress_kernel<false>, dim3((unsigned)batch_size), dim3(64), kBigBudget, stream,
                      device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
                      device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 2u,
-                     kBigBudget, 1u, 0u);
+                     kBigBudget, 1u);
   return launch_status();
 }
 
