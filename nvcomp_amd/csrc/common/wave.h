@@ -53,6 +53,28 @@ __device__ __forceinline__ u32x4 gload_u32x4(const uint8_t* p) /* any alignment 
   u32x4 r = {q->v[0], q->v[1], q->v[2], q->v[3]};
   return r;
 }
+/* Non-temporal loads whose data is NOT waited for by the compiler: the caller issues them, does other work, and calls
+ * wait_vm() on the registers before their first use (an inline-asm load is invisible to the compiler's s_waitcnt
+ * insertion, which is the point: the wait goes where the algorithm wants it; and `nt` cannot be had otherwise for an
+ * unaligned 16-byte access -- __builtin_nontemporal_load splits it into dwords). The registers must not be touched in
+ * between (the ISA of every user is checked for that: scripts/check_nt_loads.sh). */
+__device__ __forceinline__ u32x4 gload_u32x4_nt_async(const uint8_t* p)
+{
+  u32x4 r;
+  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(r) : "v"((const WAVE_GLOBAL uint8_t*)p) : "memory");
+  return r;
+}
+__device__ __forceinline__ uint32_t gload_u32_nt_async(const uint8_t* p)
+{
+  uint32_t r;
+  asm volatile("global_load_dword %0, %1, off nt" : "=v"(r) : "v"((const WAVE_GLOBAL uint8_t*)p) : "memory");
+  return r;
+}
+__device__ __forceinline__ void wait_vm(u32x4& a, u32x4& b, uint32_t& c)
+{
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c) : : "memory");
+}
+
 __device__ __forceinline__ uint64_t gload_u64(const uint8_t* p) /* any alignment (global_load_dwordx2) */
 {
   const WAVE_GLOBAL PackedU32x2* q = (const WAVE_GLOBAL PackedU32x2*)p;
