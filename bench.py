@@ -570,8 +570,8 @@ def deflate_cpu_baseline(oracle, comp, chunks, threads, unique):
 def lz_decode_kernel(algo, chunks):
     """The kernel nvcompBatched{LZ4,Snappy}DecompressAsync launches for a batch of this size (compile-time thresholds of
     common/lz_launch.hip.h: a workgroup per chunk / two waves per chunk / persistent waves)."""
-    if algo == "lz4" and chunks <= 512:
-        return "lz4_decompress_team_kernel"
+    if chunks <= 512:  # NVCOMP_LZ_TEAM_MAX_BATCH (tests/test_abi.py keeps the two in step)
+        return f"{algo}_decompress_team_kernel"
     return f"{algo}_decompress_pair_kernel" if chunks <= 3072 else f"{algo}_decompress_window_kernel"
 
 

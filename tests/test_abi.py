@@ -149,3 +149,22 @@ def test_cmake_package_exports_nvcomp_target(tmp_path):
     subprocess.run(["cmake", "--build", str(build)], check=True, capture_output=True)
     out = subprocess.run([str(build / "consumer")], check=True, capture_output=True, text=True).stdout
     assert "LZ4 bound for 64 KiB = 65809" in out
+
+
+def test_bench_names_the_kernel_the_library_launches():
+    """bench.py's `roofline.kernel` (and the PMC traffic records keyed by it) name the kernel by batch size; the
+    thresholds live in common/lz_launch.hip.h as compile-time constants -- the two must not drift apart."""
+    import re
+    import sys
+
+    sys.path.insert(0, REPO)
+    import bench
+
+    src = open(os.path.join(REPO, "nvcomp_amd", "csrc", "common", "lz_launch.hip.h")).read()
+    team = int(re.search(r"#define NVCOMP_LZ_TEAM_MAX_BATCH (\d+)", src).group(1))
+    pair = int(re.search(r"#define NVCOMP_LZ_PAIR_MAX_BATCH (\d+)", src).group(1))
+    for algo in ("lz4", "snappy"):
+        assert bench.lz_decode_kernel(algo, team) == f"{algo}_decompress_team_kernel"
+        assert bench.lz_decode_kernel(algo, team + 1) == f"{algo}_decompress_pair_kernel"
+        assert bench.lz_decode_kernel(algo, pair) == f"{algo}_decompress_pair_kernel"
+        assert bench.lz_decode_kernel(algo, pair + 1) == f"{algo}_decompress_window_kernel"
