@@ -572,7 +572,7 @@ def lz_decode_kernel(algo, chunks):
     common/lz_launch.hip.h: a workgroup per chunk / two waves per chunk / persistent waves)."""
     if chunks <= 512:  # NVCOMP_LZ_TEAM_MAX_BATCH (tests/test_abi.py keeps the two in step)
         return f"{algo}_decompress_team_kernel"
-    return f"{algo}_decompress_pair_kernel" if chunks <= 3072 else f"{algo}_decompress_window_kernel"
+    return f"{algo}_decompress_pair_kernel" if chunks <= 4096 else f"{algo}_decompress_window_kernel"
 
 
 def replayed_traffic(algo, kind, dataset, chunks):

@@ -26,7 +26,8 @@
 #include "common/wave.h"
 
 #ifndef NVCOMP_LZ_PAIR_MAX_BATCH
-#define NVCOMP_LZ_PAIR_MAX_BATCH 3072 /* profiles/r02_pair_decode.json: two waves per chunk win up to ~3 000 chunks */
+#define NVCOMP_LZ_PAIR_MAX_BATCH 4096 /* two waves per chunk up to here: 319 against 310 GB/s at 4 096 chunks since the pair kernels lost their scratch
+                                        * (round 4, profiles/r04_final_nsweep.jsonl; 3 072 before); 412 against 454 at 8 192 */
 #endif
 #ifndef NVCOMP_LZ_TEAM_MAX_BATCH
 #define NVCOMP_LZ_TEAM_MAX_BATCH 512 /* a WORKGROUP per chunk up to this many chunks (common/lz_team.hip.h): 263 us per chunk against 467 (two waves) and 677 (one); from 1 024 chunks on two waves per chunk keep more chunks in flight (profiles/r04_team.jsonl) */

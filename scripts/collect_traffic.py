@@ -21,7 +21,7 @@ KERNELS = {
     "lz4_mortgage": [("lz4_decompress_window_kernel", "lz4", "decompress")],
     # the batch-size riders of the driver's line and the unchecked fast path
     "lz4_16384": [("lz4_decompress_window_kernel", "lz4", "decompress")],
-    "lz4_4096": [("lz4_decompress_window_kernel", "lz4", "decompress")],
+    "lz4_4096": [("lz4_decompress_pair_kernel", "lz4", "decompress")],
     "lz4_256": [("lz4_decompress_team_kernel", "lz4", "decompress")],
     "lz4_unchecked": [("lz4_decompress_window_kernel", "lz4", "decompress_unchecked")],
     # the other codecs' own bench lines (python bench.py --algo X at its default size)
