@@ -4,6 +4,7 @@ data and chunk sizes that are not multiples of anything."""
 import numpy as np
 import pytest
 
+from nvcomp_amd import datasets
 from nvcomp_amd._lib import NvcompStatus
 
 
@@ -55,3 +56,34 @@ def test_fuzz_structures(backend, lz_path, oracle, fmt, seed):
         rc, ref = dec(cc, c.size)
         assert rc == 0 and np.array_equal(ref, c)
         assert np.array_equal(o, c), f"chunk {i} (size {c.size}) differs at {int(np.argmax(o != c))}"
+
+
+@pytest.mark.parametrize("fmt", ["LZ4", "Snappy"])
+def test_random_ragged_batches(backend, oracle, fmt):
+    """Batches of random size around the launch-shape thresholds of common/lz_launch.hip.h (sixteen-wave teams up to 256
+    chunks, eight-wave teams up to 512, two waves per chunk above), chunks of random length, data class, compression level
+    and alignment: every byte, size and status as the CPU library has them. (The emulator takes a handful of small
+    batches, the GPU thirty of up to 600 chunks.)"""
+    if not oracle.have_ref():
+        pytest.skip("needs liblz4 / libsnappy (oracle/_ref)")
+    rng = np.random.default_rng(11)
+    gpu = backend.name == "gpu"
+    names = sorted(datasets.CLASSES)
+    codec = backend.codec(fmt)
+    for it in range(30 if gpu else 3):
+        n = int(rng.integers(1, 600)) if gpu else int(rng.integers(1, 6))
+        chunks = []
+        for _ in range(n):
+            size = int(rng.integers(1, 65537 if gpu else 6000))
+            d = datasets.CLASSES[names[int(rng.integers(0, len(names)))]](size, int(rng.integers(0, 1000)))
+            chunks.append(np.frombuffer(d.tobytes(), dtype=np.uint8)[:size].copy())
+        if fmt == "LZ4":
+            comp = [oracle.ref_lz4_compress(c, int(rng.integers(0, 13))) for c in chunks]
+        else:
+            comp = [oracle.ref_snappy_compress(c) for c in chunks]
+        outs, act, st = codec.decompress(comp, [c.size for c in chunks], comp_align=int(rng.integers(1, 9)),
+                                         out_align=int(rng.integers(1, 9)))
+        assert (st == 0).all(), (it, n)
+        assert act.tolist() == [c.size for c in chunks]
+        for i, (o, c) in enumerate(zip(outs, chunks)):
+            assert np.array_equal(o, c), (it, n, i)
