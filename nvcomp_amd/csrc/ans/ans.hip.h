@@ -103,7 +103,7 @@ __device__ __forceinline__ void write_header(uint8_t* dst, uint32_t n, uint32_t 
 
 __device__ __forceinline__ uint32_t store_raw(const uint8_t* __restrict__ src, uint32_t n, uint8_t* __restrict__ dst)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   if (lane == 0) {
     write_header(dst, n, 0);
   }
@@ -119,7 +119,7 @@ __device__ __forceinline__ uint32_t store_raw(const uint8_t* __restrict__ src, u
  * frequent symbol (lowest index on ties), repeatedly if it cannot absorb all of it. */
 __device__ __forceinline__ void normalise(const uint32_t c[4], uint32_t n, uint32_t f[4])
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   uint32_t sum = 0;
 #pragma unroll
   for (uint32_t j = 0; j < 4; ++j) {
@@ -175,7 +175,7 @@ __device__ __forceinline__ void cumulate(const uint32_t f[4], uint32_t start[4])
 __device__ __forceinline__ uint32_t encode_chunk(
     const uint8_t* __restrict__ src, uint32_t n, uint8_t* __restrict__ dst, uint8_t* lds)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   if (n < kMinCodedBytes) {
     return store_raw(src, n, dst);
   }
@@ -307,7 +307,7 @@ struct WordRing
 /* Keep [p - 64, p) resident, fetching 128-word blocks well ahead of their use. */
 __device__ __forceinline__ void ring_fill(WordRing& w, uint32_t p)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   bool loaded = false;
   if (w.lo > 0 && p < w.lo + 320) {
     wave::sync(); /* every lane has taken its words of the last row: a refill may reuse slots just above p */
@@ -333,7 +333,7 @@ __device__ __forceinline__ void ring_fill(WordRing& w, uint32_t p)
 __device__ __forceinline__ uint32_t decode_chunk(
     const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* __restrict__ out, uint32_t out_cap, uint8_t* lds, uint32_t& err)
 {
-  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   err = kErrNone;
   if (in_len < kHeaderBytes) {
     err = kErrInput;
