@@ -168,8 +168,12 @@ __global__ void __launch_bounds__(64 * WAVES, 4) lz4_decompress_team_kernel(cons
     } else {
       produced = lzt::decode_chunk<lz4w::TeamFrontEnd, WAVES>(
           in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err,
-          [](const uint8_t* i, uint32_t n, uint8_t* o, uint32_t cap, uint8_t* scratch, uint32_t& e) {
-            return lz4w::decode_chunk<true>(i, n, o, cap, scratch, e);
+          [](uint32_t role, const uint8_t* i, uint32_t n, uint8_t* o, uint32_t cap, uint8_t* scratch, uint32_t& e) -> uint32_t {
+            if (role == 0) {
+              lz4w::pair::produce(i, n, scratch);
+              return 0u;
+            }
+            return lz4w::pair::consume<true>(i, n, o, cap, scratch, e);
           });
     }
     a = wave::kernel_args(launch);

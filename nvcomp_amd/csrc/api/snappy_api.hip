@@ -108,8 +108,12 @@ __global__ void __launch_bounds__(64 * WAVES, 4) snappy_decompress_team_kernel(c
     } else {
       produced = lzt::decode_chunk<snappyw::TeamFrontEnd, WAVES>(
           in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err,
-          [](const uint8_t* i, uint32_t n, uint8_t* o, uint32_t cap, uint8_t* scratch, uint32_t& e) {
-            return snappyw::decode_chunk<true>(i, n, o, cap, scratch, e);
+          [](uint32_t role, const uint8_t* i, uint32_t n, uint8_t* o, uint32_t cap, uint8_t* scratch, uint32_t& e) -> uint32_t {
+            if (role == 0) {
+              snappyw::pair::produce<true>(i, n, scratch);
+              return 0u;
+            }
+            return snappyw::pair::consume<true>(i, n, o, cap, scratch, e);
           });
     }
     a = wave::kernel_args(launch);

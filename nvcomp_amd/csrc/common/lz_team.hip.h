@@ -11,7 +11,7 @@
  *   buffer   the chunk's whole OUTPUT (up to 64 KiB) lives in LDS, and so does its whole compressed STREAM, right-aligned
  *            behind it in the same buffer ("in place": a decoder's write position never passes its read position by more
  *            than the format's overhead, kMargin covers it; checked every step, a stream that breaks it -- or a chunk
- *            that does not fit -- is decoded by wave 0 with the one-wave decoder). Every match is an LDS -> LDS copy:
+ *            that does not fit -- is decoded by waves 0 and 1 with the two-wave decoder). Every match is an LDS -> LDS copy:
  *            no far-match gathers, HBM traffic = stream in + output out.
  *   step     per step the eight waves look at eight consecutive windows of kPositions stream positions, one each:
  *              1. every wave builds the jump tables of its window (lzw::chase_build: they do not depend on where the
@@ -67,7 +67,7 @@ struct Geo
   static constexpr uint32_t kWaves = WAVES;
   static constexpr uint32_t kThreads = 64 * WAVES;
   static constexpr uint32_t kLds = kBufLds + WAVES * lzw::kChaseLds + kCntLds + 4 * kCtlWords;
-  static_assert(WAVES * lzw::kChaseLds >= lzw::kLdsPerWave, "the fallback decoder's scratch is the table area");
+  static_assert(WAVES * lzw::kChaseLds >= lzw::pair::kLdsPerChunk, "the fallback decoder's scratch is the table area");
   static_assert(kLds <= (WAVES == 8 ? 81920u : 163840u), "two workgroups of 8 waves per CU, or one of 16");
 };
 
@@ -260,6 +260,32 @@ __device__ __forceinline__ uint32_t cnt_read4(const uint32_t* cnt, uint32_t g)
   return wave::align_bytes(b, a, g & 3u);
 }
 
+/* A chunk that is not a team's (more than 64 KiB of capacity or stream, or a stream that breaks the in-place invariant):
+ * waves 0 and 1 decode it as producer and consumer (lz4_decode_window.hip.h: pair) in the table area, the others wait.
+ * `fallback(role, ...)`: role 0 produces, role 1 consumes and returns the bytes produced. */
+template <class Fallback>
+__device__ __forceinline__ uint32_t run_fallback(
+    const Team& t, uint8_t* scratch, const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_cap, uint32_t& err, Fallback fallback)
+{
+  if (threadIdx.x < 4) {
+    ((uint32_t*)(scratch + lzw::pair::kLdsPerChunk - lzw::pair::kCtrlBytes))[threadIdx.x] = 0; /* both slots empty, no abort */
+  }
+  __syncthreads();
+  if (t.w < 2) {
+    uint32_t e = lz::kErrNone;
+    const uint32_t produced = fallback(t.w, in, in_len, out, out_cap, scratch, e);
+    if (t.w == 1 && wave::lane_id() == 0) {
+      t.ctl[kCtlErr] = e;
+      t.ctl[kCtlTicket] = produced;
+    }
+  }
+  __syncthreads();
+  err = ctl_read(t, kCtlErr);
+  const uint32_t produced = ctl_read(t, kCtlTicket);
+  __syncthreads();
+  return produced;
+}
+
 /*
  * Decode one chunk with the calling workgroup (64 x WAVES lanes, all of them call). `lds` = Geo<WAVES>::kLds bytes, 16-byte aligned.
  * FrontEnd supplies the format: kPositions, DeltaFn / SlowFn (the chase's distance functions) and parse_batch().
@@ -287,20 +313,8 @@ __device__ __forceinline__ uint32_t decode_chunk(
   }
   uint8_t* fb_scratch = lds + kBufLds;
   if (out_cap > kMaxOut || in_len > kMaxIn) {
-    /* not a team's chunk: the one-wave decoder, by wave 0 */
-    uint32_t produced = 0;
-    if (t.w == 0) {
-      produced = fallback(in, in_len, out, out_cap, fb_scratch, err);
-      if (lane == 0) {
-        t.ctl[kCtlErr] = err;
-        t.ctl[kCtlTicket] = produced;
-      }
-    }
-    __syncthreads();
-    err = ctl_read(t, kCtlErr);
-    produced = ctl_read(t, kCtlTicket);
-    __syncthreads();
-    return produced;
+    /* not a team's chunk: the two-waves-per-chunk decoder, by waves 0 and 1 */
+    return run_fallback(t, fb_scratch, in, in_len, out, out_cap, err, fallback);
   }
   const uint32_t ia = (uint32_t)((uintptr_t)in & 15u);
   t.st.base = in - ia;
@@ -331,7 +345,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
   }
   uint32_t op = 0;      /* output produced (all of it final) */
   uint32_t flushed = 0; /* output written to HBM */
-  bool give_up = false; /* in-place invariant broken: the one-wave decoder redoes the chunk */
+  bool give_up = false; /* in-place invariant broken: waves 0 and 1 redo the chunk as producer and consumer */
   typename FrontEnd::Delta delta;
   typename FrontEnd::Slow slow;
   /* ---- 1. tables of this wave's window of the step that starts at q_, speculated exit ---- */
@@ -700,19 +714,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
   /* every wave leaves the loop at the same point (the conditions are uniform across the team) */
   __syncthreads();
   if (give_up) {
-    uint32_t produced = 0;
-    if (t.w == 0) {
-      produced = fallback(in, in_len, out, out_cap, fb_scratch, err);
-      if (lane == 0) {
-        t.ctl[kCtlErr] = err;
-        t.ctl[kCtlTicket] = produced;
-      }
-    }
-    __syncthreads();
-    err = ctl_read(t, kCtlErr);
-    produced = ctl_read(t, kCtlTicket);
-    __syncthreads();
-    return produced;
+    return run_fallback(t, fb_scratch, in, in_len, out, out_cap, err, fallback);
   }
   if (err) {
     return 0;
