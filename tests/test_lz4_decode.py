@@ -241,7 +241,8 @@ def test_stream_ends_on_ring_block_boundaries(backend, lz_path, oracle):
             seqs[-1] = (lit + b"x", off, mlen)
         raise AssertionError("no tail length fits")
 
-    for mis in (0, 1, 7, 15):
+    # (the emulated workgroup-per-chunk path has no ring and costs 16 x the coroutines: two of the four misalignments)
+    for mis in ((0, 15) if backend.name == "emu" and lz_path in ("default", "team") else (0, 1, 7, 15)):
         blocks, raws = [], []
         for k in (1, 2, 3, 5):
             for delta in (-1, 0, 1):
@@ -300,6 +301,23 @@ def test_batch_of_many_small_chunks(backend, oracle):
     chunks = datasets.split_chunks(data, 384)
     assert len(chunks) >= 8192
     check_roundtrip(backend, oracle, chunks, cpu_compress(oracle, chunks))
+
+
+@pytest.mark.parametrize("fmt", ["LZ4", "Snappy"])
+def test_persistent_workgroups(backend, oracle, fmt):
+    """300 small chunks: the eight-wave workgroup-per-chunk launch (257 ... 512 chunks), persistent -- more chunks than
+    workgroups stay resident (two on the emulator's one-CU card), the rest drawn from the ticket counter in the temp
+    buffer: every chunk decoded exactly once."""
+    data = datasets.silesia_style(300 * 160, 5)
+    chunks = datasets.split_chunks(data, 160)
+    assert 256 < len(chunks) <= 512
+    if fmt == "LZ4":
+        check_roundtrip(backend, oracle, chunks, cpu_compress(oracle, chunks))
+    else:
+        comp = [oracle.ref_snappy_compress(c) if oracle.have_ref() else oracle.snappy_compress(c) for c in chunks]
+        outs, actual, status = backend.codec("Snappy").decompress(comp, [c.size for c in chunks])
+        assert (status == NvcompStatus.Success).all() and actual.tolist() == [c.size for c in chunks]
+        assert all(np.array_equal(o, c) for o, c in zip(outs, chunks))
 
 
 def test_get_decompress_size(backend, oracle):
