@@ -6,6 +6,39 @@
 
 #include <ucontext.h>
 
+/* Context switches are what this harness does (64 per cross-lane operation, 512-1 024 lanes in a workgroup-per-chunk launch),
+ * and glibc's swapcontext saves and restores the signal mask with two system calls a switch: a third of the CPU test tier
+ * was spent in the kernel. On x86-64 (and outside sanitizer builds, which want to see ucontext) the switch is six pushes,
+ * a stack swap and six pops. */
+#if defined(__x86_64__) && !defined(__SANITIZE_ADDRESS__) && !defined(EMU_USE_UCONTEXT)
+#define EMU_FAST_SWITCH 1
+extern "C" void emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size emu_switch,.-emu_switch
+)");
+#else
+#define EMU_FAST_SWITCH 0
+#endif
+
 #include <memory>
 #include <vector>
 
@@ -20,7 +53,11 @@ enum class State { Ready, WaitWave, WaitBlock, Done };
 struct LaneRt
 {
   Lane pub;
+#if EMU_FAST_SWITCH
+  void* sp = nullptr;
+#else
   ucontext_t ctx;
+#endif
   std::unique_ptr<char[]> stack;
   State state = State::Ready;
   int wait_op = 0;
@@ -44,7 +81,11 @@ struct BlockRt
   size_t block_live = 0;
 };
 
+#if EMU_FAST_SWITCH
+void* g_sched_sp = nullptr;
+#else
 ucontext_t g_sched_ctx;
+#endif
 BlockRt* g_block = nullptr;
 LaneRt* g_cur = nullptr;
 dim3 g_bdim, g_gdim;
@@ -59,11 +100,20 @@ uint64_t next_rand()
   return g_rng;
 }
 
+inline void to_scheduler(LaneRt* me)
+{
+#if EMU_FAST_SWITCH
+  emu_switch(&me->sp, g_sched_sp);
+#else
+  swapcontext(&me->ctx, &g_sched_ctx);
+#endif
+}
+
 void lane_entry()
 {
   (*g_body)();
   g_cur->state = State::Done;
-  swapcontext(&g_cur->ctx, &g_sched_ctx);
+  to_scheduler(g_cur);
 }
 
 [[noreturn]] void die(const char* msg)
@@ -110,7 +160,7 @@ void wave_rendezvous(int op_id, uint64_t a, uint64_t b)
   if (w.arrived == w.live) {
     complete_wave(w, *g_block, me->pub.wave);
   }
-  swapcontext(&me->ctx, &g_sched_ctx);
+  to_scheduler(me);
 }
 
 const Contribution& peer(int lane)
@@ -138,7 +188,7 @@ void block_rendezvous()
       }
     }
   }
-  swapcontext(&me->ctx, &g_sched_ctx);
+  to_scheduler(me);
 }
 
 void launch(const std::function<void()>& body, dim3 grid, dim3 block)
@@ -180,11 +230,25 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block)
           l.pub.wave = (int)(t >> 6);
           l.state = State::Ready;
           b.waves[t >> 6].live |= 1ull << (t & 63);
+#if EMU_FAST_SWITCH
+          {
+            /* a fresh stack: six zeroed callee-saved registers, then lane_entry as the address emu_switch returns to (the
+             * stack pointer is 8 modulo 16 there, as after a call) */
+            uintptr_t top = ((uintptr_t)l.stack.get() + kStackBytes) & ~(uintptr_t)15;
+            void** spp = (void**)(top - 8);
+            *--spp = (void*)&lane_entry;
+            for (int r = 0; r < 6; ++r) {
+              *--spp = nullptr;
+            }
+            l.sp = (void*)spp;
+          }
+#else
           getcontext(&l.ctx);
           l.ctx.uc_stack.ss_sp = l.stack.get();
           l.ctx.uc_stack.ss_size = kStackBytes;
           l.ctx.uc_link = nullptr;
           makecontext(&l.ctx, (void (*)())lane_entry, 0);
+#endif
         }
         g_block = &b;
         size_t done = 0;
@@ -204,7 +268,11 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block)
             }
             progressed = true;
             g_cur = &l;
+#if EMU_FAST_SWITCH
+            emu_switch(&g_sched_sp, l.sp);
+#else
             swapcontext(&g_sched_ctx, &l.ctx);
+#endif
             g_cur = nullptr;
             if (l.state == State::Done) {
               ++done;
