@@ -492,6 +492,7 @@ nvcompStatus_t nvcompBatchedCascadedDecompressAsync(
   if (batch_size <= kDecTeamMaxBatch) {
     const dim3 grid((unsigned)batch_size);
     const unsigned extra = 16; /* the team's two verdict words */
+    (void)extra;               /* (the host emulation's launch macro has no LDS size) */
     hipLaunchKernelGGL(cascaded_decompress_kernel<true>, grid, dim3(256), 4 * kDecSmallBudget + extra,
                        stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
                        device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 0u,
