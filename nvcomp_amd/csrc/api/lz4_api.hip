@@ -30,6 +30,14 @@ constexpr unsigned kDecWaves = NVCOMP_LZ_DEC_WAVES_PER_BLOCK;
 #define NVCOMP_LZM_WAVES_PER_BLOCK 4
 #endif
 constexpr unsigned kEncWaves = NVCOMP_LZM_WAVES_PER_BLOCK; /* the compressors' workgroup size */
+/* Untyped data takes the 256-position steps of common/lz_match_wide.hip.h (0: the one-window compressor, A/B build). */
+#ifndef NVCOMP_LZM_WIDE
+#define NVCOMP_LZM_WIDE 1
+#endif
+#ifndef NVCOMP_LZMW_WAVES_PER_BLOCK
+#define NVCOMP_LZMW_WAVES_PER_BLOCK 1
+#endif
+constexpr unsigned kWideWaves = NVCOMP_LZMW_WAVES_PER_BLOCK;
 using lzl::kMaxOutCap;
 
 /* Profiling builds only (wrong output by construction): 1 = stop after the token chase, 2 = after the parse. */
@@ -246,6 +254,35 @@ __global__ void __launch_bounds__(64 * kEncWaves, NVCOMP_LZM_WAVES_PER_SIMD) lz4
     /* a chunk larger than the caller declared would overrun the output slot sized from GetMaxOutputChunkSize: it is
      * not compressed, its size reads 0 */
     const uint32_t produced = n64 > a->max_chunk_bytes ? 0u : lz4::encode_chunk<STRIDE>(src, (uint32_t)n64, dst, tables[w], images[w]);
+    a = wave::kernel_args(launch);
+    if (wave::lane_id() == 0) {
+      a->out_bytes[chunk] = produced;
+    }
+    uint32_t* ticket = a->ticket;
+    if (ticket == nullptr) {
+      break;
+    }
+    chunk = lzl::next_chunk(ticket, a->first_dynamic);
+  }
+}
+
+/* Untyped data: 256-position steps (common/lz_match_wide.hip.h); a wave's LDS is lzm::wide::kLdsPerWave bytes. */
+__global__ void __launch_bounds__(64 * kWideWaves) lz4_compress_wide_kernel(const lzl::CompressLaunch launch)
+{
+  __shared__ uint16_t tables[kWideWaves][lzm::wide::kEntries];
+  __shared__ __attribute__((aligned(16))) uint8_t images[kWideWaves][lzm::wide::kImage];
+  __shared__ __attribute__((aligned(16))) uint8_t scratch[kWideWaves][lzm::wide::kScratch];
+  const uint32_t w = wave::uniform(threadIdx.x >> 6);
+  size_t chunk = (size_t)blockIdx.x * kWideWaves + w;
+  for (;;) {
+    const auto* a = wave::kernel_args(launch);
+    if (chunk >= a->batch_size) {
+      break;
+    }
+    const uint8_t* src = wave::uniform_ptr((const uint8_t*)a->in_ptrs[chunk]);
+    uint8_t* dst = wave::uniform_ptr((uint8_t*)a->out_ptrs[chunk]);
+    const size_t n64 = wave::uniform64(a->in_bytes[chunk]);
+    const uint32_t produced = n64 > a->max_chunk_bytes ? 0u : lz4::encode_chunk_wide(src, (uint32_t)n64, dst, tables[w], images[w], scratch[w]);
     a = wave::kernel_args(launch);
     if (wave::lane_id() == 0) {
       a->out_bytes[chunk] = produced;
@@ -490,14 +527,39 @@ nvcompStatus_t nvcompBatchedLZ4CompressAsync(
                                         (size_t)groups * kEncWaves};                                                      \
     hipLaunchKernelGGL((lz4_compress_kernel<STRIDE>), dim3(groups), dim3(64 * kEncWaves), 0, stream, launch);             \
   } while (0)
+#define NVCOMP_LZ4_COMPRESS_WIDE()                                                                                        \
+  do {                                                                                                                    \
+    unsigned groups = (unsigned)((batch_size + kWideWaves - 1) / kWideWaves);                                             \
+    uint32_t* ticket = nullptr;                                                                                           \
+    if (NVCOMP_LZ_PERSISTENT && device_temp_ptr != nullptr && temp_bytes >= sizeof(uint32_t)                              \
+        && ((uintptr_t)device_temp_ptr & 3u) == 0) {                                                                      \
+      static lzl::ResidentCache resident; /* per device ordinal */                                                      \
+      const unsigned fit = resident.get(lz4_compress_wide_kernel, 64 * kWideWaves, 0);                                   \
+      if (fit != 0 && fit < groups && hipMemsetAsync(device_temp_ptr, 0, sizeof(uint32_t), stream) == hipSuccess) {       \
+        ticket = (uint32_t*)device_temp_ptr;                                                                              \
+        groups = fit;                                                                                                     \
+      }                                                                                                                   \
+    }                                                                                                                     \
+    const lzl::CompressLaunch launch = {device_uncompressed_ptrs, device_uncompressed_bytes, max_uncompressed_chunk_bytes, \
+                                        batch_size, device_compressed_ptrs, device_compressed_bytes, ticket,             \
+                                        (size_t)groups * kWideWaves};                                                     \
+    hipLaunchKernelGGL(lz4_compress_wide_kernel, dim3(groups), dim3(64 * kWideWaves), 0, stream, launch);                 \
+  } while (0)
   switch (format_opts.data_type) {
   case NVCOMP_TYPE_SHORT:
   case NVCOMP_TYPE_USHORT: NVCOMP_LZ4_COMPRESS(2); break;
   case NVCOMP_TYPE_INT:
   case NVCOMP_TYPE_UINT: NVCOMP_LZ4_COMPRESS(4); break;
-  default: NVCOMP_LZ4_COMPRESS(1); break;
+  default:
+#if NVCOMP_LZM_WIDE
+    NVCOMP_LZ4_COMPRESS_WIDE();
+#else
+    NVCOMP_LZ4_COMPRESS(1);
+#endif
+    break;
   }
 #undef NVCOMP_LZ4_COMPRESS
+#undef NVCOMP_LZ4_COMPRESS_WIDE
   return launch_status();
 }
 

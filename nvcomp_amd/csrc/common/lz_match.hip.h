@@ -66,6 +66,18 @@ namespace lzm {
 #ifndef NVCOMP_LZM_LIT_IMAGE
 #define NVCOMP_LZM_LIT_IMAGE 1
 #endif
+/* One step of lazy evaluation in the selection walk. Measured on the mix with the emulator (8 chunks per class, weighted
+ * by the mix's shares; liblz4 LZ4_compress_default on the same chunks: 1.8455): greedy 1.7841, lazy 1.8392 at 3 456
+ * table entries; 1.7998 -> 1.8601 at 4 096; 1.8408 -> 1.9165 at 8 192. Two or four steps add 0.0007; asking for a
+ * margin of one byte loses 0.005. */
+#ifndef NVCOMP_LZM_LAZY
+#define NVCOMP_LZM_LAZY 1
+#endif
+/* Positions inside a selected match are not inserted into the table (A/B: 1.7841 -> 1.7976 greedy, 1.8392 -> 1.8430
+ * lazy at 3 456 entries; worse than inserting everything once the table has 8 192). */
+#ifndef NVCOMP_LZM_INSERT_UNCOVERED
+#define NVCOMP_LZM_INSERT_UNCOVERED 0
+#endif
 #ifndef NVCOMP_LZM_WAVES_PER_SIMD
 #define NVCOMP_LZM_WAVES_PER_SIMD 5 /* what the 8 KiB hash table per wave allows (4-wave workgroups, 160 KB LDS per CU) */
 #endif
@@ -554,17 +566,25 @@ __device__ __forceinline__ uint32_t encode_chunk(
       /* this window's positions go into the table now: the next probe (whose loads may already be under way)
        * sees them, and nothing below reads the table */
       wave::sync();
-      if (eligible) {
-        const uint32_t slot = hash4(word);
-        table[slot] = (uint16_t)pos;
+      auto insert_lanes = [&](bool mine) {
+        if (mine) {
+          const uint32_t slot = hash4(word);
+          table[slot] = (uint16_t)pos;
 #if NVCOMP_LZM_TAGS
-        ((uint8_t*)(table + kHashSize))[slot] = (uint8_t)tag4(word);
+          ((uint8_t*)(table + kHashSize))[slot] = (uint8_t)tag4(word);
 #endif
-      }
-      wave::sync();
+        }
+        wave::sync();
+      };
+#if !NVCOMP_LZM_INSERT_UNCOVERED
+      insert_lanes(eligible);
+#endif
       const uint64_t hits = wave::ballot(pr.found && lane * STRIDE >= skip);
       LZM_T(2); /* table insert */
       if (hits == 0) {
+#if NVCOMP_LZM_INSERT_UNCOVERED
+        insert_lanes(eligible && lane * STRIDE >= skip);
+#endif
         /* no match starts in this window: its positions become literals */
         skip = skip > kWin ? skip - kWin : 0;
         ip += kWin;
@@ -583,6 +603,9 @@ __device__ __forceinline__ uint32_t encode_chunk(
         const uint64_t diff = ~wave::ballot(same);
         uint32_t len0 = diff ? kMinMatch + wave::ctz64(diff) : extend_match(src, mpos, mcand, kMinMatch + 64, match_end);
         if (len0 >= kLaneCap) {
+#if NVCOMP_LZM_INSERT_UNCOVERED
+          insert_lanes(eligible && lane <= f0 && lane * STRIDE >= skip);
+#endif
           /* grow it backwards over the pending literals (what the CPU compressors call catching up): lane l
            * compares the l-th byte before the match with the l-th byte before its source */
           {
@@ -616,11 +639,25 @@ __device__ __forceinline__ uint32_t encode_chunk(
        * find the next hit, read its length, mask off what the match covers. Where each selected lane's literal run
        * starts (the end of the match selected before it) is worked out afterwards, for all of them at once. */
       uint64_t selected = 0;
+#if NVCOMP_LZM_INSERT_UNCOVERED
+      uint64_t covered = 0;
+#endif
       uint32_t cur = 0;       /* window-relative BYTE position the next match may start at */
       uint64_t rest = hits;
       while (rest) {
-        const uint32_t f = wave::ctz64(rest);
-        const uint32_t flen = wave::read_lane(mlen, f);
+        uint32_t f = wave::ctz64(rest);
+        uint32_t flen = wave::read_lane(mlen, f);
+#if NVCOMP_LZM_LAZY
+        /* one step of lazy evaluation: every lane has measured its own match, so "does the next position start a
+         * longer one?" is one more lane read. The shorter match becomes a literal. */
+        if (f < 63 && ((hits >> (f + 1)) & 1) && flen < kLaneCap) {
+          const uint32_t l1 = wave::read_lane(mlen, f + 1);
+          if (l1 > flen) {
+            f = f + 1;
+            flen = l1;
+          }
+        }
+#endif
         selected |= 1ull << f;
         cur = f * STRIDE + flen;
         if (flen >= kLaneCap) { /* the capped match may be much longer: measure it with the whole wave */
@@ -631,8 +668,14 @@ __device__ __forceinline__ uint32_t encode_chunk(
         {
           const uint32_t next_lane = (cur + STRIDE - 1) / STRIDE; /* first lane at or behind the match's end */
           rest = next_lane < 64 ? (hits & (~0ull << next_lane)) : 0ull;
+#if NVCOMP_LZM_INSERT_UNCOVERED
+          covered |= (next_lane < 64 ? ~(~0ull << next_lane) : ~0ull) & (f < 63 ? (~0ull << (f + 1)) : 0ull);
+#endif
         }
       }
+#if NVCOMP_LZM_INSERT_UNCOVERED
+      insert_lanes(eligible && lane * STRIDE >= skip && !((covered >> lane) & 1));
+#endif
       const uint32_t lit_from = ip + cur; /* behind the last selected match */
       /* a selected lane's run starts where the selected match below it ends (the first one's: at the anchor) */
       uint32_t prev_end;

@@ -1,0 +1,488 @@
+/*
+ * common/lz_match_wide.hip.h -- the match finder of the LZ4 / Snappy compressors for untyped data, round 5: one wavefront
+ * per chunk as in common/lz_match.hip.h, but a STEP covers 256 positions (four sub-windows of 64, lane l of sub-window k
+ * at position ip + 64 k + l) and the expensive parts run on COMPACTED work:
+ *
+ *   1. probe (all 256 positions): the word at the position out of the LDS image of the input, hash, table entry ->
+ *      candidate, table insert -- sub-window after sub-window, so that a probe sees every position in front of its own
+ *      sub-window, exactly as the one-window compressor; repeats 1 / 2 / 4 / 8 bytes back by comparing with the
+ *      neighbouring lanes' words;
+ *   2. word check: ONE dword load per position with a table candidate (four in flight per lane): three candidates in
+ *      four are hash collisions, and they stop here;
+ *   3. measure: the positions whose candidate holds the same word are compacted into a queue in LDS (ballot + popcount)
+ *      and measured 64 at a time, position side out of the image, candidate side with two 16-byte loads: a window of
+ *      text has 10-20 such positions, so that the one-window compressor ran its 100-instruction measurement with a quarter
+ *      of its lanes; here a step of text needs one or two passes instead of four;
+ *   4. select: the scalar walk over the hit masks, greedy with one step of lazy evaluation (lz_match.hip.h);
+ *   5. emit: the selected matches -- at most 64 a step, a match covers four positions -- are compacted into lanes, sizes
+ *      and offsets come from one DPP scan, every lane writes its own sequence, literal bytes out of the image.
+ *
+ * Why (profiles/r04_final_pmc.json, docs/HISTORY.md 3.2): the one-window compressor spends 239 vector + 210 scalar
+ * instructions and ~470 L1 lookups per 64 positions with 15-25 % of its lanes doing useful work behind the probe; the
+ * vector units are 72 % busy, the L1 tag lookup rate is at its limit of one per cycle and CU. Per 256 positions this
+ * file issues about half the vector instructions, a third of the scalar ones and a third of the lookups.
+ *
+ * Emitter concept: as in lz_match.hip.h (formats whose sequences start at byte boundaries only).
+ */
+#pragma once
+
+#include "common/lz_match.hip.h"
+
+namespace lzm {
+namespace wide {
+
+#ifndef NVCOMP_LZMW_HASH_ENTRIES
+#define NVCOMP_LZMW_HASH_ENTRIES 4096
+#endif
+constexpr uint32_t kEntries = NVCOMP_LZMW_HASH_ENTRIES; /* 2-byte entries: position mod 65536 */
+static_assert(kEntries % 128 == 0 && kEntries <= 65536, "the table is cleared 64 dwords at a time");
+constexpr uint32_t kSub = 4;             /* sub-windows of 64 positions per step */
+constexpr uint32_t kStep = 64 * kSub;    /* positions per step */
+constexpr uint32_t kBlock = 256;         /* bytes of an image block: one dword per lane */
+constexpr uint32_t kRing = 4 * kBlock;   /* the image holds blocks b-1 ... b+2 of the step in block b, byte p at p & 1023 */
+constexpr uint32_t kMirror = 48;         /* the first bytes of slot 0 once more behind slot 3: reads run on ascending addresses */
+constexpr uint32_t kImage = kRing + kMirror;
+constexpr uint32_t kQueue = 4 * kStep;   /* hit queue: (position in the step) | distance << 8; afterwards the sequence slots */
+constexpr uint32_t kResults = kStep;     /* one byte per position: match length | backward growth << 5 */
+constexpr uint32_t kScratch = kQueue + kResults;
+constexpr uint32_t kCap = 24;            /* per-lane match measurement (longer matches: the whole wave, lzm::extend_match) */
+constexpr uint32_t kBack = 7;            /* bytes a match may grow backwards over its literal run (three bits) */
+constexpr uint32_t kLdsPerWave = 2 * kEntries + kImage + kScratch;
+
+__device__ __forceinline__ uint32_t hashw(uint32_t v)
+{
+  const uint32_t h = v * 2654435761u;
+  if constexpr ((kEntries & (kEntries - 1)) == 0) {
+    return h >> (32 - __builtin_ctz(kEntries));
+  } else {
+    return __umulhi(h, kEntries);
+  }
+}
+
+/* The input image: a ring of four 256-byte blocks, blocks [lo, hi) resident. */
+struct Image
+{
+  uint8_t* base;
+  uint32_t lo, hi;
+  uint32_t coming; /* block requested ahead (its dwords wait in `piece`), or ~0u */
+  uint32_t piece;
+};
+
+__device__ __forceinline__ uint32_t image_fetch(const uint8_t* __restrict__ src, uint32_t n, uint32_t blk)
+{
+  const uint32_t at = blk * kBlock + 4 * (uint32_t)wave::lane_id();
+  uint32_t v = 0;
+  if (at + 4 <= n) {
+    v = wave::gload_u32(src + at);
+  } else if (at < n) { /* the chunk's last one to three bytes */
+    v = wave::gload_u8(src + at);
+    if (at + 1 < n) {
+      v |= wave::gload_u8(src + at + 1) << 8;
+    }
+    if (at + 2 < n) {
+      v |= wave::gload_u8(src + at + 2) << 16;
+    }
+  }
+  return v;
+}
+
+__device__ __forceinline__ void image_commit(uint8_t* base, uint32_t blk, uint32_t piece)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  const uint32_t slot = blk & 3u;
+  *(uint32_t*)(base + slot * kBlock + 4 * lane) = piece;
+  if (slot == 0 && lane < kMirror / 4) {
+    *(uint32_t*)(base + kRing + 4 * lane) = piece;
+  }
+}
+
+/* Blocks b - 1 (when there is one), b and b + 1 resident; b + 2 requested for the next step. */
+__device__ __forceinline__ void image_ensure(Image& im, const uint8_t* __restrict__ src, uint32_t n, uint32_t b)
+{
+  const uint32_t need_lo = b ? b - 1 : 0u;
+  const uint32_t need_hi = b + 2;
+  wave::sync(); /* the step before has read what is overwritten now */
+  if (need_lo < im.lo || need_lo > im.hi) { /* behind a long match: nothing resident is of use */
+    im.lo = need_lo;
+    im.hi = need_lo;
+  }
+  while (im.hi < need_hi) {
+    const uint32_t p = im.coming == im.hi ? im.piece : image_fetch(src, n, im.hi);
+    image_commit(im.base, im.hi, p);
+    ++im.hi;
+  }
+  im.lo = im.hi - im.lo > 4 ? im.hi - 4 : im.lo;
+  im.coming = ~0u;
+  wave::sync();
+  if ((b + 2) * kBlock < n) {
+    im.piece = image_fetch(src, n, b + 2);
+    im.coming = b + 2;
+  }
+}
+
+/* The four bytes at chunk position p (resident). */
+__device__ __forceinline__ uint32_t image_u32(const uint8_t* base, uint32_t p)
+{
+  const uint32_t o = p & (kRing - 1);
+  const uint32_t* q = (const uint32_t*)(base + (o & ~3u));
+  return wave::align_bytes(q[1], q[0], o & 3u);
+}
+
+/* What the measuring lane finds for position p and candidate c (c < p, the words at both are equal or the lane is idle). */
+__device__ __forceinline__ uint32_t measure(
+    const uint8_t* __restrict__ src, uint32_t n, const uint8_t* img, uint32_t p, uint32_t c, uint32_t match_end, bool active)
+{
+  /* position side: bytes [p - 8, p + 24) out of the image, nine aligned dwords */
+  uint32_t pre0, pre1, f[6];
+  {
+    const uint32_t from = (p - 8u) & (kRing - 1);
+    const uint32_t* q = (const uint32_t*)(img + (from & ~3u));
+    const uint32_t sh = p & 3u;
+    uint32_t w[9];
+#pragma unroll
+    for (uint32_t i = 0; i < 9; ++i) {
+      w[i] = q[i];
+    }
+    pre0 = wave::align_bytes(w[1], w[0], sh);
+    pre1 = wave::align_bytes(w[2], w[1], sh);
+#pragma unroll
+    for (uint32_t i = 0; i < 6; ++i) {
+      f[i] = wave::align_bytes(w[i + 3], w[i + 2], sh);
+    }
+  }
+  /* candidate side: [c - 8, c + 24) with two 16-byte loads; a candidate in the first 8 or the last 24 bytes of the chunk
+   * (rare) is read dword by dword as far as the chunk goes and does not grow backwards */
+  uint32_t cpre0 = ~pre0, cpre1 = ~pre1, g[6];
+#pragma unroll
+  for (uint32_t i = 0; i < 6; ++i) {
+    g[i] = ~f[i];
+  }
+  const bool whole = active && c >= 8 && c + kCap <= n && p >= 8;
+  if (whole) {
+    const wave::u32x4 a = wave::gload_u32x4(src + c - 8);
+    const wave::u32x4 b = wave::gload_u32x4(src + c + 8);
+    cpre0 = a.x, cpre1 = a.y;
+    g[0] = a.z, g[1] = a.w, g[2] = b.x, g[3] = b.y, g[4] = b.z, g[5] = b.w;
+  } else if (active) {
+#pragma unroll
+    for (uint32_t i = 0; i < 6; ++i) {
+      if (c + 4 * i + 4 <= n) {
+        g[i] = wave::gload_u32(src + c + 4 * i);
+      }
+    }
+  }
+  uint32_t idx = 6, xv = 0;
+#pragma unroll
+  for (uint32_t i = 5; i >= 1; --i) {
+    const uint32_t x = f[i] ^ g[i];
+    idx = x ? i : idx;
+    xv = x ? x : xv;
+  }
+  uint32_t mlen = 4 * idx + (xv ? (uint32_t)__builtin_ctz(xv) >> 3 : 0u);
+  const uint32_t room = match_end - p;
+  mlen = mlen < room ? mlen : room;
+  mlen = (active && f[0] == g[0]) ? mlen : 0u;
+  const uint64_t xb = ((uint64_t)(pre1 ^ cpre1) << 32) | (pre0 ^ cpre0);
+  uint32_t back = xb ? (uint32_t)__builtin_clzll(xb) >> 3 : 8u;
+  back = back < kBack ? back : kBack;
+  return mlen | (back << 5);
+}
+
+/* One sub-window's part of the selection walk. `cur` = position in the step from which the next match may start (carried
+ * from sub-window to sub-window); returns the mask of selected lanes; a match that hit the per-lane cap is measured by the
+ * whole wave and its length written back. */
+__device__ __forceinline__ uint64_t select_sub(
+    const uint8_t* __restrict__ src, uint32_t ip, uint32_t k, uint64_t hits, uint32_t& mlen, uint32_t cand, uint32_t match_end,
+    uint32_t& cur)
+{
+  uint64_t selected = 0;
+  const uint32_t base = 64 * k;
+  uint64_t rest = cur <= base ? hits : (cur - base < 64 ? hits & (~0ull << (cur - base)) : 0ull);
+  while (rest) {
+    uint32_t f = wave::ctz64(rest);
+    uint32_t flen = wave::read_lane(mlen, f);
+#if NVCOMP_LZM_LAZY
+    if (f < 63 && ((hits >> (f + 1)) & 1) && flen < kCap) {
+      const uint32_t l1 = wave::read_lane(mlen, f + 1);
+      if (l1 > flen) {
+        f = f + 1;
+        flen = l1;
+      }
+    }
+#endif
+    if (flen >= kCap) {
+      flen = extend_match(src, ip + base + f, wave::read_lane(cand, f), kCap, match_end);
+      mlen = wave::write_lane(mlen, flen, f);
+    }
+    selected |= 1ull << f;
+    cur = base + f + flen;
+    const uint32_t next_lane = cur - base;
+    rest = next_lane < 64 ? (hits & (~0ull << next_lane)) : 0ull;
+  }
+  return selected;
+}
+
+template <class Emitter>
+__device__ __forceinline__ uint32_t encode_chunk(
+    const uint8_t* __restrict__ src, uint32_t n, uint8_t* dst, uint16_t* table, uint8_t* image, uint8_t* scratch,
+    uint32_t last_start, uint32_t match_end, bool any_match)
+{
+  static_assert(!Emitter::kStream, "byte-aligned formats only");
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  for (uint32_t i = lane; i < kEntries / 2; i += 64) {
+    ((uint32_t*)table)[i] = 0;
+  }
+  uint32_t* queue = (uint32_t*)scratch;
+  uint8_t* results = scratch + kQueue;
+  wave::sync();
+
+  uint32_t op = 0;
+  uint32_t anchor = 0;
+  LZM_PROF_DECL;
+  if (any_match) {
+    Image im;
+    im.base = image;
+    im.lo = 0, im.hi = 0, im.coming = ~0u, im.piece = 0;
+    uint32_t ip = 0;   /* multiple of kStep */
+    uint32_t skip = 0; /* leading positions of the step that the last match already covers */
+    while (ip <= last_start) {
+      LZM_T(0);
+      image_ensure(im, src, n, ip / kBlock);
+
+      /* ---- 1. probe ---- */
+      uint32_t word[kSub], cand[kSub];
+      bool ok[kSub], sure[kSub]; /* has a candidate / the candidate is a neighbour repeat (known to match) */
+#pragma unroll
+      for (uint32_t k = 0; k < kSub; ++k) {
+        const uint32_t rel = 64 * k + lane;
+        const uint32_t pos = ip + rel;
+        const bool inside = pos <= last_start;
+        word[k] = image_u32(image, pos);
+        const uint32_t slot = hashw(word[k]);
+        cand[k] = table_candidate(pos, table[slot], ok[k], Emitter::kReach);
+        wave::sync();
+        if (inside) {
+          table[slot] = (uint16_t)pos;
+        }
+        wave::sync();
+        /* repeats 1, 2, 4, 8 bytes back: the lower lanes of the sub-window, or the upper lanes of the one before */
+        uint32_t near = 0;
+#pragma unroll
+        for (uint32_t d = 1; d <= 8; d *= 2) {
+          uint32_t other = wave::shuffle(word[k], (lane - d) & 63u);
+          bool have = lane >= d;
+          if (k > 0) {
+            const uint32_t before = wave::shuffle(word[k - 1], (lane - d) & 63u);
+            other = lane >= d ? other : before;
+            have = true;
+          }
+          near = (near == 0 && have && other == word[k]) ? d : near;
+        }
+        sure[k] = near != 0;
+        cand[k] = near ? pos - near : cand[k];
+        ok[k] = (ok[k] || sure[k]) && inside && rel >= skip;
+      }
+      LZM_T(1);
+      /* ---- 2. word check ---- */
+      uint32_t cword[kSub];
+#pragma unroll
+      for (uint32_t k = 0; k < kSub; ++k) {
+        cword[k] = word[k];
+        if (ok[k] && !sure[k]) {
+          cword[k] = wave::gload_u32(src + cand[k]);
+        }
+      }
+      uint64_t hits[kSub];
+      uint32_t total_hits = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < kSub; ++k) {
+        ok[k] = ok[k] && cword[k] == word[k];
+        hits[k] = wave::ballot(ok[k]);
+        total_hits += wave::popc64(hits[k]);
+      }
+      LZM_T(2);
+      if (total_hits == 0) {
+        skip = skip > kStep ? skip - kStep : 0;
+        ip += kStep;
+        continue;
+      }
+
+      /* ---- long first match (runs, periodic columns): one cooperative probe decides (lz_match.hip.h) ---- */
+      {
+        const uint32_t k0 = skip >> 6; /* the first sub-window with searched positions */
+        const uint64_t h0 = k0 == 0 ? hits[0] : k0 == 1 ? hits[1] : k0 == 2 ? hits[2] : hits[3];
+        if (wave::popc64(h0) >= kDenseHits) {
+          const uint32_t c0 = k0 == 0 ? cand[0] : k0 == 1 ? cand[1] : k0 == 2 ? cand[2] : cand[3];
+          const uint32_t f0 = wave::ctz64(h0);
+          uint32_t mpos = ip + 64 * k0 + f0;
+          uint32_t mcand = wave::read_lane(c0, f0);
+          const uint32_t p = mpos + kMinMatch + lane;
+          const bool same = p < match_end && wave::gload_u8(src + p) == wave::gload_u8(src + mcand + kMinMatch + lane);
+          const uint64_t diff = ~wave::ballot(same);
+          uint32_t len0 = diff ? kMinMatch + wave::ctz64(diff) : extend_match(src, mpos, mcand, kMinMatch + 64, match_end);
+          if (len0 >= kCap) {
+            const uint32_t room = mpos - anchor < mcand ? mpos - anchor : mcand;
+            const bool eq = lane < room && wave::gload_u8(src + mpos - 1 - lane) == wave::gload_u8(src + mcand - 1 - lane);
+            const uint64_t ne = ~wave::ballot(eq);
+            const uint32_t back = ne ? wave::ctz64(ne) : 64u;
+            mpos -= back;
+            mcand -= back;
+            len0 += back;
+            op += Emitter::match(dst + op, src + anchor, mpos - anchor, mpos - mcand, len0);
+            const uint32_t next = mpos + len0;
+            anchor = next;
+            ip = next & ~(kStep - 1);
+            skip = next - ip;
+            continue;
+          }
+        }
+      }
+      LZM_T(3);
+
+      /* ---- 3. measure the hits, 64 at a time ---- */
+      {
+        uint32_t base = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kSub; ++k) {
+          if (ok[k]) {
+            const uint32_t rel = 64 * k + lane;
+            queue[base + wave::prefix_popc(hits[k])] = rel | ((ip + rel - cand[k]) << 8);
+          }
+          base += wave::popc64(hits[k]);
+        }
+        wave::sync();
+        for (uint32_t b0 = 0; b0 < total_hits; b0 += 64) {
+          const bool active = b0 + lane < total_hits;
+          const uint32_t e = active ? queue[b0 + lane] : 8u << 8;
+          const uint32_t rel = e & 255u;
+          const uint32_t p = ip + rel;
+          const uint32_t r = measure(src, n, image, active ? p : ip + 8, active ? p - (e >> 8) : ip, match_end, active);
+          if (active) {
+            results[rel] = (uint8_t)r;
+          }
+        }
+        wave::sync();
+      }
+      uint32_t mlen[kSub], back[kSub];
+#pragma unroll
+      for (uint32_t k = 0; k < kSub; ++k) {
+        const uint32_t r = ok[k] ? results[64 * k + lane] : 0u;
+        mlen[k] = r & 31u;
+        back[k] = r >> 5;
+        hits[k] = wave::ballot(mlen[k] != 0);
+      }
+      LZM_T(4);
+
+      /* ---- 4. select ---- */
+      uint32_t cur = skip;
+      uint64_t sel[kSub];
+#pragma unroll
+      for (uint32_t k = 0; k < kSub; ++k) {
+        sel[k] = select_sub(src, ip, k, hits[k], mlen[k], cand[k], match_end, cur);
+      }
+      const uint32_t n_sel = wave::popc64(sel[0]) + wave::popc64(sel[1]) + wave::popc64(sel[2]) + wave::popc64(sel[3]);
+      LZM_T(5);
+      if (n_sel != 0) {
+        /* ---- 5. the selected matches, compacted into lanes ---- */
+        wave::sync(); /* the queue has been read */
+        {
+          uint32_t base = 0;
+#pragma unroll
+          for (uint32_t k = 0; k < kSub; ++k) {
+            if ((sel[k] >> lane) & 1) {
+              const uint32_t rel = 64 * k + lane;
+              const uint32_t at = base + wave::prefix_popc(sel[k]);
+              queue[2 * at] = rel | (back[k] << 8) | ((ip + rel - cand[k]) << 16);
+              queue[2 * at + 1] = mlen[k];
+            }
+            base += wave::popc64(sel[k]);
+          }
+        }
+        wave::sync();
+        const bool mine = lane < n_sel;
+        const uint32_t s0 = mine ? queue[2 * lane] : 0u;
+        const uint32_t pos = ip + (s0 & 255u);
+        uint32_t my_len = mine ? queue[2 * lane + 1] : 0u;
+        const uint32_t offset = s0 >> 16;
+        /* a lane's literal run starts where the match of the lane below ends (the first one's: at the anchor) */
+        uint32_t prev_end = wave::prev_lane(pos + my_len);
+        prev_end = lane == 0 ? anchor : prev_end;
+        uint32_t lit_len = mine ? pos - prev_end : 0u;
+        {
+          const uint32_t grow = (s0 >> 8) & 7u;
+          const uint32_t b = grow < lit_len ? grow : lit_len; /* never into the match before */
+          lit_len -= mine ? b : 0u;
+          my_len += mine ? b : 0u;
+        }
+        const uint32_t size = mine ? Emitter::seq_size(lit_len, my_len, offset) : 0u;
+        const uint32_t incl = wave::scan_add_inclusive(size);
+        const uint32_t total = wave::read_lane(incl, 63);
+        const bool small = mine && Emitter::is_small(lit_len, my_len);
+        uint64_t big = wave::ballot(mine && !small);
+        LZM_T(6);
+        uint8_t* my_dst = dst + op + incl - size;
+        if (small) {
+          Emitter::emit_small_header(my_dst, lit_len, offset, my_len);
+        }
+        /* literal runs of the small sequences (<= 64 bytes, ending inside this step: always in the image) */
+        {
+          uint8_t* ld = my_dst + Emitter::lit_offset(lit_len);
+          const bool lit4 = small && lit_len >= 4;
+          for (uint32_t base4 = 0; wave::ballot(lit4 && lit_len > base4) != 0; base4 += 16) {
+            if (lit4 && lit_len > base4) {
+              const uint32_t lastoff = lit_len - 4;
+              uint32_t v[4];
+#pragma unroll
+              for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t o = base4 + 4 * i < lastoff ? base4 + 4 * i : lastoff;
+                v[i] = image_u32(image, prev_end + o);
+              }
+#pragma unroll
+              for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t o = base4 + 4 * i < lastoff ? base4 + 4 * i : lastoff;
+                lz::st_u32(ld + o, v[i]);
+              }
+            }
+          }
+          if (small && lit_len != 0 && lit_len < 4) {
+            const uint32_t v = image_u32(image, prev_end);
+            ld[0] = (uint8_t)v;
+            if (lit_len > 1) {
+              ld[1] = (uint8_t)(v >> 8);
+            }
+            if (lit_len > 2) {
+              ld[2] = (uint8_t)(v >> 16);
+            }
+          }
+        }
+        LZM_T(7);
+        /* the few sequences a single lane cannot write (long literal run after match-less steps, long match) */
+        while (big) {
+          const uint32_t j = wave::ctz64(big);
+          big &= big - 1;
+          const uint32_t jdst = op + wave::read_lane(incl - size, j);
+          const uint32_t jlit = wave::read_lane(prev_end, j);
+          Emitter::match(dst + jdst, src + jlit, wave::read_lane(lit_len, j), wave::read_lane(offset, j), wave::read_lane(my_len, j));
+        }
+        op += total;
+        anchor = ip + cur;
+      }
+      LZM_T(8);
+      if (cur >= 2 * kStep) { /* a long match measured by the whole wave: go on behind it */
+        const uint32_t next = ip + cur;
+        ip = next & ~(kStep - 1);
+        skip = next - ip;
+      } else {
+        ip += kStep;
+        skip = cur > kStep ? cur - kStep : 0;
+      }
+    }
+  }
+  op += Emitter::tail(dst + op, src + anchor, n - anchor);
+  LZM_T(9);
+  LZM_PROF_END;
+  return op;
+}
+
+} // namespace wide
+} // namespace lzm

@@ -15,6 +15,7 @@
 #pragma once
 
 #include "common/lz_match.hip.h"
+#include "common/lz_match_wide.hip.h"
 
 namespace lz4 {
 
@@ -124,6 +125,16 @@ __device__ __forceinline__ uint32_t encode_chunk(
   const bool any = n > kMfLimit;
   return lzm::encode_chunk<Emitter, STRIDE>(
       src, n, dst, table, image, any ? n - kMfLimit : 0, any ? n - kLastLiterals : 0, any);
+}
+
+/* The same for untyped data with the 256-position steps of common/lz_match_wide.hip.h (`table`: lzm::wide::kEntries x
+ * uint16, `image`: lzm::wide::kImage bytes, `scratch`: lzm::wide::kScratch bytes, both 16-byte aligned). */
+__device__ __forceinline__ uint32_t encode_chunk_wide(
+    const uint8_t* __restrict__ src, uint32_t n, uint8_t* dst, uint16_t* table, uint8_t* image, uint8_t* scratch)
+{
+  const bool any = n > kMfLimit;
+  return lzm::wide::encode_chunk<Emitter>(
+      src, n, dst, table, image, scratch, any ? n - kMfLimit : 0, any ? n - kLastLiterals : 0, any);
 }
 
 } // namespace lz4

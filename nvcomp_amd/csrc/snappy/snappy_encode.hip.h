@@ -11,6 +11,7 @@
 #pragma once
 
 #include "common/lz_match.hip.h"
+#include "common/lz_match_wide.hip.h"
 
 namespace snappy {
 
@@ -159,28 +160,41 @@ struct Emitter
   }
 };
 
+/* preamble: varint32 of n. Returns its length. */
+__device__ __forceinline__ uint32_t put_preamble(uint8_t* dst, uint32_t n)
+{
+  uint32_t hdr = 0;
+  uint32_t v = n;
+  uint8_t bytes[5];
+  do {
+    bytes[hdr] = (uint8_t)((v & 127u) | (v >= 128 ? 128u : 0u));
+    v >>= 7;
+    ++hdr;
+  } while (v);
+  if (wave::lane_id() == 0) {
+    for (uint32_t i = 0; i < hdr; ++i) {
+      dst[i] = bytes[i];
+    }
+  }
+  return hdr;
+}
+
 /* Compress src[0,n) into dst (capacity >= 32 + n + n/6). Returns compressed size. */
 __device__ __forceinline__ uint32_t encode_chunk(
     const uint8_t* __restrict__ src, uint32_t n, uint8_t* dst, uint16_t* table, uint8_t* image)
 {
-  /* preamble: varint32 of n */
-  uint32_t hdr = 0;
-  {
-    uint32_t v = n;
-    uint8_t bytes[5];
-    do {
-      bytes[hdr] = (uint8_t)((v & 127u) | (v >= 128 ? 128u : 0u));
-      v >>= 7;
-      ++hdr;
-    } while (v);
-    if (wave::lane_id() == 0) {
-      for (uint32_t i = 0; i < hdr; ++i) {
-        dst[i] = bytes[i];
-      }
-    }
-  }
+  const uint32_t hdr = put_preamble(dst, n);
   const bool any = n >= 8;
   return hdr + lzm::encode_chunk<Emitter>(src, n, dst + hdr, table, image, any ? n - 4 : 0, n, any);
+}
+
+/* The same with the 256-position steps of common/lz_match_wide.hip.h. */
+__device__ __forceinline__ uint32_t encode_chunk_wide(
+    const uint8_t* __restrict__ src, uint32_t n, uint8_t* dst, uint16_t* table, uint8_t* image, uint8_t* scratch)
+{
+  const uint32_t hdr = put_preamble(dst, n);
+  const bool any = n >= 8;
+  return hdr + lzm::wide::encode_chunk<Emitter>(src, n, dst + hdr, table, image, scratch, any ? n - 4 : 0, n, any);
 }
 
 } // namespace snappy
