@@ -270,7 +270,8 @@ def run_case(args, ctx):
     if own_format:
         opts = tuple(int(x) for x in args.opts.split(",")) if args.opts else OWN_FORMAT_OPTS[args.algo]
     codec = nvcomp_amd.BatchedCodec(lib, dev, fmt, opts)
-    threads = len(os.sched_getaffinity(0))
+    # host threads of the (untimed) input producer and of the cpu_baseline leg: the box's cores shared among the ranks
+    threads = max(1, len(os.sched_getaffinity(0)) // max(1, world))
 
     # ---- build the batch (untimed) ----
     from oracle import oracle_py as oracle  # producer of inputs + cpu_baseline checker only
@@ -762,6 +763,8 @@ def run_allgather_case(args, ctx):
         torch.cumsum(all_sizes, dim=1, out=offs_ext[:, 1:])
         torch.index_select(offs_ext, 1, cut_index, out=cut_offs)
         host_cuts = cut_offs.tolist()  # THE host sync of a step: byte counts, like the reference's sync_all_streams (:370)
+        for row in host_cuts:  # every peer's cuts: ascending and inside the receive buffers
+            assert row[0] == 0 and all(a <= b for a, b in zip(row, row[1:])) and row[-1] <= cap_bytes, row
         moved[0] = int(sum(row[-1] for row in host_cuts))
         for j in range(n_slices):
             c0, c1 = cuts[j], cuts[j + 1]

@@ -38,6 +38,9 @@ constexpr unsigned kEncWaves = NVCOMP_LZM_WAVES_PER_BLOCK; /* the compressors' w
 #define NVCOMP_LZMW_WAVES_PER_BLOCK 1
 #endif
 constexpr unsigned kWideWaves = NVCOMP_LZMW_WAVES_PER_BLOCK;
+#ifndef NVCOMP_LZMW_WAVES_PER_SIMD
+#define NVCOMP_LZMW_WAVES_PER_SIMD 4 /* what the wave's LDS allows (15-16 waves per CU): a budget of 128 registers */
+#endif
 using lzl::kMaxOutCap;
 
 /* Profiling builds only (wrong output by construction): 1 = stop after the token chase, 2 = after the parse. */
@@ -267,7 +270,7 @@ __global__ void __launch_bounds__(64 * kEncWaves, NVCOMP_LZM_WAVES_PER_SIMD) lz4
 }
 
 /* Untyped data: 256-position steps (common/lz_match_wide.hip.h); a wave's LDS is lzm::wide::kLdsPerWave bytes. */
-__global__ void __launch_bounds__(64 * kWideWaves) lz4_compress_wide_kernel(const lzl::CompressLaunch launch)
+__global__ void __launch_bounds__(64 * kWideWaves, NVCOMP_LZMW_WAVES_PER_SIMD) lz4_compress_wide_kernel(const lzl::CompressLaunch launch)
 {
   __shared__ uint16_t tables[kWideWaves][lzm::wide::kEntries];
   __shared__ __attribute__((aligned(16))) uint8_t images[kWideWaves][lzm::wide::kImage];

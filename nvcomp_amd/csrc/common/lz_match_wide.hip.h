@@ -32,10 +32,13 @@ namespace lzm {
 namespace wide {
 
 #ifndef NVCOMP_LZMW_HASH_ENTRIES
-#define NVCOMP_LZMW_HASH_ENTRIES 4096
+#define NVCOMP_LZMW_HASH_ENTRIES 3936
+#endif
+#ifndef NVCOMP_LZMW_EARLY_REQUEST
+#define NVCOMP_LZMW_EARLY_REQUEST 0
 #endif
 constexpr uint32_t kEntries = NVCOMP_LZMW_HASH_ENTRIES; /* 2-byte entries: position mod 65536 */
-static_assert(kEntries % 128 == 0 && kEntries <= 65536, "the table is cleared 64 dwords at a time");
+static_assert(kEntries % 2 == 0 && kEntries <= 65536, "the table is cleared a dword at a time");
 constexpr uint32_t kSub = 4;             /* sub-windows of 64 positions per step */
 constexpr uint32_t kStep = 64 * kSub;    /* positions per step */
 constexpr uint32_t kBlock = 256;         /* bytes of an image block: one dword per lane */
@@ -55,7 +58,12 @@ __device__ __forceinline__ uint32_t hashw(uint32_t v)
   if constexpr ((kEntries & (kEntries - 1)) == 0) {
     return h >> (32 - __builtin_ctz(kEntries));
   } else {
-    return __umulhi(h, kEntries);
+    /* the next power of two's worth of hash bits, folded: the first slots take two values each. (A multiply-shift range
+     * reduction is a second quarter-rate multiplication per position.) */
+    constexpr uint32_t kBits = 32 - __builtin_clz(kEntries - 1);
+    static_assert(2 * kEntries >= (1u << kBits), "one fold");
+    const uint32_t x = h >> (32 - kBits);
+    return x < kEntries ? x : x - kEntries;
   }
 }
 
@@ -101,7 +109,7 @@ __device__ __forceinline__ void image_ensure(Image& im, const uint8_t* __restric
 {
   const uint32_t need_lo = b ? b - 1 : 0u;
   const uint32_t need_hi = b + 2;
-  wave::sync(); /* the step before has read what is overwritten now */
+  wave::sync_wave(); /* the step before has read what is overwritten now */
   if (need_lo < im.lo || need_lo > im.hi) { /* behind a long match: nothing resident is of use */
     im.lo = need_lo;
     im.hi = need_lo;
@@ -113,7 +121,7 @@ __device__ __forceinline__ void image_ensure(Image& im, const uint8_t* __restric
   }
   im.lo = im.hi - im.lo > 4 ? im.hi - 4 : im.lo;
   im.coming = ~0u;
-  wave::sync();
+  wave::sync_wave();
   if ((b + 2) * kBlock < n) {
     im.piece = image_fetch(src, n, b + 2);
     im.coming = b + 2;
@@ -128,10 +136,38 @@ __device__ __forceinline__ uint32_t image_u32(const uint8_t* base, uint32_t p)
   return wave::align_bytes(q[1], q[0], o & 3u);
 }
 
-/* What the measuring lane finds for position p and candidate c (c < p, the words at both are equal or the lane is idle). */
-__device__ __forceinline__ uint32_t measure(
-    const uint8_t* __restrict__ src, uint32_t n, const uint8_t* img, uint32_t p, uint32_t c, uint32_t match_end, bool active)
+/* The candidate side of a measurement, requested: bytes [c - 8, c + 24) in two 16-byte loads. A candidate in the first 8 or
+ * the last 24 bytes of the chunk (rare) is read dword by dword, as far as the chunk goes, when the measurement is finished,
+ * and does not grow backwards. */
+struct Pending
 {
+  wave::u32x4 a, b;
+  uint32_t p, c;
+  bool active, whole;
+};
+
+__device__ __forceinline__ Pending measure_request(const uint8_t* __restrict__ src, uint32_t n, uint32_t p, uint32_t c, bool active)
+{
+  Pending m;
+  m.p = p, m.c = c, m.active = active;
+  m.whole = active && c >= 8 && c + kCap <= n && p >= 8;
+  /* a lane that has nothing to measure (or goes the slow way) reads the chunk's first bytes: one address for all of them */
+  const uint8_t* at = src + (m.whole ? c - 8 : 0u);
+  const bool any32 = n >= 32;
+  m.a.x = m.a.y = m.a.z = m.a.w = 0, m.b = m.a;
+  if (any32) {
+    m.a = wave::gload_u32x4(at);
+    m.b = wave::gload_u32x4(at + 16);
+  }
+  return m;
+}
+
+/* What the measuring lane finds for position p and candidate c (c < p, the words at both are equal or the lane is idle):
+ * match length (0: no match after all, otherwise 4 ... kCap and at most match_end - p) | backward growth << 5. */
+__device__ __forceinline__ uint32_t measure_finish(
+    const uint8_t* __restrict__ src, uint32_t n, const uint8_t* img, const Pending& m, uint32_t match_end)
+{
+  const uint32_t p = m.p, c = m.c;
   /* position side: bytes [p - 8, p + 24) out of the image, nine aligned dwords */
   uint32_t pre0, pre1, f[6];
   {
@@ -150,22 +186,12 @@ __device__ __forceinline__ uint32_t measure(
       f[i] = wave::align_bytes(w[i + 3], w[i + 2], sh);
     }
   }
-  /* candidate side: [c - 8, c + 24) with two 16-byte loads; a candidate in the first 8 or the last 24 bytes of the chunk
-   * (rare) is read dword by dword as far as the chunk goes and does not grow backwards */
-  uint32_t cpre0 = ~pre0, cpre1 = ~pre1, g[6];
-#pragma unroll
-  for (uint32_t i = 0; i < 6; ++i) {
-    g[i] = ~f[i];
-  }
-  const bool whole = active && c >= 8 && c + kCap <= n && p >= 8;
-  if (whole) {
-    const wave::u32x4 a = wave::gload_u32x4(src + c - 8);
-    const wave::u32x4 b = wave::gload_u32x4(src + c + 8);
-    cpre0 = a.x, cpre1 = a.y;
-    g[0] = a.z, g[1] = a.w, g[2] = b.x, g[3] = b.y, g[4] = b.z, g[5] = b.w;
-  } else if (active) {
+  uint32_t cpre0 = m.whole ? m.a.x : ~pre0, cpre1 = m.whole ? m.a.y : ~pre1, g[6];
+  g[0] = m.a.z, g[1] = m.a.w, g[2] = m.b.x, g[3] = m.b.y, g[4] = m.b.z, g[5] = m.b.w;
+  if (m.active && !m.whole) {
 #pragma unroll
     for (uint32_t i = 0; i < 6; ++i) {
+      g[i] = ~f[i];
       if (c + 4 * i + 4 <= n) {
         g[i] = wave::gload_u32(src + c + 4 * i);
       }
@@ -181,45 +207,109 @@ __device__ __forceinline__ uint32_t measure(
   uint32_t mlen = 4 * idx + (xv ? (uint32_t)__builtin_ctz(xv) >> 3 : 0u);
   const uint32_t room = match_end - p;
   mlen = mlen < room ? mlen : room;
-  mlen = (active && f[0] == g[0]) ? mlen : 0u;
+  mlen = (m.active && f[0] == g[0]) ? mlen : 0u;
   const uint64_t xb = ((uint64_t)(pre1 ^ cpre1) << 32) | (pre0 ^ cpre0);
   uint32_t back = xb ? (uint32_t)__builtin_clzll(xb) >> 3 : 8u;
   back = back < kBack ? back : kBack;
   return mlen | (back << 5);
 }
 
-/* One sub-window's part of the selection walk. `cur` = position in the step from which the next match may start (carried
- * from sub-window to sub-window); returns the mask of selected lanes; a match that hit the per-lane cap is measured by the
- * whole wave and its length written back. */
+/* One sub-window's part of the selection walk: greedy over `eff`, the hit lanes that lazy evaluation does not pass over
+ * (decided per lane in front of the walk, so that a step of it is: find the lane, read its length, mask). `cur` =
+ * position in the step from which the next match may start (carried from sub-window to sub-window); returns the mask of
+ * selected lanes; a match that hit the per-lane cap is measured by the whole wave and its length written back. */
 __device__ __forceinline__ uint64_t select_sub(
-    const uint8_t* __restrict__ src, uint32_t ip, uint32_t k, uint64_t hits, uint32_t& mlen, uint32_t cand, uint32_t match_end,
-    uint32_t& cur)
+    const uint8_t* __restrict__ src, uint32_t ip, uint32_t k, uint64_t eff, uint64_t capped, uint32_t& mlen, uint32_t cand,
+    uint32_t match_end, uint32_t& cur)
 {
-  uint64_t selected = 0;
   const uint32_t base = 64 * k;
-  uint64_t rest = cur <= base ? hits : (cur - base < 64 ? hits & (~0ull << (cur - base)) : 0ull);
+  const uint32_t start = cur <= base ? 0u : cur - base;
+  if (start >= 64 || (eff >> start) == 0) {
+    return 0;
+  }
+  if ((eff & capped) == 0) { /* the common case: every length is below 64, the walk is eight scalar instructions a match */
+    uint64_t selected;
+    uint32_t end;
+    wave::select_walk(eff, mlen, start, selected, end);
+    cur = base + end;
+    return selected;
+  }
+  uint64_t selected = 0;
+  uint64_t rest = eff & (~0ull << start);
   while (rest) {
-    uint32_t f = wave::ctz64(rest);
+    const uint32_t f = wave::ctz64(rest);
     uint32_t flen = wave::read_lane(mlen, f);
-#if NVCOMP_LZM_LAZY
-    if (f < 63 && ((hits >> (f + 1)) & 1) && flen < kCap) {
-      const uint32_t l1 = wave::read_lane(mlen, f + 1);
-      if (l1 > flen) {
-        f = f + 1;
-        flen = l1;
-      }
-    }
-#endif
     if (flen >= kCap) {
       flen = extend_match(src, ip + base + f, wave::read_lane(cand, f), kCap, match_end);
       mlen = wave::write_lane(mlen, flen, f);
     }
     selected |= 1ull << f;
-    cur = base + f + flen;
-    const uint32_t next_lane = cur - base;
-    rest = next_lane < 64 ? (hits & (~0ull << next_lane)) : 0ull;
+    const uint32_t next_lane = f + flen;
+    cur = base + next_lane;
+    rest = next_lane < 64 ? (eff & (~0ull << next_lane)) : 0ull;
   }
   return selected;
+}
+
+/* What the probe of a step leaves behind: per sub-window the word at the lane's position, its candidate, whether there is one
+ * and whether it is known to match, and the candidate's word -- on its way: the loads are not waited for here. */
+struct Probed
+{
+  uint32_t word[kSub], cand[kSub], cword[kSub];
+  uint32_t flags; /* bit k: sub-window k has a candidate; bit 4 + k: ... that is known to match (a neighbour repeat) */
+};
+
+template <class Emitter>
+__device__ __forceinline__ void probe_step(
+    Probed& pr, Image& im, const uint8_t* __restrict__ src, uint32_t n, uint16_t* table, uint32_t ip, uint32_t last_start)
+{
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  uint8_t* image = im.base;
+  image_ensure(im, src, n, ip / kBlock);
+  uint32_t slot[kSub];
+#pragma unroll
+  for (uint32_t k = 0; k < kSub; ++k) {
+    pr.word[k] = image_u32(image, ip + 64 * k + lane);
+    slot[k] = hashw(pr.word[k]);
+  }
+  /* table entry -> candidate, then this sub-window's positions go in: the LDS serves a wave's accesses in issue order, so
+   * that the next sub-window's probe sees them without a wait */
+  bool ok[kSub];
+#pragma unroll
+  for (uint32_t k = 0; k < kSub; ++k) {
+    const uint32_t pos = ip + 64 * k + lane;
+    pr.cand[k] = table_candidate(pos, table[slot[k]], ok[k], Emitter::kReach);
+    wave::sync_wave();
+    if (pos <= last_start) {
+      table[slot[k]] = (uint16_t)pos;
+    }
+    wave::sync_wave();
+  }
+  pr.flags = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kSub; ++k) {
+    const uint32_t pos = ip + 64 * k + lane;
+    /* repeats 1, 2, 4, 8 bytes back: the lower lanes of the sub-window, or the upper lanes of the one before */
+    uint32_t near = 0;
+#pragma unroll
+    for (uint32_t d = 1; d <= 8; d *= 2) {
+      uint32_t other = wave::shuffle(pr.word[k], (lane - d) & 63u);
+      bool have = lane >= d;
+      if (k > 0) {
+        const uint32_t before = wave::shuffle(pr.word[k - 1], (lane - d) & 63u);
+        other = lane >= d ? other : before;
+        have = true;
+      }
+      near = (near == 0 && have && other == pr.word[k]) ? d : near;
+    }
+    const bool sure = near != 0;
+    pr.cand[k] = near ? pos - near : pr.cand[k];
+    const bool has = (ok[k] || sure) && pos <= last_start;
+    pr.flags |= (has ? 1u << k : 0u) | (has && sure ? 16u << k : 0u);
+    /* word check: ONE dword per position with a table candidate, the four loads of a lane travel together (a lane
+     * without a candidate reads the chunk's first word: one address for all of them) */
+    pr.cword[k] = wave::gload_u32(src + ((has && !sure) ? pr.cand[k] : 0u));
+  }
 }
 
 template <class Emitter>
@@ -234,7 +324,7 @@ __device__ __forceinline__ uint32_t encode_chunk(
   }
   uint32_t* queue = (uint32_t*)scratch;
   uint8_t* results = scratch + kQueue;
-  wave::sync();
+  wave::sync_wave();
 
   uint32_t op = 0;
   uint32_t anchor = 0;
@@ -245,58 +335,19 @@ __device__ __forceinline__ uint32_t encode_chunk(
     im.lo = 0, im.hi = 0, im.coming = ~0u, im.piece = 0;
     uint32_t ip = 0;   /* multiple of kStep */
     uint32_t skip = 0; /* leading positions of the step that the last match already covers */
+    Probed pr;
+    probe_step<Emitter>(pr, im, src, n, table, ip, last_start);
     while (ip <= last_start) {
       LZM_T(0);
-      image_ensure(im, src, n, ip / kBlock);
-
-      /* ---- 1. probe ---- */
-      uint32_t word[kSub], cand[kSub];
-      bool ok[kSub], sure[kSub]; /* has a candidate / the candidate is a neighbour repeat (known to match) */
-#pragma unroll
-      for (uint32_t k = 0; k < kSub; ++k) {
-        const uint32_t rel = 64 * k + lane;
-        const uint32_t pos = ip + rel;
-        const bool inside = pos <= last_start;
-        word[k] = image_u32(image, pos);
-        const uint32_t slot = hashw(word[k]);
-        cand[k] = table_candidate(pos, table[slot], ok[k], Emitter::kReach);
-        wave::sync();
-        if (inside) {
-          table[slot] = (uint16_t)pos;
-        }
-        wave::sync();
-        /* repeats 1, 2, 4, 8 bytes back: the lower lanes of the sub-window, or the upper lanes of the one before */
-        uint32_t near = 0;
-#pragma unroll
-        for (uint32_t d = 1; d <= 8; d *= 2) {
-          uint32_t other = wave::shuffle(word[k], (lane - d) & 63u);
-          bool have = lane >= d;
-          if (k > 0) {
-            const uint32_t before = wave::shuffle(word[k - 1], (lane - d) & 63u);
-            other = lane >= d ? other : before;
-            have = true;
-          }
-          near = (near == 0 && have && other == word[k]) ? d : near;
-        }
-        sure[k] = near != 0;
-        cand[k] = near ? pos - near : cand[k];
-        ok[k] = (ok[k] || sure[k]) && inside && rel >= skip;
-      }
-      LZM_T(1);
-      /* ---- 2. word check ---- */
-      uint32_t cword[kSub];
-#pragma unroll
-      for (uint32_t k = 0; k < kSub; ++k) {
-        cword[k] = word[k];
-        if (ok[k] && !sure[k]) {
-          cword[k] = wave::gload_u32(src + cand[k]);
-        }
-      }
+      /* ---- the step's hits: the candidates that hold the position's word (the loads were requested a step ago) ---- */
+      uint32_t cand[kSub];
+      bool ok[kSub];
       uint64_t hits[kSub];
       uint32_t total_hits = 0;
 #pragma unroll
       for (uint32_t k = 0; k < kSub; ++k) {
-        ok[k] = ok[k] && cword[k] == word[k];
+        cand[k] = pr.cand[k];
+        ok[k] = ((pr.flags >> k) & 1u) != 0 && 64 * k + lane >= skip && (((pr.flags >> (4 + k)) & 1u) != 0 || pr.cword[k] == pr.word[k]);
         hits[k] = wave::ballot(ok[k]);
         total_hits += wave::popc64(hits[k]);
       }
@@ -304,6 +355,10 @@ __device__ __forceinline__ uint32_t encode_chunk(
       if (total_hits == 0) {
         skip = skip > kStep ? skip - kStep : 0;
         ip += kStep;
+        if (ip <= last_start) {
+          probe_step<Emitter>(pr, im, src, n, table, ip, last_start);
+        }
+        LZM_T(1);
         continue;
       }
 
@@ -333,13 +388,18 @@ __device__ __forceinline__ uint32_t encode_chunk(
             anchor = next;
             ip = next & ~(kStep - 1);
             skip = next - ip;
+            LZM_T(3);
+            if (ip <= last_start) {
+              probe_step<Emitter>(pr, im, src, n, table, ip, last_start);
+            }
+            LZM_T(1);
             continue;
           }
         }
       }
       LZM_T(3);
 
-      /* ---- 3. measure the hits, 64 at a time ---- */
+      /* ---- measure the hits, 64 at a time: compacted into a queue, the first two batches' candidate sides requested ---- */
       {
         uint32_t base = 0;
 #pragma unroll
@@ -350,41 +410,105 @@ __device__ __forceinline__ uint32_t encode_chunk(
           }
           base += wave::popc64(hits[k]);
         }
-        wave::sync();
-        for (uint32_t b0 = 0; b0 < total_hits; b0 += 64) {
-          const bool active = b0 + lane < total_hits;
-          const uint32_t e = active ? queue[b0 + lane] : 8u << 8;
-          const uint32_t rel = e & 255u;
-          const uint32_t p = ip + rel;
-          const uint32_t r = measure(src, n, image, active ? p : ip + 8, active ? p - (e >> 8) : ip, match_end, active);
-          if (active) {
-            results[rel] = (uint8_t)r;
-          }
-        }
-        wave::sync();
+        wave::sync_wave();
       }
-      uint32_t mlen[kSub], back[kSub];
+#if NVCOMP_LZMW_EARLY_REQUEST
+      /* the first batch's candidate sides are requested in front of the next step's probe and looked at behind it */
+      const bool early_act = lane < total_hits;
+      const uint32_t early_e = early_act ? queue[lane] : 8u << 8;
+      const uint32_t early_p = early_act ? ip + (early_e & 255u) : ip + 8;
+      const Pending early = measure_request(src, n, early_p, early_p - (early_e >> 8), early_act);
+#endif
+      LZM_T(4);
+
+      /* ---- the NEXT step's probe and word-check loads: they travel while this step is measured, selected and written.
+       * (The step behind a long match starts elsewhere: then this probe only put positions inside that match into the
+       * table.) `pr` is free: what this step needs of it are the candidates and the hit masks ---- */
+      const uint32_t nip = ip + kStep;
+      if (nip <= last_start) {
+        probe_step<Emitter>(pr, im, src, n, table, nip, last_start);
+      }
+      LZM_T(1);
+
+#if NVCOMP_LZMW_EARLY_REQUEST
+      {
+        Pending m = early;
+        for (uint32_t b0 = 0; b0 < total_hits; b0 += 64) {
+          const bool more = b0 + 64 < total_hits;
+          Pending mn = m;
+          if (more) { /* the next batch travels while this one is looked at */
+            const bool act = b0 + 64 + lane < total_hits;
+            const uint32_t e = act ? queue[b0 + 64 + lane] : 8u << 8;
+            const uint32_t p = act ? ip + (e & 255u) : ip + 8;
+            mn = measure_request(src, n, p, p - (e >> 8), act);
+          }
+          const uint32_t r = measure_finish(src, n, image, m, match_end);
+          if (m.active) {
+            results[m.p - ip] = (uint8_t)r;
+          }
+          m = mn;
+        }
+      }
+#else
+      /* two batches a round: their loads travel together */
+      for (uint32_t b0 = 0; b0 < total_hits; b0 += 128) {
+        const bool act0 = b0 + lane < total_hits, act1 = b0 + 64 + lane < total_hits;
+        const uint32_t e0 = act0 ? queue[b0 + lane] : 8u << 8;
+        const uint32_t e1 = act1 ? queue[b0 + 64 + lane] : 8u << 8;
+        const uint32_t rel0 = e0 & 255u, rel1 = e1 & 255u;
+        const uint32_t p0 = act0 ? ip + rel0 : ip + 8, p1 = act1 ? ip + rel1 : ip + 8;
+        const Pending m0 = measure_request(src, n, p0, p0 - (e0 >> 8), act0);
+        uint32_t r1 = 0;
+        if (b0 + 64 < total_hits) {
+          const Pending m1 = measure_request(src, n, p1, p1 - (e1 >> 8), act1);
+          r1 = measure_finish(src, n, image, m1, match_end);
+        }
+        const uint32_t r0 = measure_finish(src, n, image, m0, match_end);
+        if (act0) {
+          results[rel0] = (uint8_t)r0;
+        }
+        if (act1) {
+          results[rel1] = (uint8_t)r1;
+        }
+      }
+#endif
+      wave::sync_wave();
+      uint32_t mlen[kSub];
+      uint64_t capped[kSub];
 #pragma unroll
       for (uint32_t k = 0; k < kSub; ++k) {
         const uint32_t r = ok[k] ? results[64 * k + lane] : 0u;
         mlen[k] = r & 31u;
-        back[k] = r >> 5;
         hits[k] = wave::ballot(mlen[k] != 0);
+        capped[k] = wave::ballot(mlen[k] >= kCap);
       }
-      LZM_T(4);
+      LZM_T(5);
 
-      /* ---- 4. select ---- */
+      /* ---- select ---- */
+      /* lazy evaluation, per lane: a match shorter than the one starting at the next position is passed over (the next
+       * position's is looked at in its turn) */
+#if NVCOMP_LZM_LAZY
+#pragma unroll
+      for (uint32_t k = 0; k < kSub; ++k) {
+        uint32_t ahead = wave::next_lane(mlen[k]);
+        if (k + 1 < kSub) {
+          const uint32_t first = wave::read_lane(mlen[k + 1], 0);
+          ahead = lane == 63 ? first : ahead;
+        }
+        hits[k] = wave::ballot(mlen[k] != 0 && !(mlen[k] < kCap && ahead > mlen[k]));
+      }
+#endif
       uint32_t cur = skip;
       uint64_t sel[kSub];
 #pragma unroll
       for (uint32_t k = 0; k < kSub; ++k) {
-        sel[k] = select_sub(src, ip, k, hits[k], mlen[k], cand[k], match_end, cur);
+        sel[k] = select_sub(src, ip, k, hits[k], capped[k], mlen[k], cand[k], match_end, cur);
       }
       const uint32_t n_sel = wave::popc64(sel[0]) + wave::popc64(sel[1]) + wave::popc64(sel[2]) + wave::popc64(sel[3]);
-      LZM_T(5);
+      LZM_T(6);
       if (n_sel != 0) {
         /* ---- 5. the selected matches, compacted into lanes ---- */
-        wave::sync(); /* the queue has been read */
+        wave::sync_wave(); /* the queue has been read */
         {
           uint32_t base = 0;
 #pragma unroll
@@ -392,13 +516,13 @@ __device__ __forceinline__ uint32_t encode_chunk(
             if ((sel[k] >> lane) & 1) {
               const uint32_t rel = 64 * k + lane;
               const uint32_t at = base + wave::prefix_popc(sel[k]);
-              queue[2 * at] = rel | (back[k] << 8) | ((ip + rel - cand[k]) << 16);
+              queue[2 * at] = rel | ((uint32_t)(results[rel] >> 5) << 8) | ((ip + rel - cand[k]) << 16);
               queue[2 * at + 1] = mlen[k];
             }
             base += wave::popc64(sel[k]);
           }
         }
-        wave::sync();
+        wave::sync_wave();
         const bool mine = lane < n_sel;
         const uint32_t s0 = mine ? queue[2 * lane] : 0u;
         const uint32_t pos = ip + (s0 & 255u);
@@ -419,7 +543,6 @@ __device__ __forceinline__ uint32_t encode_chunk(
         const uint32_t total = wave::read_lane(incl, 63);
         const bool small = mine && Emitter::is_small(lit_len, my_len);
         uint64_t big = wave::ballot(mine && !small);
-        LZM_T(6);
         uint8_t* my_dst = dst + op + incl - size;
         if (small) {
           Emitter::emit_small_header(my_dst, lit_len, offset, my_len);
@@ -472,8 +595,12 @@ __device__ __forceinline__ uint32_t encode_chunk(
         const uint32_t next = ip + cur;
         ip = next & ~(kStep - 1);
         skip = next - ip;
+        if (ip <= last_start) {
+          probe_step<Emitter>(pr, im, src, n, table, ip, last_start);
+        }
+        LZM_T(1);
       } else {
-        ip += kStep;
+        ip = nip;
         skip = cur > kStep ? cur - kStep : 0;
       }
     }

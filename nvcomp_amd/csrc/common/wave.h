@@ -227,6 +227,35 @@ __device__ __forceinline__ void chain_walk(uint32_t step, uint32_t limit, uint32
       : "scc", "m0");
 }
 
+/*
+ * Greedy walk over a mask of candidate lanes, each with a length below 64 in `len`: from lane `start` (< 64, and at least
+ * one candidate at or above it) repeat { f = the lowest candidate at or above the current lane; take it; go on at
+ * f + len[f] }. Returns the taken lanes in `taken` and where the walk stopped (f + len[f] of the last one taken) in `end`.
+ * The serial part of the LZ compressors' match selection, one iteration per selected match, written out: 7 SALU + 1 VALU
+ * an iteration (the compiler's version of the same loop: 16).
+ */
+__device__ __forceinline__ void select_walk(uint64_t candidates, uint32_t len, uint32_t start, uint64_t& taken, uint32_t& end)
+{
+  uint64_t r;
+  uint32_t t, l;
+  asm volatile(
+      "s_lshr_b64 %[r], %[cand], %[start]\n\t"
+      "s_mov_b32 %[pos], %[start]\n\t"
+      "s_mov_b64 %[taken], 0\n"
+      "1:\n\t"
+      "s_ff1_i32_b64 %[t], %[r]\n\t"
+      "s_add_u32 %[pos], %[pos], %[t]\n\t"
+      "s_lshr_b64 %[r], %[r], %[t]\n\t"
+      "v_readlane_b32 %[l], %[len], %[pos]\n\t"
+      "s_bitset1_b64 %[taken], %[pos]\n\t"
+      "s_add_u32 %[pos], %[pos], %[l]\n\t"
+      "s_lshr_b64 %[r], %[r], %[l]\n\t"
+      "s_cbranch_scc1 1b"
+      : [taken] "=&s"(taken), [pos] "=&s"(end), [r] "=&s"(r), [t] "=&s"(t), [l] "=&s"(l)
+      : [cand] "s"(candidates), [len] "v"(len), [start] "s"(start)
+      : "scc");
+}
+
 /* Per-lane gather: lane i receives v of lane src_lane(i) (ds_bpermute_b32). */
 __device__ __forceinline__ uint32_t shuffle(uint32_t v, uint32_t src_lane)
 {
@@ -237,6 +266,12 @@ __device__ __forceinline__ uint32_t shuffle(uint32_t v, uint32_t src_lane)
 __device__ __forceinline__ uint32_t prev_lane(uint32_t v)
 {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
+}
+
+/* v of the lane above (lane 63: 0): wave_shl:1. */
+__device__ __forceinline__ uint32_t next_lane(uint32_t v)
+{
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
 }
 
 /* Inclusive prefix sum across the wave: 4 row_shr steps inside each row of 16
@@ -294,11 +329,26 @@ __device__ __forceinline__ uint32_t reduce_add(uint32_t v)
  * same-wave cross-lane read-after-write; what has to be stopped is the
  * compiler moving a load above a store it believes cannot alias.
  */
+#if defined(NVCOMP_WAVE_SYNC_WAVEFRONT) && NVCOMP_WAVE_SYNC_WAVEFRONT
+#define NVCOMP_WAVE_SYNC_SCOPE "wavefront" /* A/B build: see sync_wave() */
+#else
+#define NVCOMP_WAVE_SYNC_SCOPE "workgroup"
+#endif
 __device__ __forceinline__ void sync()
 {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, NVCOMP_WAVE_SYNC_SCOPE);
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, NVCOMP_WAVE_SYNC_SCOPE);
+}
+
+/* The same between the lanes of ONE wave only (the compressors' per-wave LDS: nothing another wave reads). A release at
+ * workgroup scope drains the wave's LDS queue (s_waitcnt lgkmcnt(0)) in front of every such point; at wavefront scope it is
+ * what the comment above asks for and nothing else -- the compiler keeps the order, the hardware needs no wait. */
+__device__ __forceinline__ void sync_wave()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 /* LDS word |= bits, no return value (ds_or_b32): lanes of one instruction may hit the same word. */

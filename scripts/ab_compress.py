@@ -84,8 +84,8 @@ def main():
                         tot = float(sum(slots)) or 1.0
                         names = ["loop_top", "probe", "insert", "dense", "select", "scan", "headers", "literals", "coop", "tail", "-", "-"]
                         if tag.startswith("w") or tag == "libnvcomp":  # the 256-position steps (common/lz_match_wide.hip.h)
-                            names = ["image", "probe", "word_check", "dense", "measure", "select", "compact_scan", "headers_literals",
-                                     "coop", "tail", "-", "-"]
+                            names = ["loop_top", "probe_next_step", "hits", "dense", "queue_and_requests", "measure", "select",
+                                     "emit", "coop", "tail", "-", "-"]
                         line["phase_share"] = {k: round(v / tot, 3) for k, v in zip(names, slots) if v}
                 del out, ob
             except Exception as e:  # noqa: BLE001

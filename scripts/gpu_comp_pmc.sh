@@ -20,7 +20,7 @@ for f in glob.glob(out + "/pmc_*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
         acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, cs in acc.items():
-        if "_compress_kernel" not in k: continue
+        if "_compress_" not in k: continue
         for c, v in cs.items(): res.setdefault(k.split("(")[0][-40:], {})[c] = sum(v) / len(v)
 json.dump(res, open(out + "/summary.json", "w"), indent=1); print(json.dumps(res, indent=1))
 PY

@@ -111,6 +111,27 @@ inline void chain_walk(uint32_t step, uint32_t limit, uint32_t& r, uint32_t& k, 
   } while (r < limit);
 }
 
+inline void select_walk(uint64_t candidates, uint32_t len, uint32_t start, uint64_t& taken, uint32_t& end)
+{
+  uint64_t r = candidates >> start;
+  uint32_t pos = start;
+  taken = 0;
+  do {
+    const uint32_t t = (uint32_t)__builtin_ctzll(r);
+    pos += t;
+    r >>= t;
+    const uint32_t l = read_lane(len, pos);
+    if (l >= 64) {
+      fprintf(stderr, "emu: select_walk with a length of 64 or more\n");
+      abort();
+    }
+    taken |= 1ull << pos;
+    pos += l;
+    r >>= l;
+  } while (r);
+  end = pos;
+}
+
 inline uint32_t gload_u8(const uint8_t* p) { return *p; }
 inline uint32_t gload_u32(const uint8_t* p)
 {
@@ -152,6 +173,12 @@ inline uint32_t shuffle(uint32_t v, uint32_t src_lane)
 {
   emu::wave_rendezvous(kShuffle, v, src_lane);
   return (uint32_t)emu::peer((int)(src_lane & 63)).a;
+}
+
+inline uint32_t next_lane(uint32_t v)
+{
+  const uint32_t r = shuffle(v, (uint32_t)(lane_id() + 1) & 63u);
+  return lane_id() == 63 ? 0u : r;
 }
 
 inline uint32_t scan_add_inclusive(uint32_t v)
@@ -197,6 +224,7 @@ inline uint32_t reduce_add(uint32_t v)
 }
 
 inline void sync() { emu::wave_rendezvous(kSync, 0, 0); }
+inline void sync_wave() { sync(); }
 
 inline void lds_or(uint32_t* p, uint32_t bits) { *p |= bits; }
 inline void lds_add(uint32_t* p, uint32_t v) { *p += v; }
