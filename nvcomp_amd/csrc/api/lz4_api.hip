@@ -392,8 +392,8 @@ nvcompStatus_t nvcompBatchedLZ4DecompressAsync(
       return launch_status();
     }
     if (device_temp_ptr != nullptr && temp_bytes >= sizeof(uint32_t) && ((uintptr_t)device_temp_ptr & 3u) == 0) {
-      static lzl::ResidentCache resident[2]; /* per device ordinal */
-      const unsigned fit = resident[1].get(lz4_decompress_team_kernel<true, 8>, 512, 0);
+      static lzl::ResidentCache resident; /* per device ordinal */
+      const unsigned fit = resident.get(lz4_decompress_team_kernel<true, 8>, 512, 0);
       if (fit != 0 && fit < groups && hipMemsetAsync(device_temp_ptr, 0, sizeof(uint32_t), stream) == hipSuccess) {
         ticket = (uint32_t*)device_temp_ptr;
         groups = fit;
@@ -414,8 +414,8 @@ nvcompStatus_t nvcompBatchedLZ4DecompressAsync(
   uint32_t* ticket = nullptr;
 #if NVCOMP_LZ_PERSISTENT
   if (device_temp_ptr != nullptr && temp_bytes >= sizeof(uint32_t) && ((uintptr_t)device_temp_ptr & 3u) == 0) {
-    static lzl::ResidentCache resident[2]; /* per device ordinal */
-    const unsigned fit = resident[1].get(lz4_decompress_window_kernel<true>, 64 * kDecWaves);
+    static lzl::ResidentCache resident; /* per device ordinal */
+    const unsigned fit = resident.get(lz4_decompress_window_kernel<true>, 64 * kDecWaves);
     if (fit != 0 && fit < groups && hipMemsetAsync(device_temp_ptr, 0, sizeof(uint32_t), stream) == hipSuccess) {
       ticket = (uint32_t*)device_temp_ptr;
       groups = fit;

@@ -52,9 +52,8 @@ namespace lzw {
 #ifndef NVCOMP_LZW_FAR_L4_FROM_F0
 #define NVCOMP_LZW_FAR_L4_FROM_F0 0 /* A/B: the last dword of a far match of up to 16 bytes out of its first load */
 #endif
-#ifndef NVCOMP_LZW_FAR_NT
-#define NVCOMP_LZW_FAR_NT 0 /* A/B: far-match loads non-temporal (inline-asm loads waited for by hand) */
-#endif
+/* (Round 4 measured the far-match loads non-temporal -- inline-asm loads waited for by hand --: 663 -> 412 GB/s,
+ * docs/HISTORY.md 4; the path is gone.) */
 #ifndef NVCOMP_LZW_FLUSH_ALIGN
 #define NVCOMP_LZW_FLUSH_ALIGN 16 /* a batch's flush ends on this address boundary (16 | 32 | 64 | 128); the rest waits in the window */
 #endif
@@ -1121,10 +1120,6 @@ __device__ __forceinline__ uint32_t execute_window_batch(
   const bool far_lane = short_match && match_src + my_match <= ow.flushed && out_cap >= 32 && match_src <= out_cap - 32;
   uint32_t far_l4 = 0;
   uint32_t far_data[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#if NVCOMP_LZW_FAR_NT
-  wave::u32x4 nt0 = {0, 0, 0, 0}, nt1 = {0, 0, 0, 0};
-  uint32_t nt4 = 0;
-#endif
   const uint32_t far_steps = steps_for(far_lane, my_match);
   if (far_lane && !(NVCOMP_LZW_ABLATE_EXEC & 2)) {
 #ifdef NVCOMP_LZW_FAR_ABLATE /* profiling builds only (wrong output): far reads folded onto the chunk's first KiB */
@@ -1135,15 +1130,6 @@ __device__ __forceinline__ uint32_t execute_window_batch(
     /* A scattered load costs the CU's address unit a slot per lane whatever its width (profiles/r02_decode_phases.json:
      * issuing 3-9 dword loads per batch was 11 % of the wave's time): 16 bytes per load, two loads at most, plus the
      * match's last dword. */
-#if NVCOMP_LZW_FAR_NT
-    /* non-temporal: a far match's line is used once -- fetched as a normal load it evicts a line of recently WRITTEN output,
-     * which is what the next far matches of the XCD's 900 open chunks would have hit */
-    nt0 = wave::gload_u32x4_nt_async(src);
-    if (my_match > 16) {
-      nt1 = wave::gload_u32x4_nt_async(src + 16);
-    }
-    nt4 = wave::gload_u32_nt_async(src + (my_match >= 4 ? my_match - 4 : 0u));
-#else
     const wave::u32x4 f0 = wave::gload_u32x4(src);
     far_data[0] = f0.x, far_data[1] = f0.y, far_data[2] = f0.z, far_data[3] = f0.w;
     if (my_match > 16) {
@@ -1163,7 +1149,6 @@ __device__ __forceinline__ uint32_t execute_window_batch(
     }
 #else
     far_l4 = RING_LITERALS && my_match < 4 ? f0.x << 8 : wave::gload_u32(src + my_match - 4);
-#endif
 #endif
   }
 
@@ -1237,14 +1222,6 @@ __device__ __forceinline__ uint32_t execute_window_batch(
 
   LZW_T(13); /* long literal runs, whole wave */
   /* ---- far match data into the window ---- */
-#if NVCOMP_LZW_FAR_NT
-  if (wave::ballot(far_lane)) {
-    wave::wait_vm(nt0, nt1, nt4);
-    far_data[0] = nt0.x, far_data[1] = nt0.y, far_data[2] = nt0.z, far_data[3] = nt0.w;
-    far_data[4] = nt1.x, far_data[5] = nt1.y, far_data[6] = nt1.z, far_data[7] = nt1.w;
-    far_l4 = RING_LITERALS && my_match < 4 ? nt0.x << 8 : nt4;
-  }
-#endif
   if (wave::ballot(far_lane) && !(NVCOMP_LZW_ABLATE_EXEC & 16)) {
     uint8_t* dst = out_at(ow, far_lane ? match_dst : ow.wbase);
     if (far_steps == 2) {

@@ -53,27 +53,6 @@ __device__ __forceinline__ u32x4 gload_u32x4(const uint8_t* p) /* any alignment 
   u32x4 r = {q->v[0], q->v[1], q->v[2], q->v[3]};
   return r;
 }
-/* Non-temporal loads whose data is NOT waited for by the compiler: the caller issues them, does other work, and calls
- * wait_vm() on the registers before their first use (an inline-asm load is invisible to the compiler's s_waitcnt
- * insertion, which is the point: the wait goes where the algorithm wants it; and `nt` cannot be had otherwise for an
- * unaligned 16-byte access -- __builtin_nontemporal_load splits it into dwords). The registers must not be touched in
- * between (the ISA of every user is checked for that: scripts/check_nt_loads.sh). */
-__device__ __forceinline__ u32x4 gload_u32x4_nt_async(const uint8_t* p)
-{
-  u32x4 r;
-  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(r) : "v"((const WAVE_GLOBAL uint8_t*)p) : "memory");
-  return r;
-}
-__device__ __forceinline__ uint32_t gload_u32_nt_async(const uint8_t* p)
-{
-  uint32_t r;
-  asm volatile("global_load_dword %0, %1, off nt" : "=v"(r) : "v"((const WAVE_GLOBAL uint8_t*)p) : "memory");
-  return r;
-}
-__device__ __forceinline__ void wait_vm(u32x4& a, u32x4& b, uint32_t& c)
-{
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c) : : "memory");
-}
 
 __device__ __forceinline__ uint64_t gload_u64(const uint8_t* p) /* any alignment (global_load_dwordx2) */
 {
@@ -329,10 +308,16 @@ __device__ __forceinline__ uint32_t reduce_add(uint32_t v)
  * same-wave cross-lane read-after-write; what has to be stopped is the
  * compiler moving a load above a store it believes cannot alias.
  */
-#if defined(NVCOMP_WAVE_SYNC_WAVEFRONT) && NVCOMP_WAVE_SYNC_WAVEFRONT
-#define NVCOMP_WAVE_SYNC_SCOPE "wavefront" /* A/B build: see sync_wave() */
-#else
+/* The fences are at WAVEFRONT scope (round 5): what is asked for is the compiler's order -- the hardware keeps a wave's
+ * LDS and vector-memory operations in issue order by itself. At workgroup scope (rounds 1-4) every release drained the
+ * wave's LDS queue (s_waitcnt lgkmcnt(0)) in front of each of these points: measured on the decoders with the same sources,
+ * mix 654 -> 668 GB/s, 4 096 chunks 305 -> 316, sorted-key column 1 668 -> 1 720 (gpurun r5b). Waves of one workgroup
+ * that hand data to each other do it through lds_store_release / lds_load_acquire or a workgroup barrier, which carry
+ * their own scope. NVCOMP_WAVE_SYNC_WORKGROUP=1: the old behaviour (A/B build). */
+#if defined(NVCOMP_WAVE_SYNC_WORKGROUP) && NVCOMP_WAVE_SYNC_WORKGROUP
 #define NVCOMP_WAVE_SYNC_SCOPE "workgroup"
+#else
+#define NVCOMP_WAVE_SYNC_SCOPE "wavefront"
 #endif
 __device__ __forceinline__ void sync()
 {
@@ -341,9 +326,7 @@ __device__ __forceinline__ void sync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, NVCOMP_WAVE_SYNC_SCOPE);
 }
 
-/* The same between the lanes of ONE wave only (the compressors' per-wave LDS: nothing another wave reads). A release at
- * workgroup scope drains the wave's LDS queue (s_waitcnt lgkmcnt(0)) in front of every such point; at wavefront scope it is
- * what the comment above asks for and nothing else -- the compiler keeps the order, the hardware needs no wait. */
+/* The same, always at wavefront scope (the compressors' per-wave LDS: nothing another wave reads). */
 __device__ __forceinline__ void sync_wave()
 {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -146,9 +146,6 @@ inline u32x4 gload_u32x4(const uint8_t* p)
   memcpy(&v, p, 16);
   return v;
 }
-inline u32x4 gload_u32x4_nt_async(const uint8_t* p) { return gload_u32x4(p); }
-inline uint32_t gload_u32_nt_async(const uint8_t* p) { return gload_u32(p); }
-inline void wait_vm(u32x4&, u32x4&, uint32_t&) {}
 inline uint64_t gload_u64(const uint8_t* p)
 {
   uint64_t v;
