@@ -46,10 +46,10 @@ constexpr uint32_t kRing = 4 * kBlock;   /* the image holds blocks b-1 ... b+2 o
 constexpr uint32_t kMirror = 48;         /* the first bytes of slot 0 once more behind slot 3: reads run on ascending addresses */
 constexpr uint32_t kImage = kRing + kMirror;
 constexpr uint32_t kQueue = 4 * kStep;   /* hit queue: (position in the step) | distance << 8; afterwards the sequence slots */
-constexpr uint32_t kResults = kStep;     /* one byte per position: match length | backward growth << 5 */
+constexpr uint32_t kResults = kStep;     /* one byte per position: the match length of a hit that was measured through the queue */
 constexpr uint32_t kScratch = kQueue + kResults;
 constexpr uint32_t kCap = 24;            /* per-lane match measurement (longer matches: the whole wave, lzm::extend_match) */
-constexpr uint32_t kBack = 7;            /* bytes a match may grow backwards over its literal run (three bits) */
+constexpr uint32_t kBack = 4;            /* bytes a match may grow backwards over its literal run: what the word check brings */
 constexpr uint32_t kLdsPerWave = 2 * kEntries + kImage + kScratch;
 
 __device__ __forceinline__ uint32_t hashw(uint32_t v)
@@ -136,12 +136,23 @@ __device__ __forceinline__ uint32_t image_u32(const uint8_t* base, uint32_t p)
   return wave::align_bytes(q[1], q[0], o & 3u);
 }
 
-/* The candidate side of a measurement, requested: bytes [c - 8, c + 24) in two 16-byte loads. A candidate in the first 8 or
- * the last 24 bytes of the chunk (rare) is read dword by dword, as far as the chunk goes, when the measurement is finished,
- * and does not grow backwards. */
+/* Twelve bytes from chunk position p on (resident): four aligned dwords. */
+__device__ __forceinline__ wave::u32x3 image_u96(const uint8_t* base, uint32_t p)
+{
+  const uint32_t o = p & (kRing - 1);
+  const uint32_t* q = (const uint32_t*)(base + (o & ~3u));
+  const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+  wave::u32x3 r = {wave::align_bytes(q1, q0, o & 3u), wave::align_bytes(q2, q1, o & 3u), wave::align_bytes(q3, q2, o & 3u)};
+  return r;
+}
+
+/* The candidate side of a measurement, requested: the position and its candidate agree in their first 8 bytes (the word
+ * check brought those, and the growth backwards); what is still open are bytes [c + 8, c + 24): one 16-byte load. A
+ * candidate in the last 24 bytes of the chunk (rare) is read dword by dword, as far as the chunk goes, when the measurement
+ * is finished. */
 struct Pending
 {
-  wave::u32x4 a, b;
+  wave::u32x4 b;
   uint32_t p, c;
   bool active, whole;
 };
@@ -150,68 +161,57 @@ __device__ __forceinline__ Pending measure_request(const uint8_t* __restrict__ s
 {
   Pending m;
   m.p = p, m.c = c, m.active = active;
-  m.whole = active && c >= 8 && c + kCap <= n && p >= 8;
+  m.whole = active && c + kCap <= n;
   /* a lane that has nothing to measure (or goes the slow way) reads the chunk's first bytes: one address for all of them */
-  const uint8_t* at = src + (m.whole ? c - 8 : 0u);
-  const bool any32 = n >= 32;
-  m.a.x = m.a.y = m.a.z = m.a.w = 0, m.b = m.a;
-  if (any32) {
-    m.a = wave::gload_u32x4(at);
-    m.b = wave::gload_u32x4(at + 16);
+  m.b.x = m.b.y = m.b.z = m.b.w = 0;
+  if (n >= 16) {
+    m.b = wave::gload_u32x4(src + (m.whole ? c + 8 : 0u));
   }
   return m;
 }
 
-/* What the measuring lane finds for position p and candidate c (c < p, the words at both are equal or the lane is idle):
- * match length (0: no match after all, otherwise 4 ... kCap and at most match_end - p) | backward growth << 5. */
+/* What the measuring lane finds for position p and candidate c (c < p, their first 8 bytes are equal or the lane is idle):
+ * the match length, 8 ... kCap and at most match_end - p. */
 __device__ __forceinline__ uint32_t measure_finish(
     const uint8_t* __restrict__ src, uint32_t n, const uint8_t* img, const Pending& m, uint32_t match_end)
 {
   const uint32_t p = m.p, c = m.c;
-  /* position side: bytes [p - 8, p + 24) out of the image, nine aligned dwords */
-  uint32_t pre0, pre1, f[6];
+  /* position side: bytes [p + 8, p + 24) out of the image, five aligned dwords */
+  uint32_t f[4];
   {
-    const uint32_t from = (p - 8u) & (kRing - 1);
-    const uint32_t* q = (const uint32_t*)(img + (from & ~3u));
     const uint32_t sh = p & 3u;
-    uint32_t w[9];
+    const uint32_t* r = (const uint32_t*)(img + (((p + 8u) & (kRing - 1)) & ~3u));
+    uint32_t v[5];
 #pragma unroll
-    for (uint32_t i = 0; i < 9; ++i) {
-      w[i] = q[i];
+    for (uint32_t i = 0; i < 5; ++i) {
+      v[i] = r[i];
     }
-    pre0 = wave::align_bytes(w[1], w[0], sh);
-    pre1 = wave::align_bytes(w[2], w[1], sh);
 #pragma unroll
-    for (uint32_t i = 0; i < 6; ++i) {
-      f[i] = wave::align_bytes(w[i + 3], w[i + 2], sh);
+    for (uint32_t i = 0; i < 4; ++i) {
+      f[i] = wave::align_bytes(v[i + 1], v[i], sh);
     }
   }
-  uint32_t cpre0 = m.whole ? m.a.x : ~pre0, cpre1 = m.whole ? m.a.y : ~pre1, g[6];
-  g[0] = m.a.z, g[1] = m.a.w, g[2] = m.b.x, g[3] = m.b.y, g[4] = m.b.z, g[5] = m.b.w;
+  uint32_t g[4] = {m.b.x, m.b.y, m.b.z, m.b.w};
   if (m.active && !m.whole) {
 #pragma unroll
-    for (uint32_t i = 0; i < 6; ++i) {
+    for (uint32_t i = 0; i < 4; ++i) {
       g[i] = ~f[i];
-      if (c + 4 * i + 4 <= n) {
-        g[i] = wave::gload_u32(src + c + 4 * i);
+      if (c + 8 + 4 * i + 4 <= n) {
+        g[i] = wave::gload_u32(src + c + 8 + 4 * i);
       }
     }
   }
-  uint32_t idx = 6, xv = 0;
+  uint32_t idx = 4, xv = 0;
 #pragma unroll
-  for (uint32_t i = 5; i >= 1; --i) {
+  for (int i = 3; i >= 0; --i) {
     const uint32_t x = f[i] ^ g[i];
-    idx = x ? i : idx;
+    idx = x ? (uint32_t)i : idx;
     xv = x ? x : xv;
   }
-  uint32_t mlen = 4 * idx + (xv ? (uint32_t)__builtin_ctz(xv) >> 3 : 0u);
+  uint32_t mlen = 8 + 4 * idx + (xv ? (uint32_t)__builtin_ctz(xv) >> 3 : 0u);
   const uint32_t room = match_end - p;
   mlen = mlen < room ? mlen : room;
-  mlen = (m.active && f[0] == g[0]) ? mlen : 0u;
-  const uint64_t xb = ((uint64_t)(pre1 ^ cpre1) << 32) | (pre0 ^ cpre0);
-  uint32_t back = xb ? (uint32_t)__builtin_clzll(xb) >> 3 : 8u;
-  back = back < kBack ? back : kBack;
-  return mlen | (back << 5);
+  return m.active ? mlen : 0u;
 }
 
 /* One sub-window's part of the selection walk: greedy over `eff`, the hit lanes that lazy evaluation does not pass over
@@ -251,12 +251,13 @@ __device__ __forceinline__ uint64_t select_sub(
   return selected;
 }
 
-/* What the probe of a step leaves behind: per sub-window the word at the lane's position, its candidate, whether there is one
- * and whether it is known to match, and the candidate's word -- on its way: the loads are not waited for here. */
+/* What the probe of a step leaves behind: per sub-window the lane's candidate, whether there is one, and the candidate's
+ * bytes [c - 4, c + 8) -- on their way: the loads are not waited for here. */
 struct Probed
 {
-  uint32_t word[kSub], cand[kSub], cword[kSub];
-  uint32_t flags; /* bit k: sub-window k has a candidate; bit 4 + k: ... that is known to match (a neighbour repeat) */
+  uint32_t cand[kSub];
+  wave::u32x3 cbytes[kSub]; /* the candidate's bytes [c - 4, c + 8) */
+  uint32_t has; /* bit k: sub-window k has a candidate */
 };
 
 template <class Emitter>
@@ -266,11 +267,11 @@ __device__ __forceinline__ void probe_step(
   const uint32_t lane = (uint32_t)wave::lane_id();
   uint8_t* image = im.base;
   image_ensure(im, src, n, ip / kBlock);
-  uint32_t slot[kSub];
+  uint32_t word[kSub], slot[kSub];
 #pragma unroll
   for (uint32_t k = 0; k < kSub; ++k) {
-    pr.word[k] = image_u32(image, ip + 64 * k + lane);
-    slot[k] = hashw(pr.word[k]);
+    word[k] = image_u32(image, ip + 64 * k + lane);
+    slot[k] = hashw(word[k]);
   }
   /* table entry -> candidate, then this sub-window's positions go in: the LDS serves a wave's accesses in issue order, so
    * that the next sub-window's probe sees them without a wait */
@@ -285,7 +286,7 @@ __device__ __forceinline__ void probe_step(
     }
     wave::sync_wave();
   }
-  pr.flags = 0;
+  pr.has = 0;
 #pragma unroll
   for (uint32_t k = 0; k < kSub; ++k) {
     const uint32_t pos = ip + 64 * k + lane;
@@ -293,22 +294,23 @@ __device__ __forceinline__ void probe_step(
     uint32_t near = 0;
 #pragma unroll
     for (uint32_t d = 1; d <= 8; d *= 2) {
-      uint32_t other = wave::shuffle(pr.word[k], (lane - d) & 63u);
+      uint32_t other = wave::shuffle(word[k], (lane - d) & 63u);
       bool have = lane >= d;
       if (k > 0) {
-        const uint32_t before = wave::shuffle(pr.word[k - 1], (lane - d) & 63u);
+        const uint32_t before = wave::shuffle(word[k - 1], (lane - d) & 63u);
         other = lane >= d ? other : before;
         have = true;
       }
-      near = (near == 0 && have && other == pr.word[k]) ? d : near;
+      near = (near == 0 && have && other == word[k]) ? d : near;
     }
-    const bool sure = near != 0;
     pr.cand[k] = near ? pos - near : pr.cand[k];
-    const bool has = (ok[k] || sure) && pos <= last_start;
-    pr.flags |= (has ? 1u << k : 0u) | (has && sure ? 16u << k : 0u);
-    /* word check: ONE dword per position with a table candidate, the four loads of a lane travel together (a lane
-     * without a candidate reads the chunk's first word: one address for all of them) */
-    pr.cword[k] = wave::gload_u32(src + ((has && !sure) ? pr.cand[k] : 0u));
+    const bool has = (ok[k] || near != 0) && pos <= last_start && pr.cand[k] >= 4 && pr.cand[k] + 8 <= n;
+    pr.has |= has ? 1u << k : 0u;
+    /* word check: the candidate's bytes [c - 4, c + 8), ONE load per position with a candidate, the four loads of a lane
+     * travel together (a lane without a candidate reads the chunk's first bytes: one address for all of them). Three
+     * candidates in four are hash collisions and stop here; half of the rest end inside these bytes and are measured by
+     * them, growth backwards included */
+    pr.cbytes[k] = wave::gload_u32x3(src + (has ? pr.cand[k] - 4 : 0u));
   }
 }
 
@@ -339,15 +341,26 @@ __device__ __forceinline__ uint32_t encode_chunk(
     probe_step<Emitter>(pr, im, src, n, table, ip, last_start);
     while (ip <= last_start) {
       LZM_T(0);
-      /* ---- the step's hits: the candidates that hold the position's word (the loads were requested a step ago) ---- */
-      uint32_t cand[kSub];
-      bool ok[kSub];
+      /* ---- the step's hits: the candidates that hold the position's word (the loads were requested a step ago). A hit
+       * that ends within its first eight bytes is measured by that; the others wait for the queue ---- */
+      uint32_t cand[kSub], mlen[kSub];
+      uint32_t back = 0; /* four bits a sub-window: the bytes a hit may grow backwards */
+      bool ok[kSub], longer[kSub];
       uint64_t hits[kSub];
-      uint32_t total_hits = 0;
+      uint32_t total_hits = 0, total_long = 0;
 #pragma unroll
       for (uint32_t k = 0; k < kSub; ++k) {
+        const uint32_t rel = 64 * k + lane;
         cand[k] = pr.cand[k];
-        ok[k] = ((pr.flags >> k) & 1u) != 0 && 64 * k + lane >= skip && (((pr.flags >> (4 + k)) & 1u) != 0 || pr.cword[k] == pr.word[k]);
+        const wave::u32x3 mine = image_u96(image, ip + rel - 4);
+        const uint32_t xb = mine.x ^ pr.cbytes[k].x, xw = mine.y ^ pr.cbytes[k].y, xf = mine.z ^ pr.cbytes[k].z;
+        ok[k] = ((pr.has >> k) & 1u) != 0 && rel >= skip && xw == 0;
+        const uint32_t room = match_end - (ip + rel);
+        uint32_t len = xf ? 4 + ((uint32_t)__builtin_ctz(xf) >> 3) : 8u;
+        len = len < room ? len : room;
+        longer[k] = ok[k] && xf == 0 && room > 8;
+        mlen[k] = ok[k] ? len : 0u;
+        back |= (xb ? (uint32_t)__builtin_clz(xb) >> 3 : 4u) << (4 * k);
         hits[k] = wave::ballot(ok[k]);
         total_hits += wave::popc64(hits[k]);
       }
@@ -399,22 +412,24 @@ __device__ __forceinline__ uint32_t encode_chunk(
       }
       LZM_T(3);
 
-      /* ---- measure the hits, 64 at a time: compacted into a queue, the first two batches' candidate sides requested ---- */
+      /* ---- the hits that are still open after eight bytes, compacted into a queue, are measured 64 at a time ---- */
       {
         uint32_t base = 0;
 #pragma unroll
         for (uint32_t k = 0; k < kSub; ++k) {
-          if (ok[k]) {
+          const uint64_t lm = wave::ballot(longer[k]);
+          if (longer[k]) {
             const uint32_t rel = 64 * k + lane;
-            queue[base + wave::prefix_popc(hits[k])] = rel | ((ip + rel - cand[k]) << 8);
+            queue[base + wave::prefix_popc(lm)] = rel | ((ip + rel - cand[k]) << 8);
           }
-          base += wave::popc64(hits[k]);
+          base += wave::popc64(lm);
         }
+        total_long = base;
         wave::sync_wave();
       }
 #if NVCOMP_LZMW_EARLY_REQUEST
       /* the first batch's candidate sides are requested in front of the next step's probe and looked at behind it */
-      const bool early_act = lane < total_hits;
+      const bool early_act = lane < total_long;
       const uint32_t early_e = early_act ? queue[lane] : 8u << 8;
       const uint32_t early_p = early_act ? ip + (early_e & 255u) : ip + 8;
       const Pending early = measure_request(src, n, early_p, early_p - (early_e >> 8), early_act);
@@ -433,11 +448,11 @@ __device__ __forceinline__ uint32_t encode_chunk(
 #if NVCOMP_LZMW_EARLY_REQUEST
       {
         Pending m = early;
-        for (uint32_t b0 = 0; b0 < total_hits; b0 += 64) {
-          const bool more = b0 + 64 < total_hits;
+        for (uint32_t b0 = 0; b0 < total_long; b0 += 64) {
+          const bool more = b0 + 64 < total_long;
           Pending mn = m;
           if (more) { /* the next batch travels while this one is looked at */
-            const bool act = b0 + 64 + lane < total_hits;
+            const bool act = b0 + 64 + lane < total_long;
             const uint32_t e = act ? queue[b0 + 64 + lane] : 8u << 8;
             const uint32_t p = act ? ip + (e & 255u) : ip + 8;
             mn = measure_request(src, n, p, p - (e >> 8), act);
@@ -451,15 +466,15 @@ __device__ __forceinline__ uint32_t encode_chunk(
       }
 #else
       /* two batches a round: their loads travel together */
-      for (uint32_t b0 = 0; b0 < total_hits; b0 += 128) {
-        const bool act0 = b0 + lane < total_hits, act1 = b0 + 64 + lane < total_hits;
+      for (uint32_t b0 = 0; b0 < total_long; b0 += 128) {
+        const bool act0 = b0 + lane < total_long, act1 = b0 + 64 + lane < total_long;
         const uint32_t e0 = act0 ? queue[b0 + lane] : 8u << 8;
         const uint32_t e1 = act1 ? queue[b0 + 64 + lane] : 8u << 8;
         const uint32_t rel0 = e0 & 255u, rel1 = e1 & 255u;
         const uint32_t p0 = act0 ? ip + rel0 : ip + 8, p1 = act1 ? ip + rel1 : ip + 8;
         const Pending m0 = measure_request(src, n, p0, p0 - (e0 >> 8), act0);
         uint32_t r1 = 0;
-        if (b0 + 64 < total_hits) {
+        if (b0 + 64 < total_long) {
           const Pending m1 = measure_request(src, n, p1, p1 - (e1 >> 8), act1);
           r1 = measure_finish(src, n, image, m1, match_end);
         }
@@ -473,12 +488,12 @@ __device__ __forceinline__ uint32_t encode_chunk(
       }
 #endif
       wave::sync_wave();
-      uint32_t mlen[kSub];
       uint64_t capped[kSub];
 #pragma unroll
       for (uint32_t k = 0; k < kSub; ++k) {
-        const uint32_t r = ok[k] ? results[64 * k + lane] : 0u;
-        mlen[k] = r & 31u;
+        if (longer[k]) {
+          mlen[k] = results[64 * k + lane];
+        }
         hits[k] = wave::ballot(mlen[k] != 0);
         capped[k] = wave::ballot(mlen[k] >= kCap);
       }
@@ -516,7 +531,7 @@ __device__ __forceinline__ uint32_t encode_chunk(
             if ((sel[k] >> lane) & 1) {
               const uint32_t rel = 64 * k + lane;
               const uint32_t at = base + wave::prefix_popc(sel[k]);
-              queue[2 * at] = rel | ((uint32_t)(results[rel] >> 5) << 8) | ((ip + rel - cand[k]) << 16);
+              queue[2 * at] = rel | (((back >> (4 * k)) & 7u) << 8) | ((ip + rel - cand[k]) << 16);
               queue[2 * at + 1] = mlen[k];
             }
             base += wave::popc64(sel[k]);

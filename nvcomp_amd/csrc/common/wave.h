@@ -54,6 +54,21 @@ __device__ __forceinline__ u32x4 gload_u32x4(const uint8_t* p) /* any alignment 
   return r;
 }
 
+struct __attribute__((packed)) PackedU32x3
+{
+  uint32_t v[3];
+};
+struct u32x3
+{
+  uint32_t x, y, z;
+};
+__device__ __forceinline__ u32x3 gload_u32x3(const uint8_t* p) /* any alignment (global_load_dwordx3) */
+{
+  const WAVE_GLOBAL PackedU32x3* q = (const WAVE_GLOBAL PackedU32x3*)p;
+  u32x3 r = {q->v[0], q->v[1], q->v[2]};
+  return r;
+}
+
 __device__ __forceinline__ uint64_t gload_u64(const uint8_t* p) /* any alignment (global_load_dwordx2) */
 {
   const WAVE_GLOBAL PackedU32x2* q = (const WAVE_GLOBAL PackedU32x2*)p;

@@ -146,6 +146,16 @@ inline u32x4 gload_u32x4(const uint8_t* p)
   memcpy(&v, p, 16);
   return v;
 }
+struct u32x3
+{
+  uint32_t x, y, z;
+};
+inline u32x3 gload_u32x3(const uint8_t* p)
+{
+  u32x3 v;
+  memcpy(&v, p, 12);
+  return v;
+}
 inline uint64_t gload_u64(const uint8_t* p)
 {
   uint64_t v;
