@@ -32,6 +32,31 @@ nvcompStatus_t nvcompAmdBatchedPackAsync(
     size_t* device_offsets,
     hipStream_t stream);
 
+/* The order in which nvcompBatched{LZ4,Snappy}DecompressAsync hands the chunks of a batch to its persistent waves when
+ * the batch is large enough for them (more chunks than waves stay resident) and the temp buffer has the size
+ * nvcompBatched<Fmt>DecompressGetTempSize reports: the chunks that will take longest first. The cost of a chunk is
+ * estimated from the first tokens of its stream. Exposed for inspection and tests: after the call (on `stream`)
+ * `device_order[0 .. batch_size)` is a permutation of the chunk indices and `device_cost_class[i]` the class (0 ... 15,
+ * a power-of-two scale of the estimated sequence count) of chunk i. `device_temp_ptr` as for the decompress call. */
+nvcompStatus_t nvcompAmdBatchedLZ4DecompressOrderAsync(
+    const void* const* device_compressed_ptrs,
+    const size_t* device_compressed_bytes,
+    size_t batch_size,
+    void* device_temp_ptr,
+    size_t temp_bytes,
+    unsigned* device_order,
+    unsigned char* device_cost_class,
+    hipStream_t stream);
+nvcompStatus_t nvcompAmdBatchedSnappyDecompressOrderAsync(
+    const void* const* device_compressed_ptrs,
+    const size_t* device_compressed_bytes,
+    size_t batch_size,
+    void* device_temp_ptr,
+    size_t temp_bytes,
+    unsigned* device_order,
+    unsigned char* device_cost_class,
+    hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

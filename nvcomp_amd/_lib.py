@@ -123,6 +123,10 @@ def declare(lib: C.CDLL, formats=FORMATS) -> C.CDLL:
             getattr(lib, "nvcompBatchedGzip" + name).restype = C.c_int
     if hasattr(lib, "nvcompAmdBatchedPackAsync"):  # include/nvcomp/amd_ext.h
         lib.nvcompAmdBatchedPackAsync.argtypes = [vp, vp, sz, vp, sz, vp, vp]
+    for fmt in ("LZ4", "Snappy"):
+        fn = getattr(lib, f"nvcompAmdBatched{fmt}DecompressOrderAsync", None)
+        if fn is not None:
+            fn.argtypes, fn.restype = [vp, vp, sz, vp, sz, vp, vp, vp], C.c_int
     return lib
 
 

@@ -9,12 +9,15 @@
 
 #include "nvcomp/snappy.h"
 
+#include "nvcomp/amd_ext.h"
+
 #include "common/log.h"
 
 #include "common/lz_launch.hip.h"
 #include "snappy/snappy_decode.hip.h"
 #include "snappy/snappy_decode_window.hip.h"
 #include "common/lz_team.hip.h"
+#include "common/lz_order.hip.h"
 #include "snappy/snappy_encode.hip.h"
 
 namespace {
@@ -76,20 +79,22 @@ __global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_WAVES_PER_SIMD) sna
 {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kDecWaves][lzw::kLdsPerWave];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
-  size_t chunk = (size_t)blockIdx.x * kDecWaves + w;
+  size_t place = (size_t)blockIdx.x * kDecWaves + w; /* the wave's place in the launch: chunk order[place] */
   for (;;) {
     /* the arguments are read where they are used, not held in scalar registers across the decode (wave::kernel_args) */
     const auto* a = wave::kernel_args(launch);
-    if (chunk >= a->b.batch_size) {
+    if (place >= a->b.batch_size) {
       break;
     }
+    const uint32_t* order = a->order;
+    const size_t chunk = order != nullptr ? (size_t)wave::uniform(order[place]) : place;
     decode_one<CHECKED>(&a->b, chunk, lds[w]);
     a = wave::kernel_args(launch);
     uint32_t* ticket = a->ticket;
     if (ticket == nullptr) {
       break;
     }
-    chunk = lzl::next_chunk(ticket, a->first_dynamic);
+    place = lzl::next_chunk(ticket, a->first_dynamic);
   }
 }
 
@@ -310,7 +315,7 @@ nvcompStatus_t nvcompBatchedSnappyDecompressGetTempSize(
   }
   /* the ticket counter of the persistent waves / workgroups (common/lz_launch.hip.h); the decoder itself keeps all state in
    * registers and LDS */
-  *temp_bytes = num_chunks != 0 ? lzl::kTicketBytes : 0;
+  *temp_bytes = num_chunks == 0 ? 0 : num_chunks > lzl::kPairMaxBatch && NVCOMP_LZ_ORDERED ? lzo::temp_bytes(num_chunks) : lzl::kTicketBytes;
   return nvcompSuccess;
 }
 
@@ -356,7 +361,7 @@ nvcompStatus_t nvcompBatchedSnappyDecompressAsync(
   if (batch_size <= lzl::kTeamMaxBatch) {
     unsigned groups = (unsigned)batch_size;
     uint32_t* ticket = nullptr;
-    const lzl::Launch one_each = {b, nullptr, (size_t)groups};
+    const lzl::Launch one_each = {b, nullptr, (size_t)groups, nullptr};
     if (batch_size <= lzl::kTeam16MaxBatch) {
       /* at most one chunk per CU: sixteen waves a chunk (one team holds a whole CU's LDS budget for two) */
       hipLaunchKernelGGL((snappy_decompress_team_kernel<true, 16>), dim3(groups), dim3(1024), 0, stream, one_each);
@@ -370,7 +375,7 @@ nvcompStatus_t nvcompBatchedSnappyDecompressAsync(
         groups = fit;
       }
     }
-    const lzl::Launch launch = {b, ticket, (size_t)groups};
+    const lzl::Launch launch = {b, ticket, (size_t)groups, nullptr};
     hipLaunchKernelGGL((snappy_decompress_team_kernel<true, 8>), dim3(groups), dim3(512), 0, stream, launch);
     return launch_status();
   }
@@ -393,9 +398,30 @@ nvcompStatus_t nvcompBatchedSnappyDecompressAsync(
     }
   }
 #endif
-  const lzl::Launch launch = {b, ticket, (size_t)groups * kDecWaves};
+  /* ... and the expensive chunks first (common/lz_order.hip.h), when the temp buffer has room for the order */
+  const uint32_t* order = nullptr;
+  if (ticket != nullptr && NVCOMP_LZ_ORDERED) {
+    order = lzo::make_order<lzo::SnappyCost>(b, device_temp_ptr, temp_bytes, stream);
+  }
+  const lzl::Launch launch = {b, ticket, (size_t)groups * kDecWaves, order};
   hipLaunchKernelGGL((snappy_decompress_window_kernel<true>), dim3(groups), dim3(64 * kDecWaves), 0, stream, launch);
   return launch_status();
+}
+
+nvcompStatus_t nvcompAmdBatchedSnappyDecompressOrderAsync(
+    const void* const* device_compressed_ptrs,
+    const size_t* device_compressed_bytes,
+    size_t batch_size,
+    void* device_temp_ptr,
+    size_t temp_bytes,
+    unsigned* device_order,
+    unsigned char* device_cost_class,
+    hipStream_t stream)
+{
+  clear_stale_error();
+  const nvcompStatus_t st = lzo::order_for_inspection<lzo::SnappyCost>(
+      device_compressed_ptrs, device_compressed_bytes, batch_size, device_temp_ptr, temp_bytes, device_order, device_cost_class, stream);
+  return st != nvcompSuccess ? st : launch_status();
 }
 
 nvcompStatus_t nvcompBatchedSnappyGetDecompressSizeAsync(

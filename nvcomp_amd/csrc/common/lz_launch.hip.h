@@ -42,6 +42,13 @@
                                    * 750): 28 waves per CU already keep the vector, scalar and LDS pipes two thirds busy, four more
                                    * only add contention for L1 / L2 and the LDS pipe; 6 is worse again (607). */
 #endif
+#ifndef NVCOMP_LZ_ORDERED
+#define NVCOMP_LZ_ORDERED 0 /* 1: the persistent waves take the expensive chunks first (common/lz_order.hip.h). Built, parity-green and
+                             * measured in round 5 (gpurun r5j, mix, ordered against the caller's order): 65 536 chunks 676 = 675,
+                             * 32 768: 613 = 615, 16 384: 529 against 512 (+3 %), 8 192: 432 against 458 (-6 %), uniform text and the
+                             * sorted-key column -6 ... -7 % (the two kernels in front cost ~0.1 ms): the end of a launch is not
+                             * where medium batches lose their time. Off. */
+#endif
 #ifndef NVCOMP_LZ_PERSISTENT
 #define NVCOMP_LZ_PERSISTENT 1 /* A/B: 0 = one wave per chunk, static mapping (round 2) */
 #endif
@@ -73,6 +80,7 @@ struct Launch
   Batch b;
   uint32_t* ticket;
   size_t first_dynamic;
+  const uint32_t* order; /* place in the launch -> chunk (common/lz_order.hip.h: expensive chunks first); NULL: the caller's order */
 };
 
 /* The same for the compressors: the caller's arrays of one nvcompBatched<Fmt>CompressAsync call. */

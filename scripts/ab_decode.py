@@ -35,6 +35,10 @@ CASES = {
     "mix4m": ("LZ4", "silesia_style", "hc", 4, 4),
     "mix1m": ("LZ4", "silesia_style", "hc", 1, 1),
     "snappy_mix": ("Snappy", "silesia_style", "snappy", 64, None),
+    "snappy1g": ("Snappy", "silesia_style", "snappy", 64, 1024),
+    "snappy512m": ("Snappy", "silesia_style", "snappy", 64, 512),
+    "mix2g": ("LZ4", "silesia_style", "hc", 64, 2048),
+    "mix320m": ("LZ4", "silesia_style", "hc", 64, 320),
     "mortgage": ("LZ4", "mortgage_col0_like", "fast", 64, 1024),
     "mortgage5k": ("LZ4", "mortgage_col0_like", "fast", 64, 314),
     "mortgage_hc": ("LZ4", "mortgage_col0_like", "hc", 64, 1024),

@@ -11,7 +11,7 @@ mkdir -p "$OUT"; : > "$OUT/rc.txt"
 timeout 600 python -m pytest tests/test_lz4_encode.py tests/test_snappy.py -m gpu -q -x --timeout 300 > "$OUT/pytest_enc.log" 2>&1; echo "pytest enc rc=$?" >> "$OUT/rc.txt"
 tail -3 "$OUT/pytest_enc.log"
 CASES=${2:-mix,snappy_mix,text,int32,mortgage,noise}
-timeout 1500 python scripts/ab_compress.py --libs nvcomp_amd/lib/libnvcomp.so nvcomp_amd/lib/cab/libnvcomp_*.so \
+timeout 1500 python scripts/ab_compress.py --libs nvcomp_amd/lib/libnvcomp.so $(ls nvcomp_amd/lib/cab/libnvcomp_*.so 2>/dev/null) \
   --cases $CASES --steps 5 --prof --out "$OUT/ab_comp.jsonl" > /dev/null 2> "$OUT/ab_comp.err"; echo "ab comp rc=$?" >> "$OUT/rc.txt"
 python - "$OUT" <<'PY'
 import json, sys, os

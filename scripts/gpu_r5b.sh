@@ -10,7 +10,7 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"; : > "$OUT/rc.txt"
 CASES=${2:-mix,snappy_mix,text,int32,mortgage,noise}
 if [ "$CASES" != none ]; then
-timeout 1500 python scripts/ab_compress.py --libs nvcomp_amd/lib/libnvcomp.so nvcomp_amd/lib/cab/libnvcomp_*.so \
+timeout 1500 python scripts/ab_compress.py --libs nvcomp_amd/lib/libnvcomp.so $(ls nvcomp_amd/lib/cab/libnvcomp_*.so 2>/dev/null) \
   --cases $CASES --steps 5 --prof --out "$OUT/ab_comp.jsonl" > /dev/null 2> "$OUT/ab_comp.err"; echo "ab comp rc=$?" >> "$OUT/rc.txt"
 python - "$OUT" <<'PY'
 import json, sys, os
