@@ -556,3 +556,23 @@ nvcompStatus_t nvcompBatchedCascadedDecompressGetTempSizeEx(
 }
 
 } // extern "C"
+
+#ifdef NVCOMP_CASC_PROF
+/* Profiling builds only: read (and clear) the per-phase cycle sums of the Cascaded decoder. */
+extern "C" int nvcompAmdCascProfRead(unsigned long long* host_slots, int n)
+{
+  static unsigned long long v[casc::kProfSlots * 64];
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(casc::g_prof), sizeof(v)) != hipSuccess) {
+    return -1;
+  }
+  for (int i = 0; i < n && i < (int)casc::kProfSlots; ++i) {
+    host_slots[i] = 0;
+    for (int k = 0; k < 64; ++k) {
+      host_slots[i] += v[i * 64 + k];
+    }
+  }
+  static const unsigned long long z[casc::kProfSlots * 64] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(casc::g_prof), z, sizeof(z));
+  return (int)casc::kProfSlots;
+}
+#endif

@@ -243,6 +243,36 @@ __device__ __forceinline__ bool unpack_stream(const uint8_t* src, uint32_t avail
   /* several tiles per step: their loads are issued together -- one memory round trip instead of one per tile.
    * Elements of up to 4 bytes never straddle three words, so they get 8 tiles in flight for the same registers. */
   constexpr uint32_t kTiles = sizeof(T) <= 4 ? 8 : 4;
+  if (sizeof(T) <= 4 && bits != 0 && bits <= 32 && count != 0) {
+    /* Elements of up to 4 bytes in 32-bit arithmetic throughout (round 5: the unpack was 36 % of the decoder's time on
+     * the float columns, most of it 64-bit multiplies and shifts the values never needed): the element's bit position
+     * is a 24-bit product (count <= 16 384, bits <= 32), its bits come out of two words with one v_alignbit. Both words
+     * are loaded whenever they exist: no lane-dependent branch around the second load. */
+    const uint32_t vmask32 = bits == 32 ? ~0u : ((1u << bits) - 1u);
+    const uint32_t mn32 = (uint32_t)mn;
+    /* no lane-dependent branches: a lane beyond the count works on the last element once more (the same value to the same
+     * place), the second word's index stops at the stream's last word (an element that needs its second word has one) */
+    const uint32_t last = count - 1;
+    for (uint32_t base = 0; base < count; base += 64 * kTiles) {
+      uint32_t lo[kTiles], hi[kTiles];
+#pragma unroll
+      for (uint32_t u = 0; u < kTiles; ++u) {
+        const uint32_t i = base + 64 * u + lane < last ? base + 64 * u + lane : last;
+        const uint32_t k = __umul24(i, bits) >> 5;
+        lo[u] = in[3 + k];
+        hi[u] = in[3 + (k + 1 < words ? k + 1 : k)];
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < kTiles; ++u) {
+        const uint32_t i = base + 64 * u + lane < last ? base + 64 * u + lane : last;
+        const uint32_t sh = __umul24(i, bits) & 31u;
+        const uint32_t x = wave::align_bits(hi[u], lo[u], sh) & vmask32;
+        dst[i] = (T)(x + mn32);
+      }
+    }
+    used = 12 + 4 * words;
+    return true;
+  }
   for (uint32_t base = 0; base < count; base += 64 * kTiles) {
     uint32_t w0[kTiles], w1[kTiles], w2[sizeof(T) <= 4 ? 1 : kTiles];
 #pragma unroll
@@ -648,6 +678,30 @@ __device__ __forceinline__ bool rle_expand_inplace(T* A, const uint32_t* packed,
   return above == target;
 }
 
+/* ---- phase clock (profiling builds only: -DNVCOMP_CASC_PROF) ---- */
+#ifdef NVCOMP_CASC_PROF
+constexpr uint32_t kProfSlots = 12;
+__device__ unsigned long long g_prof[kProfSlots * 64]; /* 64 copies of every slot: the atomics of 8 000 waves on one word would be the profile */
+struct ProfClock
+{
+  unsigned long long last;
+  __device__ __forceinline__ void begin() { last = __builtin_readcyclecounter(); }
+  __device__ __forceinline__ void mark(uint32_t slot)
+  {
+    const unsigned long long t = __builtin_readcyclecounter();
+    if (wave::lane_id() == 0) {
+      atomicAdd(&g_prof[slot * 64 + (blockIdx.x & 63u)], t - last);
+    }
+    last = __builtin_readcyclecounter();
+  }
+};
+#define CASC_PROF_DECL casc::ProfClock prof_clock; prof_clock.begin()
+#define CASC_T(slot) prof_clock.mark(slot)
+#else
+#define CASC_PROF_DECL ((void)0)
+#define CASC_T(slot) ((void)0)
+#endif
+
 /* ---- sub-chunk codec ------------------------------------------------------- */
 
 constexpr uint32_t kSubNeedsLds = 0xffffffffu; /* compress_sub: the streams do not fit the LDS slice it was given */
@@ -702,16 +756,21 @@ __device__ __forceinline__ uint32_t compress_sub(
   const T* cur = in; /* HBM until layer 0 (or a delta) has put the data into V */
   for (uint32_t l = 0; l < layers && !raw; ++l) {
     if (l < rl) {
-      const uint32_t m = rle_encode(cur, c, V, pool, pool_cap, can_skip);
-      bool id;
-      if (m == kRleOverflow) {
-        /* a partial compaction may have overwritten the head of V: only an input still in HBM can be recounted */
-        if (!(can_skip && cur == in && count_heads(cur, c) == c)) {
+      /* A layer that would take out fewer than one element in eight is left out: its values pass through, every run
+       * length is 1 (a legal run-length stream; with bit-packing it is just a header). Such a layer saves next to nothing
+       * and costs the decoder a full expansion -- on smooth float columns, where two sub-chunks in five have a few equal
+       * neighbours, the two expansions were 42 % of the decoder's time (phase clock, round 5). The heads are counted
+       * first: the compaction works in place and cannot be undone. */
+      bool id = false;
+      if (can_skip) {
+        const uint32_t heads = count_heads(cur, c);
+        id = heads + (c >> 3) > c;
+      }
+      if (!id) {
+        const uint32_t m = rle_encode(cur, c, V, pool, pool_cap);
+        if (m == kRleOverflow) {
           return kSubNeedsLds;
         }
-        id = true;
-      } else {
-        id = can_skip && m == c; /* no runs: V holds the values unchanged, the runs (all 1) are dropped */
         cur = V;
         c = m;
       }
@@ -809,6 +868,7 @@ __device__ __forceinline__ uint32_t decompress_sub(
   const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   const uint32_t w = sizeof(T);
   const uint32_t n = bytes / w;
+  CASC_PROF_DECL;
   if (avail < 4) {
     return kSubBad;
   }
@@ -829,15 +889,16 @@ __device__ __forceinline__ uint32_t decompress_sub(
   if (first != n || avail < 4 + 4 * num_rles) {
     return kSubBad;
   }
-  LayerMeta* meta = (LayerMeta*)lds;
-  uint32_t* counts = meta->counts;
-  uint32_t* run_off = meta->run_off;
-  uint32_t* ident = meta->ident;
-  uint32_t* src_off = meta->src_off;
-  const uint32_t meta_bytes = align16((uint32_t)sizeof(LayerMeta));
-  if (budget < meta_bytes) {
-    return kSubNeedLds;
-  }
+  /* The layer table -- counts, run-pool offsets, identity flags, stream offsets, one entry per RLE layer -- lives in four
+   * vector registers, entry l in lane l (v_readlane / v_writelane with the wave-uniform layer number): private arrays
+   * indexed at run time would go to scratch memory, and until round 5 the table sat in LDS (a dependent LDS round trip
+   * per look-up, two fences per sub-chunk: 15 % of the decoder's time went into this prologue). */
+  uint32_t counts_v = 0, run_off_v = 0, ident_v = 0, src_off_v = 0;
+  auto counts = [&](uint32_t l) { return wave::read_lane(counts_v, l); };
+  auto run_off = [&](uint32_t l) { return wave::read_lane(run_off_v, l); };
+  auto ident = [&](uint32_t l) { return wave::read_lane(ident_v, l); };
+  auto src_off = [&](uint32_t l) { return wave::read_lane(src_off_v, l); };
+  constexpr uint32_t meta_bytes = 0;
   uint32_t pos = 4;
   uint32_t prev = n;
   for (uint32_t l = 0; l < num_rles; ++l) {
@@ -847,11 +908,8 @@ __device__ __forceinline__ uint32_t decompress_sub(
       return kSubBad;
     }
     prev = cl;
-    if (lane == 0) {
-      counts[l] = cl;
-    }
+    counts_v = wave::write_lane(counts_v, cl, l);
   }
-  wave::sync();
   /* walk the run-stream headers: a layer whose runs are all 1 (bits 0, minimum 1, as many runs as outputs) is the
    * identity -- its values pass through and it needs neither its runs nor an expansion buffer */
   uint32_t pool_used = 0;    /* run entries that must be unpacked */
@@ -868,19 +926,17 @@ __device__ __forceinline__ uint32_t decompress_sub(
     if (bits > 64) {
       return kSubBad;
     }
-    const uint32_t cl = counts[l];
-    const uint32_t target = l == 0 ? n : counts[l - 1];
+    const uint32_t cl = counts(l);
+    const uint32_t target = l == 0 ? n : counts(l - 1);
     const uint64_t words = ((uint64_t)cl * bits + 31) / 32;
     if ((avail - pos - 12) / 4 < words) {
       return kSubBad;
     }
     const bool id = bits == 0 && mn_lo == 1 && mn_hi == 0 && cl == target;
     all_short = all_short && (id || runs_are_short(bits, mn_lo, mn_hi));
-    if (lane == 0) {
-      ident[l] = id ? 1u : 0u;
-      src_off[l] = pos;
-      run_off[l] = pool_used;
-    }
+    ident_v = wave::write_lane(ident_v, id ? 1u : 0u, l);
+    src_off_v = wave::write_lane(src_off_v, pos, l);
+    run_off_v = wave::write_lane(run_off_v, pool_used, l);
     if (!id) {
       pool_used += cl;
       inner_real += l > 0 ? 1u : 0u;
@@ -891,7 +947,7 @@ __device__ __forceinline__ uint32_t decompress_sub(
   wave::sync();
   /* value buffers: the outermost expanding layer writes to HBM when it is layer 0, so a buffer holds at most
    * counts[0] elements then; without that it holds the n elements of the sub-chunk */
-  const bool outer_to_hbm = num_rles != 0 && ident[0] == 0;
+  const bool outer_to_hbm = num_rles != 0 && ident(0) == 0;
   /* all runs short: one value buffer, expanded in place, no pool, no marks */
   const bool direct = all_short && pool_used != 0;
   if (direct) {
@@ -899,7 +955,7 @@ __device__ __forceinline__ uint32_t decompress_sub(
     marks_elems = 0;
     inner_real = 0;
   }
-  const uint32_t top = outer_to_hbm ? counts[0] : n;
+  const uint32_t top = outer_to_hbm ? counts(0) : n;
   const uint32_t val_bytes = align16(top * w);
   const uint32_t n_bufs = inner_real ? 2u : 1u;
   const uint32_t pool_bytes = align16(2 * pool_used);
@@ -907,20 +963,22 @@ __device__ __forceinline__ uint32_t decompress_sub(
   if ((uint64_t)meta_bytes + (uint64_t)n_bufs * val_bytes + pool_bytes + marks_bytes > budget) {
     return kSubNeedLds;
   }
+  CASC_T(0); /* headers, layer table, LDS plan */
   T* A = (T*)(lds + meta_bytes);
   T* B = (T*)(lds + meta_bytes + val_bytes); /* only touched when n_bufs == 2 */
   uint16_t* pool = (uint16_t*)(lds + meta_bytes + n_bufs * val_bytes);
   uint16_t* marks = (uint16_t*)(lds + meta_bytes + n_bufs * val_bytes + pool_bytes);
   for (uint32_t l = 0; l < num_rles; ++l) {
-    if (ident[l] || direct) {
+    if (ident(l) || direct) {
       continue;
     }
     uint32_t used;
-    if (!unpack_stream<uint16_t>(src + src_off[l], avail - src_off[l], pool + run_off[l], counts[l], 2, used)) {
+    if (!unpack_stream<uint16_t>(src + src_off(l), avail - src_off(l), pool + run_off(l), counts(l), 2, used)) {
       return kSubBad;
     }
   }
-  uint32_t c = num_rles ? counts[num_rles - 1] : n;
+  CASC_T(1); /* run pools unpacked */
+  uint32_t c = num_rles ? counts(num_rles - 1) : n;
   {
     uint32_t used;
     if (!unpack_stream<T>(src + pos, avail - pos, A, c, w, used)) {
@@ -928,6 +986,7 @@ __device__ __forceinline__ uint32_t decompress_sub(
     }
   }
   wave::sync();
+  CASC_T(2); /* values unpacked */
   const uint32_t layers = num_rles > num_deltas ? num_rles : num_deltas;
   T* cur = A;
   T* oth = B;
@@ -935,12 +994,13 @@ __device__ __forceinline__ uint32_t decompress_sub(
   for (uint32_t l = layers; l-- > 0;) {
     if (l < num_deltas) {
       delta_decode(cur, c);
+      CASC_T(3); /* delta */
     }
-    if (l < num_rles && !ident[l]) {
-      const uint32_t target = l == 0 ? n : counts[l - 1];
+    if (l < num_rles && !ident(l)) {
+      const uint32_t target = l == 0 ? n : counts(l - 1);
       /* layer 0 writes the sub-chunk itself */
       if (direct) {
-        const uint32_t so = src_off[l];
+        const uint32_t so = src_off(l);
         const uint32_t bits = word_at(so);
         const uint32_t mn = word_at(so + 4);
         const uint32_t* packed = (const uint32_t*)(src + so + 12);
@@ -950,9 +1010,10 @@ __device__ __forceinline__ uint32_t decompress_sub(
         }
         in_hbm = l == 0;
         c = target;
+        CASC_T(4 + (l == 0 ? 1 : 0)); /* direct expansion: inner layers / the outermost one (to memory) */
         continue;
       }
-      if (!rle_decode(cur, pool + run_off[l], c, l == 0 ? (T*)dst : oth, target, marks)) {
+      if (!rle_decode(cur, pool + run_off(l), c, l == 0 ? (T*)dst : oth, target, marks)) {
         return kSubBad;
       }
       in_hbm = l == 0;
@@ -960,6 +1021,7 @@ __device__ __forceinline__ uint32_t decompress_sub(
       T* t = cur;
       cur = oth;
       oth = t;
+      CASC_T(6); /* pool + marks expansion */
     }
   }
   if (!in_hbm) {
@@ -968,6 +1030,7 @@ __device__ __forceinline__ uint32_t decompress_sub(
       out[i] = cur[i];
     }
   }
+  CASC_T(7); /* copy out */
   return kSubOk;
 }
 

@@ -409,6 +409,19 @@ __device__ __forceinline__ uint32_t popc64(uint64_t m)
   return (uint32_t)__builtin_popcountll(m);
 }
 
+/* "This value is used here": a loaded register whose only purpose was to bring its cache line closer (there is no
+ * prefetch instruction on gfx950) is waited for at this point and nowhere earlier; no instruction is emitted. */
+__device__ __forceinline__ void keep(uint32_t v)
+{
+  asm volatile("" : : "v"(v));
+}
+
+/* (hi:lo) >> shift, low 32 bits, shift = 0 ... 31 (v_alignbit_b32). */
+__device__ __forceinline__ uint32_t align_bits(uint32_t hi, uint32_t lo, uint32_t shift)
+{
+  return __builtin_amdgcn_alignbit(hi, lo, shift);
+}
+
 /* Bytes [shift, shift + 4) of the 8-byte value hi:lo, shift in 0..3 (v_alignbyte_b32). */
 __device__ __forceinline__ uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t shift)
 {

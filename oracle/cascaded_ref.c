@@ -241,8 +241,16 @@ size_t oracle_cascaded_compress(
             runs[l][m - 1]++;
           }
         }
-        memcpy(vals, tmp, sizeof(uint64_t) * m);
-        c = m;
+        /* a layer that would take out fewer than one element in eight is left out (bit-packed streams only, where a
+         * stream of ones is just a header): the values pass through, every run length is 1 */
+        if (use_bp && m + (c >> 3) > c) {
+          for (uint32_t i = 0; i < c; ++i) {
+            runs[l][i] = 1;
+          }
+        } else {
+          memcpy(vals, tmp, sizeof(uint64_t) * m);
+          c = m;
+        }
         counts[l] = c;
       }
       if (l < num_deltas) {
