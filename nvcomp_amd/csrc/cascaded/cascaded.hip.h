@@ -192,7 +192,7 @@ __device__ __forceinline__ uint32_t pack_stream(uint8_t* dst, const S& s, uint32
     for (uint32_t k = lane; k < words; k += 64) {
       const uint32_t bit0 = 32 * k;
       uint32_t e = bits > 1 ? __umulhi(bit0, recip) : bit0;
-      int32_t rel = (int32_t)(e * bits) - (int32_t)bit0; /* in (-bits, 0] */
+      int32_t rel = (int32_t)wave::mul24(e, bits) - (int32_t)bit0; /* in (-bits, 0] */
       uint32_t word = 0;
       for (; rel < 32 && e < count; ++e, rel += (int32_t)bits) {
         const uint32_t x = (s.get32(e) - mn32) & vmask;
@@ -258,14 +258,14 @@ __device__ __forceinline__ bool unpack_stream(const uint8_t* src, uint32_t avail
 #pragma unroll
       for (uint32_t u = 0; u < kTiles; ++u) {
         const uint32_t i = base + 64 * u + lane < last ? base + 64 * u + lane : last;
-        const uint32_t k = __umul24(i, bits) >> 5;
+        const uint32_t k = wave::mul24(i, bits) >> 5;
         lo[u] = in[3 + k];
         hi[u] = in[3 + (k + 1 < words ? k + 1 : k)];
       }
 #pragma unroll
       for (uint32_t u = 0; u < kTiles; ++u) {
         const uint32_t i = base + 64 * u + lane < last ? base + 64 * u + lane : last;
-        const uint32_t sh = __umul24(i, bits) & 31u;
+        const uint32_t sh = wave::mul24(i, bits) & 31u;
         const uint32_t x = wave::align_bits(hi[u], lo[u], sh) & vmask32;
         dst[i] = (T)(x + mn32);
       }
@@ -600,7 +600,7 @@ __device__ __forceinline__ void load_short_runs(const T* A, const uint32_t* pack
   const uint32_t mask = (1u << bits) - 1u;
   uint64_t v = 0;
   if (bits && j0 < c) {
-    const uint32_t bit = j0 * bits;
+    const uint32_t bit = wave::mul24(j0, bits);
     const uint32_t k = bit >> 5;
     const uint32_t lo = packed[k];
     const uint32_t hi = k + 1 < words ? packed[k + 1] : 0u;

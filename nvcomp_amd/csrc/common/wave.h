@@ -416,6 +416,15 @@ __device__ __forceinline__ void keep(uint32_t v)
   asm volatile("" : : "v"(v));
 }
 
+/* a * b for operands below 2^24 (v_mul_u32_u24: full rate; a 32-bit v_mul_lo_u32 takes four times as long, and
+ * __umul24 compiles to a mask and that). */
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b)
+{
+  uint32_t r;
+  asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 /* (hi:lo) >> shift, low 32 bits, shift = 0 ... 31 (v_alignbit_b32). */
 __device__ __forceinline__ uint32_t align_bits(uint32_t hi, uint32_t lo, uint32_t shift)
 {
