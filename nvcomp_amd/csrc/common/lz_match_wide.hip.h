@@ -267,11 +267,29 @@ __device__ __forceinline__ void probe_step(
   const uint32_t lane = (uint32_t)wave::lane_id();
   uint8_t* image = im.base;
   image_ensure(im, src, n, ip / kBlock);
-  uint32_t word[kSub], slot[kSub];
+  /* the word at the position, and whether it stands 1, 2, 4 or 8 bytes back as well (runs, typed columns): the twelve bytes
+   * from 8 before the position on come out of the image as four aligned dwords, the five words are byte alignments of
+   * neighbouring pairs. (Until the middle of round 5 the repeats were found by comparing with the neighbouring lanes'
+   * words: seven or eight cross-lane fetches per sub-window through the LDS crossbar.) */
+  uint32_t word[kSub], slot[kSub], near[kSub];
 #pragma unroll
   for (uint32_t k = 0; k < kSub; ++k) {
-    word[k] = image_u32(image, ip + 64 * k + lane);
-    slot[k] = hashw(word[k]);
+    const uint32_t pos = ip + 64 * k + lane;
+    const uint32_t o = (pos - 8u) & (kRing - 1);
+    const uint32_t* q = (const uint32_t*)(image + (o & ~3u));
+    const uint32_t qa = q[0], qb = q[1], qc = q[2], qd = q[3]; /* bytes [A - 8, A + 8), A = the position's dword */
+    const uint32_t sh = pos & 3u;
+    word[k] = wave::align_bytes(qd, qc, sh);
+    const uint32_t w4 = wave::align_bytes(qc, qb, sh), w8 = wave::align_bytes(qb, qa, sh);
+    const uint32_t w1 = wave::align_bytes(sh >= 1 ? qd : qc, sh >= 1 ? qc : qb, sh + 3u);
+    const uint32_t w2 = wave::align_bytes(sh >= 2 ? qd : qc, sh >= 2 ? qc : qb, sh + 2u);
+    const uint32_t w = word[k];
+    uint32_t d = w8 == w ? 8u : 0u;
+    d = w4 == w ? 4u : d;
+    d = w2 == w ? 2u : d;
+    d = w1 == w ? 1u : d;
+    near[k] = pos >= 8 ? d : 0u; /* (the chunk's first eight positions have nothing 8 bytes back) */
+    slot[k] = hashw(w);
   }
   /* table entry -> candidate, then this sub-window's positions go in: the LDS serves a wave's accesses in issue order, so
    * that the next sub-window's probe sees them without a wait */
@@ -290,21 +308,8 @@ __device__ __forceinline__ void probe_step(
 #pragma unroll
   for (uint32_t k = 0; k < kSub; ++k) {
     const uint32_t pos = ip + 64 * k + lane;
-    /* repeats 1, 2, 4, 8 bytes back: the lower lanes of the sub-window, or the upper lanes of the one before */
-    uint32_t near = 0;
-#pragma unroll
-    for (uint32_t d = 1; d <= 8; d *= 2) {
-      uint32_t other = wave::shuffle(word[k], (lane - d) & 63u);
-      bool have = lane >= d;
-      if (k > 0) {
-        const uint32_t before = wave::shuffle(word[k - 1], (lane - d) & 63u);
-        other = lane >= d ? other : before;
-        have = true;
-      }
-      near = (near == 0 && have && other == word[k]) ? d : near;
-    }
-    pr.cand[k] = near ? pos - near : pr.cand[k];
-    const bool has = (ok[k] || near != 0) && pos <= last_start && pr.cand[k] >= 4 && pr.cand[k] + 8 <= n;
+    pr.cand[k] = near[k] ? pos - near[k] : pr.cand[k];
+    const bool has = (ok[k] || near[k] != 0) && pos <= last_start && pr.cand[k] >= 4 && pr.cand[k] + 8 <= n;
     pr.has |= has ? 1u << k : 0u;
     /* word check: the candidate's bytes [c - 4, c + 8), ONE load per position with a candidate, the four loads of a lane
      * travel together (a lane without a candidate reads the chunk's first bytes: one address for all of them). Three

@@ -32,6 +32,10 @@
  */
 #pragma once
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "common/lz_team.hip.h: the workgroup-per-chunk decoders hold a chunk's output and stream in 79-91 KB of static LDS: gfx950 (160 KB per CU) only"
+#endif
+
 #include "common/lz_window.hip.h"
 
 namespace lzt {
@@ -312,6 +316,13 @@ __device__ __forceinline__ uint32_t decode_chunk(
     return 0;
   }
   uint8_t* fb_scratch = lds + kBufLds;
+  if (out_cap > kMaxOut && in_len <= kMaxIn) {
+    /* a generous capacity: what counts is what the stream decodes to, where it says so (Snappy's preamble) */
+    const uint32_t declared = wave::uniform(FrontEnd::declared_length(in, in_len));
+    if (declared <= kMaxOut) {
+      out_cap = kMaxOut;
+    }
+  }
   if (out_cap > kMaxOut || in_len > kMaxIn) {
     /* not a team's chunk: the two-waves-per-chunk decoder, by waves 0 and 1 */
     return run_fallback(t, fb_scratch, in, in_len, out, out_cap, err, fallback);

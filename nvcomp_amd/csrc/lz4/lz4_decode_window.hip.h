@@ -339,6 +339,8 @@ struct TeamFrontEnd
   static constexpr bool kEmptyIsError = false; /* an empty block decodes to nothing */
   using Delta = DeltaFn;
   using Slow = SlowFn;
+  /* an LZ4 block does not say what it decodes to: the caller's capacity decides (pass tight capacities for the team path) */
+  static __device__ __forceinline__ uint32_t declared_length(const uint8_t*, uint32_t) { return ~0u; }
   template <class R>
   static __device__ __forceinline__ bool begin(const R& r, uint32_t out_cap, uint32_t& q, uint32_t& limit, uint32_t&)
   {

@@ -313,6 +313,21 @@ struct TeamFrontEnd
   static constexpr bool kEmptyIsError = true; /* no preamble */
   using Delta = DeltaFn;
   using Slow = SlowFn;
+  /* What the stream says it decodes to (its varint32 preamble), read straight from memory by every lane alike; ~0u when
+   * there is no complete preamble. The team decoder keeps a chunk on chip when THIS fits its buffer, whatever capacity the
+   * caller passed (a rounded-up max_uncompressed_chunk_bytes, say: ADVICE r4). */
+  static __device__ __forceinline__ uint32_t declared_length(const uint8_t* in, uint32_t in_len)
+  {
+    uint32_t v = 0;
+    for (uint32_t i = 0; i < 5 && i < in_len; ++i) {
+      const uint32_t b = in[i];
+      v |= (b & 127u) << (7 * i);
+      if (!(b & 128u)) {
+        return (i == 4 && b > 15u) ? ~0u : v;
+      }
+    }
+    return ~0u;
+  }
   /* the preamble: first element, and the length the elements must produce exactly */
   template <class R>
   static __device__ __forceinline__ bool begin(const R& r, uint32_t out_cap, uint32_t& q, uint32_t& limit, uint32_t& err)

@@ -14,16 +14,17 @@ sys.path.insert(0, REPO)
 
 # run name -> [(kernel substring, algo, kind)]
 KERNELS = {
-    "lz4": [("lz4_decompress_window_kernel", "lz4", "decompress"), ("lz4_compress_kernel", "lz4", "compress")],
-    "snappy": [("snappy_decompress_window_kernel", "snappy", "decompress")],
+    "lz4": [("lz4_decompress_window_kernel", "lz4", "decompress"), ("lz4_compress_wide_kernel", "lz4", "compress")],
+    "snappy": [("snappy_decompress_window_kernel", "snappy", "decompress"), ("snappy_compress_wide_kernel", "snappy", "compress")],
     "deflate": [("deflate_decompress_kernel", "deflate", "decompress")],
-    "cascaded": [("cascaded_decompress_kernel", "cascaded", "decompress")],
+    "cascaded": [("cascaded_decompress_kernel", "cascaded", "decompress"), ("cascaded_compress_kernel", "cascaded", "compress")],
+    "ans": [("ans_decompress_kernel", "ans", "decompress"), ("ans_compress_kernel", "ans", "compress")],
+    "bitcomp": [("bitcomp_decompress_kernel", "bitcomp", "decompress"), ("bitcomp_compress_kernel", "bitcomp", "compress")],
     "lz4_mortgage": [("lz4_decompress_window_kernel", "lz4", "decompress")],
-    # the batch-size riders of the driver's line and the unchecked fast path
+    # the batch-size riders of the driver's line
     "lz4_16384": [("lz4_decompress_window_kernel", "lz4", "decompress")],
     "lz4_4096": [("lz4_decompress_pair_kernel", "lz4", "decompress")],
     "lz4_256": [("lz4_decompress_team_kernel", "lz4", "decompress")],
-    "lz4_unchecked": [("lz4_decompress_window_kernel", "lz4", "decompress_unchecked")],
     # the other codecs' own bench lines (python bench.py --algo X at its default size)
     "cascaded_line": [("cascaded_decompress_kernel", "cascaded", "decompress")],
     "bitcomp_line": [("bitcomp_decompress_kernel", "bitcomp", "decompress")],
@@ -31,16 +32,17 @@ KERNELS = {
     "deflate_line": [("deflate_decompress_kernel", "deflate", "decompress")],
 }
 
+# API calls of a run (scripts/gpu_traffic.sh: --steps 2 --warmup 1; the compress leg of bench.py: one call + five timed ones).
+# A call may be several dispatches of one kernel (the Cascaded codec runs passes of growing LDS budget): the counters of a
+# call are the sum over its dispatches.
+CALLS = {"decompress": 3, "compress": 6}
 
-# dispatches of the kernel per API call (the Cascaded decoder runs three passes of one kernel: the traffic of a call is their sum)
-DISPATCHES_PER_CALL = {"cascaded_decompress_kernel": 3}
 
-
-def per_launch(path, substr):
-    rows = [r for r in csv.DictReader(open(path)) if substr in r["Kernel_Name"]]
-    launches = len({r["Dispatch_Id"] for r in rows}) // DISPATCHES_PER_CALL.get(substr, 1)
-    total = sum(float(r["Counter_Value"]) for r in rows)
-    return (total / launches if launches else None), launches
+def per_call(path, substr, kind, counter=None):
+    rows = [r for r in csv.DictReader(open(path)) if substr in r["Kernel_Name"] and (counter is None or r["Counter_Name"] == counter)]
+    if not rows:
+        return None
+    return sum(float(r["Counter_Value"]) for r in rows) / CALLS[kind]
 
 
 def main():
@@ -63,11 +65,21 @@ def main():
             for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
                 hits = glob.glob(os.path.join(out_dir, f"{run}_{ctr}", "**", "*counter_collection.csv"), recursive=True)
                 if hits:
-                    vals[ctr], n = per_launch(hits[0], substr)
+                    vals[ctr] = per_call(hits[0], substr, kind)
+            insts = {}
+            hits = glob.glob(os.path.join(out_dir, f"{run}_INSTS", "**", "*counter_collection.csv"), recursive=True)
+            if hits:
+                for ctr in ("SQ_INSTS_VALU", "SQ_INSTS_SALU"):
+                    insts[ctr] = per_call(hits[0], substr, kind, ctr)
             if vals.get("FETCH_SIZE") is None or vals.get("WRITE_SIZE") is None:
                 continue
             fetch, write = vals["FETCH_SIZE"] * 1024, vals["WRITE_SIZE"] * 1024  # the counters are in KB
             comp, raw = cfg["compressed_bytes_per_gpu"], cfg["uncompressed_bytes_per_gpu"]
+            if kind == "compress":  # the compress leg writes its own sizes: the line's extras carry them
+                e = line.get("extras", {})
+                if not e.get("gpu_compress_ratio"):
+                    continue
+                comp = int(raw / e["gpu_compress_ratio"])
             # gfx950: FETCH_SIZE = TCC_EA0_RDREQ x 64, and every L2 miss is ONE 128-byte request whatever the access shape --
             # calibrated in round 4 on known load counts (scripts/probes/gather_calib.hip, profiles/r04_feasibility.json:
             # coalesced 16-byte lane loads 0.125 requests per load, lanes 64 bytes apart 0.5, lanes 128 bytes apart and random
@@ -81,6 +93,7 @@ def main():
                 "lib_source_digest": bench.library_source_digest(algo),
                 "fetch_bytes_counted": int(fetch), "write_bytes_counted": int(write),
                 "hbm_bytes_per_launch": int(fetch + uncounted + write),
+                "valu_wave_insts": insts.get("SQ_INSTS_VALU"), "salu_wave_insts": insts.get("SQ_INSTS_SALU"),
                 "algorithmic_bytes": int(comp + raw + (44 if kind == "decompress" else 40) * cfg["chunks_per_gpu"]),
                 "calibration": {"fetch_factor": 2.0, "basis": "profiles/r04_feasibility.json fetch_size_calibration: 128-byte "
                                 "requests tallied at 64 bytes for every access shape measured", "write_factor": 1.0},

@@ -1,35 +1,40 @@
 #!/bin/bash
-# HBM traffic of the kernels behind the driver's bench line (the headline, its riders, the compress leg): FETCH_SIZE and
-# WRITE_SIZE per launch, SEPARATE rocprofv3 --pmc passes of the same commands (MI355X_MICROARCH.md: FETCH_SIZE costs 3 TCC
-# slots, WRITE_SIZE 2; never together with trace domains). scripts/collect_traffic.py turns the CSVs into
-# profiles/pmc_traffic_r04.json, which bench.py replays for the same workload AND the same kernel sources only.
+# Counters of the kernels behind the driver's bench line (the headline, its riders, the compress legs): FETCH_SIZE, WRITE_SIZE
+# and the vector / scalar instruction counts per launch, SEPARATE rocprofv3 --pmc passes of the same commands
+# (MI355X_MICROARCH.md: FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2; never together with trace domains).
+# scripts/collect_traffic.py turns the CSVs into profiles/pmc_traffic_r05.json, which bench.py replays for the same workload
+# AND the same kernel sources only.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=gpurun_out/${1:-traffic}
 mkdir -p "$OUT"
-B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-riders"
 run() { # name, bench args...
   local name=$1; shift
-  for ctr in FETCH_SIZE WRITE_SIZE; do
-    timeout 400 rocprofv3 --pmc $ctr --output-format csv -d "$OUT/${name}_$ctr" -o r -- $B "$@" > "$OUT/${name}_$ctr.log" 2>&1
+  for ctr in FETCH_SIZE WRITE_SIZE INSTS; do
+    local pmc=$ctr; [ $ctr = INSTS ] && pmc="SQ_INSTS_VALU SQ_INSTS_SALU"
+    timeout 400 rocprofv3 --pmc $pmc --output-format csv -d "$OUT/${name}_$ctr" -o r -- $B "$@" > "$OUT/${name}_$ctr.log" 2>&1
     echo "$name $ctr rc=$?" | tee -a "$OUT/rc.txt"
   done
 }
-run lz4 --no-riders                                   # lz4_decompress_window_kernel + lz4_compress_kernel (the extras leg)
-run snappy --algo snappy --no-extras
+run lz4                                               # lz4_decompress_window_kernel + lz4_compress_wide_kernel (the extras leg)
+run snappy --algo snappy                              # ... and Snappy's pair (BASELINE.json configs[2]: a round trip)
 run deflate --algo deflate --no-extras --mib-per-gpu 1024 --unique-mib 32
-run cascaded --algo cascaded --no-extras --dataset example_float_columns --mib-per-gpu 1024 --unique-mib 32
+run cascaded --algo cascaded --dataset example_float_columns --mib-per-gpu 1024 --unique-mib 32
+run ans --algo ans --dataset silesia_style --mib-per-gpu 1024 --unique-mib 32
+run bitcomp --algo bitcomp --dataset float_columns --mib-per-gpu 1024 --unique-mib 32
 run lz4_mortgage --no-extras --dataset mortgage_col0_like --mib-per-gpu 1024 --unique-mib 64
 run lz4_16384 --no-extras --mib-per-gpu 1024
 run lz4_4096 --no-extras --mib-per-gpu 256
 run lz4_256 --no-extras --mib-per-gpu 16 --unique-mib 16
-run lz4_unchecked --no-extras --unchecked
-if [ "${LINES:-1}" = 1 ]; then # the other codecs' own lines at their default sizes
+if [ "${LINES:-0}" = 1 ]; then # the other codecs' own lines at their default sizes
   run cascaded_line --algo cascaded --no-extras
   run bitcomp_line --algo bitcomp --no-extras
   run ans_line --algo ans --no-extras
   run deflate_line --algo deflate --no-extras
 fi
 find "$OUT" -name "*.csv" -size +16M -delete
-python scripts/collect_traffic.py "$OUT" > "$OUT/pmc_traffic_r04.json" && cat "$OUT/pmc_traffic_r04.json" | head -60
+python scripts/collect_traffic.py "$OUT" > "$OUT/pmc_traffic_r05.json" && python -c "
+import json; r=json.load(open('$OUT/pmc_traffic_r05.json'))
+for x in r: print(x['algo'], x['kind'], x['dataset'], x['chunks_per_gpu'], 'traffic x', round(x['hbm_bytes_per_launch']/x['algorithmic_bytes'],2), 'valu', x.get('valu_wave_insts'))"
