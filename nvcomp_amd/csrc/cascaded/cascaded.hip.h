@@ -189,6 +189,27 @@ __device__ __forceinline__ uint32_t pack_stream(uint8_t* dst, const S& s, uint32
   if (S::kBytes <= 4 && bits <= 32) {
     const uint32_t mn32 = (uint32_t)mn;
     const uint32_t vmask = bits == 32 ? ~0u : ((1u << bits) - 1u); /* bits <= 8 w: the width mask is implied */
+    if (bits > 16) {
+      /* more than 16 bits an element (float columns: 24-28): a word holds parts of at most three elements -- straight-line
+       * code, no per-lane loop (the loop below was 40 % of the compressor's time on such data: phase clock, round 5).
+       * An element beyond the count is read as the last one and contributes nothing. */
+      const uint32_t last = count - 1;
+      for (uint32_t k = lane; k < words; k += 64) {
+        const uint32_t bit0 = 32 * k;
+        const uint32_t e = __umulhi(bit0, recip);
+        const uint32_t back = bit0 - wave::mul24(e, bits); /* bits of element e in front of this word: 0 ... bits - 1 */
+        const uint32_t x0 = (s.get32(e) - mn32) & vmask;
+        const uint32_t x1 = e + 1 <= last ? (s.get32(e + 1) - mn32) & vmask : 0u;
+        const uint32_t x2 = e + 2 <= last ? (s.get32(e + 2 <= last ? e + 2 : last) - mn32) & vmask : 0u;
+        const uint32_t r1 = bits - back;     /* where element e + 1 starts in the word: 1 ... 32 */
+        const uint32_t r2 = r1 + bits;       /* ... and e + 2: may lie behind the word */
+        uint32_t word = x0 >> back;
+        word |= r1 < 32 ? x1 << r1 : 0u;
+        word |= r2 < 32 ? x2 << r2 : 0u;
+        out[3 + k] = word;
+      }
+      return 12 + 4 * words;
+    }
     for (uint32_t k = lane; k < words; k += 64) {
       const uint32_t bit0 = 32 * k;
       uint32_t e = bits > 1 ? __umulhi(bit0, recip) : bit0;
@@ -734,6 +755,7 @@ __device__ __forceinline__ uint32_t compress_sub(
   const uint32_t w = sizeof(T);
   const uint32_t n = bytes / w;
   const T* in = (const T*)src;
+  CASC_PROF_DECL;
   const uint32_t rl = p.num_rles;
   const uint32_t layers = rl > p.num_deltas ? rl : p.num_deltas;
   /* One value buffer V of n elements and the run pool behind it. Layer 0 reads the input from HBM and compacts
@@ -753,7 +775,30 @@ __device__ __forceinline__ uint32_t compress_sub(
   uint32_t pos = 4 + 4 * rl;
   bool raw = pos >= raw_sz;
   uint32_t c = n;
-  const T* cur = in; /* HBM until layer 0 (or a delta) has put the data into V */
+  const T* cur = in; /* HBM until the data has been put into V */
+  if (layers != 0 && !raw) {
+    /* The sub-chunk is staged into V once, eight tiles' loads in flight together (round 5): the layers -- the count of run
+     * heads that decides whether an RLE layer pays, the compaction, the deltas -- then work on LDS. Counting the heads
+     * straight from memory, a tile at a time, was 43 % of the compressor's time: sixteen dependent round trips a
+     * sub-chunk (phase clock, scripts/casc_prof.py --compress). */
+    for (uint32_t base = 0; base < n; base += 512) {
+      T v[8];
+#pragma unroll
+      for (uint32_t u = 0; u < 8; ++u) {
+        const uint32_t i = base + 64 * u + lane;
+        v[u] = in[i < n ? i : n - 1];
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 8; ++u) {
+        const uint32_t i = base + 64 * u + lane;
+        if (i < n) {
+          V[i] = v[u];
+        }
+      }
+    }
+    wave::sync();
+    cur = V;
+  }
   for (uint32_t l = 0; l < layers && !raw; ++l) {
     if (l < rl) {
       /* A layer that would take out fewer than one element in eight is left out: its values pass through, every run
@@ -766,6 +811,7 @@ __device__ __forceinline__ uint32_t compress_sub(
         const uint32_t heads = count_heads(cur, c);
         id = heads + (c >> 3) > c;
       }
+      CASC_T(8); /* compress: run heads counted */
       if (!id) {
         const uint32_t m = rle_encode(cur, c, V, pool, pool_cap);
         if (m == kRleOverflow) {
@@ -775,6 +821,7 @@ __device__ __forceinline__ uint32_t compress_sub(
         c = m;
       }
       wave::sync();
+      CASC_T(9); /* compress: run-length compaction */
       uint64_t mn;
       uint32_t bits;
       if (id) { /* all run lengths are 1: what stream_range finds for them, without the stream */
@@ -799,6 +846,7 @@ __device__ __forceinline__ uint32_t compress_sub(
       pack_stream(dst + pos, s, c, 2, mn, bits);
       pos += sb;
       wave::sync(); /* the pool is free for the next layer */
+      CASC_T(10); /* compress: run stream ranged and packed */
     }
     if (l < p.num_deltas) {
       if (cur == in) { /* nothing has moved the data into V yet */
@@ -809,6 +857,7 @@ __device__ __forceinline__ uint32_t compress_sub(
         cur = V;
       }
       delta_encode(V, c);
+      CASC_T(11); /* compress: staging + delta */
     }
   }
   wave::sync();
@@ -824,8 +873,10 @@ __device__ __forceinline__ uint32_t compress_sub(
     if (pos + sb >= raw_sz) {
       raw = true;
     } else {
+      CASC_T(6); /* compress: values ranged */
       pack_stream(dst + pos, s, c, w, mn, bits);
       pos += sb;
+      CASC_T(7); /* compress: values packed */
     }
   }
   if (raw) { /* would not shrink: marker + the bytes, zero padded to a multiple of 4 */
