@@ -280,7 +280,7 @@ __device__ __forceinline__ uint32_t encode_chunk(
           const uint32_t l = e[h] >> 24;
           const uint32_t t = __umulhi(magic[h], xs[h]);
           const uint32_t quot = (t + ((xs[h] - t) >> (l ? 1u : 0u))) >> (l ? l - 1u : 0u);
-          xs[h] = (quot << kProbBits) + (xs[h] - __umul24(quot, freq)) + base; /* quot < 2^22 after renormalisation */
+          xs[h] = (quot << kProbBits) + (xs[h] - wave::mul24(quot, freq)) + base; /* quot < 2^22 after renormalisation */
         }
       }
     }

@@ -428,7 +428,8 @@ nvcompStatus_t nvcompBatchedLZ4DecompressAsync(
   /* ... and the expensive chunks first (common/lz_order.hip.h), when the temp buffer has room for the order */
   const uint32_t* order = nullptr;
   if (ticket != nullptr && NVCOMP_LZ_ORDERED) {
-    order = lzo::make_order<lzo::Lz4Cost>(b, device_temp_ptr, temp_bytes, stream);
+    order = NVCOMP_LZ_ORDERED == 2 ? lzo::make_order_by_sizes<lzo::Lz4Cost>(b, device_temp_ptr, temp_bytes, stream)
+                                   : lzo::make_order<lzo::Lz4Cost>(b, device_temp_ptr, temp_bytes, stream);
   }
   const lzl::Launch launch = {b, ticket, (size_t)groups * kDecWaves, order};
   hipLaunchKernelGGL((lz4_decompress_window_kernel<true>), dim3(groups), dim3(64 * kDecWaves), 0, stream, launch);

@@ -401,7 +401,8 @@ nvcompStatus_t nvcompBatchedSnappyDecompressAsync(
   /* ... and the expensive chunks first (common/lz_order.hip.h), when the temp buffer has room for the order */
   const uint32_t* order = nullptr;
   if (ticket != nullptr && NVCOMP_LZ_ORDERED) {
-    order = lzo::make_order<lzo::SnappyCost>(b, device_temp_ptr, temp_bytes, stream);
+    order = NVCOMP_LZ_ORDERED == 2 ? lzo::make_order_by_sizes<lzo::SnappyCost>(b, device_temp_ptr, temp_bytes, stream)
+                                   : lzo::make_order<lzo::SnappyCost>(b, device_temp_ptr, temp_bytes, stream);
   }
   const lzl::Launch launch = {b, ticket, (size_t)groups * kDecWaves, order};
   hipLaunchKernelGGL((snappy_decompress_window_kernel<true>), dim3(groups), dim3(64 * kDecWaves), 0, stream, launch);

@@ -47,7 +47,10 @@
                              * measured in round 5 (gpurun r5j, mix, ordered against the caller's order): 65 536 chunks 676 = 675,
                              * 32 768: 613 = 615, 16 384: 529 against 512 (+3 %), 8 192: 432 against 458 (-6 %), uniform text and the
                              * sorted-key column -6 ... -7 % (the two kernels in front cost ~0.1 ms): the end of a launch is not
-                             * where medium batches lose their time. Off. */
+                             * where medium batches lose their time. 2: the cheap variant, one kernel that looks at the sizes only and
+                             * hands the (nearly) incompressible and the highly compressible chunks out last (gpurun r5l, interleaved
+                             * A/B): 16 384 chunks +4 % (496-504 -> 514-524), 8 192 / 32 768 / 65 536 chunks and uniform batches +-1 %.
+                             * Off: T(N) = 0.63 ms + 87.6 ns x N is the start of a launch, not its end. */
 #endif
 #ifndef NVCOMP_LZ_PERSISTENT
 #define NVCOMP_LZ_PERSISTENT 1 /* A/B: 0 = one wave per chunk, static mapping (round 2) */

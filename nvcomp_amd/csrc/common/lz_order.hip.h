@@ -183,6 +183,52 @@ __global__ void __launch_bounds__(256) order_kernel(size_t n, uint32_t* temp)
   }
 }
 
+/* The cheap variant (NVCOMP_LZ_ORDERED == 2): no look at the streams, one kernel. A chunk whose compressed size is (nearly)
+ * its capacity is one literal run, a chunk that shrank eight times or more is a few long matches: both cost the decoder a
+ * fraction of what text does. Those are handed out LAST (from the end of the order downwards), everything else first in
+ * roughly the caller's order: the launch then drains through short chunks, and the first round keeps its mix. */
+template <class Cost>
+__global__ void __launch_bounds__(256) order_by_sizes_kernel(lzl::Batch b, uint32_t* temp)
+{
+  __shared__ uint32_t local[2], base[2];
+  if (threadIdx.x < 2) {
+    local[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  const size_t n = b.batch_size;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t cheap = 0, mine = 0;
+  if (i < n) {
+    const size_t comp = b.comp_bytes[i], cap = b.out_caps != nullptr ? b.out_caps[i] : 0;
+    cheap = (comp == 0 || comp + (cap >> 6) >= cap || comp * 8 <= cap) ? 1u : 0u;
+    mine = atomicAdd(local + cheap, 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 && local[threadIdx.x] != 0) {
+    base[threadIdx.x] = atomicAdd(temp + 4 + threadIdx.x, local[threadIdx.x]);
+  }
+  __syncthreads();
+  if (i < n) {
+    uint32_t* order = (uint32_t*)((uint8_t*)temp + kHeaderBytes);
+    const uint32_t at = base[cheap] + mine;
+    order[cheap ? (uint32_t)n - 1 - at : at] = (uint32_t)i;
+  }
+}
+
+template <class Cost>
+inline const uint32_t* make_order_by_sizes(const lzl::Batch& b, void* temp, size_t bytes, hipStream_t stream)
+{
+  if (temp == nullptr || ((uintptr_t)temp & 15u) != 0 || bytes < temp_bytes(b.batch_size) || b.batch_size > 0x7fffffffu) {
+    return nullptr;
+  }
+  if (hipMemsetAsync(temp, 0, kHeaderBytes, stream) != hipSuccess) {
+    return nullptr;
+  }
+  const unsigned groups = (unsigned)((b.batch_size + 255) / 256);
+  hipLaunchKernelGGL((order_by_sizes_kernel<Cost>), dim3(groups), dim3(256), 0, stream, b, (uint32_t*)temp);
+  return (const uint32_t*)((const uint8_t*)temp + kHeaderBytes);
+}
+
 /* Clears the header, runs the two kernels on `stream`; returns the order array (device) or nullptr when the temp buffer
  * does not hold it (the decoder then hands the chunks out in the caller's order). The header's first word is the decoder's
  * ticket counter: cleared here too. */
