@@ -50,7 +50,8 @@
                              * where medium batches lose their time. 2: the cheap variant, one kernel that looks at the sizes only and
                              * hands the (nearly) incompressible and the highly compressible chunks out last (gpurun r5l, interleaved
                              * A/B): 16 384 chunks +4 % (496-504 -> 514-524), 8 192 / 32 768 / 65 536 chunks and uniform batches +-1 %.
-                             * Off: T(N) = 0.63 ms + 87.6 ns x N is the start of a launch, not its end. */
+                             * Off. (Nor is it the waves starting in the same phase: starts staggered by up to one batch period --
+                             * 16 K or 64 K cycles -- change nothing, gpurun r5m.) */
 #endif
 #ifndef NVCOMP_LZ_PERSISTENT
 #define NVCOMP_LZ_PERSISTENT 1 /* A/B: 0 = one wave per chunk, static mapping (round 2) */
