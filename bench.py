@@ -1001,7 +1001,9 @@ def main():
         names = ["in_ensure", "chase_build", "chase_enum", "parse", "exec_prep", "make_room", "literals_4_32",
                  "far_store", "match_rounds", "flush", "loop_top", "far_issue", "literals_1_3", "literals_long",
                  "matches_whole_wave", "-"]
-        reader = "nvcompAmdProfRead"
+        reader = "nvcompAmdProfReadSnappy" if args.algo == "snappy" else "nvcompAmdProfRead"
+        if args.algo == "snappy":
+            names[15] = "copy_trains"
         if args.algo == "deflate":  # scripts/build_deflate_variant.sh dprof -DNVCOMP_LZW_PROF: the front end's phases + the executor's
             reader = "nvcompAmdProfReadDeflate"
             for i, n in ((0, "headers_and_code_tables"), (1, "window_tables"), (2, "enumerations"), (3, "round_decode_and_records"),

@@ -80,6 +80,9 @@ __global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_WAVES_PER_SIMD) sna
   __shared__ __attribute__((aligned(16))) uint8_t lds[kDecWaves][lzw::kLdsPerWave];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
   size_t place = (size_t)blockIdx.x * kDecWaves + w; /* the wave's place in the launch: chunk order[place] */
+#ifdef NVCOMP_LZW_PROF
+  lzw::prof_begin();
+#endif
   for (;;) {
     /* the arguments are read where they are used, not held in scalar registers across the decode (wave::kernel_args) */
     const auto* a = wave::kernel_args(launch);
@@ -96,6 +99,9 @@ __global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_WAVES_PER_SIMD) sna
     }
     place = lzl::next_chunk(ticket, a->first_dynamic);
   }
+#ifdef NVCOMP_LZW_PROF
+  lzw::prof_end();
+#endif
 }
 
 /* A workgroup per chunk (common/lz_team.hip.h): batches that cannot fill the card with one wave per chunk. Persistent
@@ -536,3 +542,20 @@ nvcompStatus_t nvcompBatchedSnappyCompressAsync(
 }
 
 } // extern "C"
+
+#ifdef NVCOMP_LZW_PROF
+/* Profiling builds only: read (and clear) the per-phase cycle sums of the Snappy window decoder. */
+extern "C" int nvcompAmdProfReadSnappy(unsigned long long* host_slots, int n)
+{
+  unsigned long long v[lzw::kProfSlots] = {};
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(lzw::g_prof), sizeof(v)) != hipSuccess) {
+    return -1;
+  }
+  for (int i = 0; i < n && i < (int)lzw::kProfSlots; ++i) {
+    host_slots[i] = v[i];
+  }
+  unsigned long long z[lzw::kProfSlots] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(lzw::g_prof), z, sizeof(z));
+  return (int)lzw::kProfSlots;
+}
+#endif

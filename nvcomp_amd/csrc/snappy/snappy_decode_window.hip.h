@@ -403,7 +403,9 @@ __device__ __forceinline__ uint32_t decode_chunk(
     }
     if (count < kRefillBelow && c.q < ir.vend) {
       const uint32_t oldest = count ? wave::read_lane(seqpos, 0) : c.q;
+      LZW_T(10);
       lzw::in_ensure(ir, oldest, (c.q & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
+      LZW_T(0);
       const uint32_t before = count;
       count = lzw::chase_tokens(c, ir, seqpos, count, DeltaFn(), SlowFn());
       lz::Seq fresh;
@@ -421,8 +423,10 @@ __device__ __forceinline__ uint32_t decode_chunk(
         err |= lz::kErrInput;
         return 0;
       }
+      LZW_T(3);
     }
     const uint64_t train = merge_trains(s, count);
+    LZW_T(15); /* copy trains merged */
     LZ_STAT("sn_rounds", 1);
     LZ_STAT("sn_rounds_with_train", train ? 1 : 0);
     bool big;
