@@ -364,8 +364,12 @@ __device__ __forceinline__ uint32_t encode_chunk(
         uint32_t len = xf ? 4 + ((uint32_t)__builtin_ctz(xf) >> 3) : 8u;
         len = len < room ? len : room;
         longer[k] = ok[k] && xf == 0 && room > 8;
+        const uint32_t grow = xb ? (uint32_t)__builtin_clz(xb) >> 3 : 4u;
+        /* (Matches of 4 bytes are kept: dropping what is shorter than 5 after its growth backwards would take 17 % of the
+         * sequences out of the stream -- 6 671 -> 5 516 a chunk, HC-12 writes 6 035 -- and 1.2 % off the ratio, 1.8549 ->
+         * 1.8320: measured with the emulator, not shipped.) */
         mlen[k] = ok[k] ? len : 0u;
-        back |= (xb ? (uint32_t)__builtin_clz(xb) >> 3 : 4u) << (4 * k);
+        back |= grow << (4 * k);
         hits[k] = wave::ballot(ok[k]);
         total_hits += wave::popc64(hits[k]);
       }
