@@ -103,3 +103,50 @@ def test_oversized_chunk_is_refused_by_every_compressor(backend, fmt, opts):
     chunks = [datasets.int32_column(3000, 1), datasets.int32_column(9000, 2), datasets.int32_column(2000, 3)]
     comp = backend.codec(fmt, opts).compress(chunks, max_chunk=4096)
     assert comp[1].size == 0 and comp[0].size > 0 and comp[2].size > 0
+
+
+@pytest.mark.parametrize("fmt", ["LZ4", "Snappy"])
+def test_compress_fuzz_structured(backend, oracle, fmt):
+    """Chunks built to hit the corners of the 256-position steps (common/lz_match_wide.hip.h): runs and periods that start
+    and end at every alignment of the step and of the image blocks, matches that continue at the same distance behind a
+    few changed bytes, long matches followed by text, sizes around the multiples of 256, unaligned chunk starts. Every
+    stream must decode with the CPU library to the original."""
+    rng = np.random.RandomState(77)
+    text = datasets.text(1 << 16, 9)
+    chunks = []
+    for i in range(36 if backend.name == "gpu" else 14):
+        n = int(rng.choice([255, 256, 257, 511, 513, 1023, 1280, 4095, 4097, 20000, 65535, 65536]))
+        kind = i % 7
+        if kind == 0:  # periodic column with occasional changed bytes (the same-distance continuation)
+            period = int(rng.choice([1, 2, 3, 4, 8, 12, 16, 24]))
+            c = np.tile(rng.randint(0, 256, period).astype(np.uint8), n // period + 1)[:n].copy()
+            for p in rng.randint(0, n, size=max(1, n // 300)):
+                c[p] ^= 1 + rng.randint(0, 255)
+        elif kind == 1:  # text with a long run spliced in at a random place
+            c = text[rng.randint(0, 1000):][:n].copy()
+            a = rng.randint(0, max(1, n - 1))
+            c[a: a + rng.randint(1, 3000)] = rng.randint(0, 256)
+        elif kind == 2:  # a block repeated at a distance just below / above 64 KiB of reach and 256 of a step
+            c = rng.randint(0, 256, n).astype(np.uint8)
+            d = int(rng.choice([1, 255, 256, 257, 1024, 4096]))
+            if n > 2 * d + 8:
+                c[d: 2 * d] = c[:d]
+        elif kind == 3:
+            c = np.zeros(n, np.uint8)
+            c[rng.randint(0, n)] = 1
+        elif kind == 4:
+            c = datasets.int32_column(n, i)
+        elif kind == 5:
+            c = np.concatenate([text[:n // 2], text[:n - n // 2]])  # the second half is one long match ... of text
+        else:
+            c = datasets.lowcard(n, i)
+        chunks.append(np.ascontiguousarray(c[:n]))
+    codec = backend.codec(fmt)
+    comp = codec.compress(chunks, in_align=1)
+    for i, (cc, c) in enumerate(zip(comp, chunks)):
+        if fmt == "LZ4":
+            rc, out = (oracle.ref_lz4_decompress if oracle.have_ref() else oracle.lz4_decompress)(cc, c.size)
+        else:
+            rc, out = (oracle.ref_snappy_decompress if oracle.have_ref() else oracle.snappy_decompress)(cc, c.size)
+        assert rc == 0 and np.array_equal(out, c), f"chunk {i} ({c.size} bytes, kind {i % 7})"
+    assert all(cc.size <= codec.max_compressed_size(max(c.size, 1)) for cc, c in zip(comp, chunks))
