@@ -57,6 +57,7 @@ fi
 if ls nvcomp_amd/lib/cab/libnvcomp_cascprof.so > /dev/null 2>&1; then
   for ds in example_float_columns int32; do
     NVCOMP_AMD_LIB=$PWD/nvcomp_amd/lib/cab/libnvcomp_cascprof.so timeout 200 python scripts/casc_prof.py $ds 1024 2>/dev/null | tail -1 >> "$OUT/cascaded_phases.jsonl"
+    NVCOMP_AMD_LIB=$PWD/nvcomp_amd/lib/cab/libnvcomp_cascprof.so timeout 200 python scripts/casc_prof.py $ds 1024 --compress 2>/dev/null | tail -1 | sed 's/^{/{"with_compress_leg": true, /' >> "$OUT/cascaded_phases.jsonl"
   done
 fi
 if ls nvcomp_amd/lib/cab/libnvcomp_lzwprof.so > /dev/null 2>&1; then
