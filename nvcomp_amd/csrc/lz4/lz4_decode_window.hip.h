@@ -337,6 +337,7 @@ struct TeamFrontEnd
 {
   static constexpr uint32_t kPositions = 192; /* a sequence is at least 3 bytes (token + offset): 64 tokens at most */
   static constexpr bool kEmptyIsError = false; /* an empty block decodes to nothing */
+  static constexpr uint32_t kFewLongMatchesRatio = 16; /* common/lz_team.hip.h: such chunks go to the two-wave decoder */
   using Delta = DeltaFn;
   using Slow = SlowFn;
   /* an LZ4 block does not say what it decodes to: the caller's capacity decides (pass tight capacities for the team path) */

@@ -311,6 +311,7 @@ struct TeamFrontEnd
 {
   static constexpr uint32_t kPositions = 128; /* a token is at least 2 bytes (a copy element with a one-byte offset) */
   static constexpr bool kEmptyIsError = true; /* no preamble */
+  static constexpr uint32_t kFewLongMatchesRatio = 12; /* common/lz_team.hip.h: such chunks go to the two-wave decoder */
   using Delta = DeltaFn;
   using Slow = SlowFn;
   /* What the stream says it decodes to (its varint32 preamble), read straight from memory by every lane alike; ~0u when

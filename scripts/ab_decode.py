@@ -36,6 +36,15 @@ CASES = {
     "mix1m": ("LZ4", "silesia_style", "hc", 1, 1),
     "snappy_mix": ("Snappy", "silesia_style", "snappy", 64, None),
     "snappy1g": ("Snappy", "silesia_style", "snappy", 64, 1024),
+    "mortgage16m": ("LZ4", "mortgage_col0_like", "fast", 16, 16),
+    "mortgage32m": ("LZ4", "mortgage_col0_like", "fast", 32, 32),
+    "int32_16m": ("LZ4", "int32", "fast", 16, 16),
+    "text16m": ("LZ4", "text", "hc", 16, 16),
+    "zeros16m": ("LZ4", "zeros", "fast", 16, 16),
+    "snappy_mortgage16m": ("Snappy", "mortgage_col0_like", "snappy", 16, 16),
+    "snappy_int32_16m": ("Snappy", "int32", "snappy", 16, 16),
+    "snappy_zeros16m": ("Snappy", "zeros", "snappy", 16, 16),
+    "snappy_text16m": ("Snappy", "text", "snappy", 16, 16),
     "snappy512m": ("Snappy", "silesia_style", "snappy", 64, 512),
     "mix2g": ("LZ4", "silesia_style", "hc", 64, 2048),
     "mix320m": ("LZ4", "silesia_style", "hc", 64, 320),
