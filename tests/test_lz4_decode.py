@@ -93,6 +93,26 @@ def test_long_matches_and_overlaps(backend, lz_path, oracle):
     check_roundtrip(backend, oracle, chunks, cpu_compress(oracle, chunks))
 
 
+def test_long_overlapping_matches_inside_text(backend, lz_path, oracle):
+    """Runs and short periods between stretches of text: the chunk's ratio stays far below the 16 x from which the
+    workgroup-per-chunk decoder hands a chunk to its two-wave fallback (common/lz_team.hip.h), so that its OWN handling of
+    matches that overlap their source (periods below the match length, the step's frontier) is what runs here."""
+    rng = np.random.RandomState(21)
+    noise = rng.randint(0, 256, size=1 << 16).astype(np.uint8)
+    parts = []
+    for period in [1, 2, 3, 4, 5, 7, 8, 12, 16, 31, 64, 100, 255]:
+        for _ in range(3):
+            pat = rng.randint(0, 256, size=period).astype(np.uint8)
+            parts.append(np.tile(pat, rng.randint(40, 900) // period + 2))
+            a = rng.randint(0, 60000)
+            parts.append(noise[a: a + rng.randint(150, 400)])
+    data = np.concatenate(parts)
+    chunks = datasets.split_chunks(data)
+    comp = cpu_compress(oracle, chunks)
+    assert all(16 * cc.size > c.size for cc, c in zip(comp, chunks)), "the chunks must stay team chunks"
+    check_roundtrip(backend, oracle, chunks, comp)
+
+
 def _lz4_block(seqs, tail):
     """Hand-built LZ4 block: seqs = [(literal bytes, offset, match length >= 4)], tail = the final literal-only sequence."""
     out = bytearray()

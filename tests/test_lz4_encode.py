@@ -150,3 +150,28 @@ def test_compress_fuzz_structured(backend, oracle, fmt):
             rc, out = (oracle.ref_snappy_decompress if oracle.have_ref() else oracle.snappy_decompress)(cc, c.size)
         assert rc == 0 and np.array_equal(out, c), f"chunk {i} ({c.size} bytes, kind {i % 7})"
     assert all(cc.size <= codec.max_compressed_size(max(c.size, 1)) for cc, c in zip(comp, chunks))
+
+
+@pytest.mark.parametrize("fmt", ["LZ4", "Snappy"])
+def test_compress_chunks_beyond_64k(backend, oracle, fmt):
+    """Chunks larger than the 64 KiB the tables' two-byte positions cover (up to nvcomp*CompressionMaxAllowedChunkSize =
+    16 MiB are legal): candidates are rebuilt modulo 65 536 and must stay within the formats' 65 535-byte reach; matches
+    across the 64 KiB marks, repeats at a distance of exactly 65 536 (not encodable: must not be taken), long runs."""
+    rng = np.random.RandomState(5)
+    sizes = [65537, 70000, 131072 + 3, 200000] + ([1 << 20, (1 << 22) + 17] if backend.name == "gpu" else [])
+    text = datasets.text(1 << 16, 3)
+    chunks = []
+    for n in sizes:
+        period = np.tile(rng.randint(0, 256, 65536).astype(np.uint8), n // 65536 + 2)[:n]  # repeats exactly 65 536 back
+        mixed = np.concatenate([np.tile(text, n // text.size + 1)[: n // 2], np.zeros(n // 4, np.uint8),
+                                datasets.int32_column(n - n // 2 - n // 4, 2)])
+        chunks += [period.copy(), mixed[:n].copy()]
+    codec = backend.codec(fmt)
+    comp = codec.compress(chunks, in_align=1)
+    dec = ((oracle.ref_lz4_decompress if fmt == "LZ4" else oracle.ref_snappy_decompress) if oracle.have_ref()
+           else (oracle.lz4_decompress if fmt == "LZ4" else oracle.snappy_decompress))
+    for i, (cc, c) in enumerate(zip(comp, chunks)):
+        rc, out = dec(cc, c.size)
+        assert rc == 0 and np.array_equal(out, c), f"chunk {i} ({c.size} bytes)"
+    # the text half repeats at 65 536 bytes' distance too, the zeros and the column compress well: well below half
+    assert sum(cc.size for cc in comp[1::2]) < 0.5 * sum(c.size for c in chunks[1::2])
