@@ -280,8 +280,13 @@ __device__ __forceinline__ bool unpack_stream(const uint8_t* src, uint32_t avail
       for (uint32_t u = 0; u < kTiles; ++u) {
         const uint32_t i = base + 64 * u + lane < last ? base + 64 * u + lane : last;
         const uint32_t k = wave::mul24(i, bits) >> 5;
+#ifdef NVCOMP_CASC_ABLATE_UNPACK_LOADS /* profiling builds only (wrong output): what do the loads of the unpack cost? */
+        lo[u] = k;
+        hi[u] = i;
+#else
         lo[u] = in[3 + k];
         hi[u] = in[3 + (k + 1 < words ? k + 1 : k)];
+#endif
       }
 #pragma unroll
       for (uint32_t u = 0; u < kTiles; ++u) {
