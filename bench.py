@@ -625,11 +625,6 @@ def replayed_counters(algo, kind, dataset, chunks):
     return None, "no PMC record for this workload (scripts/gpu_traffic.sh)"
 
 
-def replayed_traffic(algo, kind, dataset, chunks):
-    rec, source = replayed_counters(algo, kind, dataset, chunks)
-    return (rec.get("hbm_bytes_per_launch") if rec else None), source
-
-
 def roofline_block(kernel, algorithmic, kernel_ms, algo, kind, dataset, chunks):
     """The `roofline` object of a line: useful bytes against the HBM peak, the replayed fabric traffic, and the issue side
     (VERDICT r4 weak #8: for the LZ kernels it is vector issue, not bytes, that binds)."""
