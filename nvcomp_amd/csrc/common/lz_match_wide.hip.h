@@ -34,8 +34,12 @@ namespace wide {
 #ifndef NVCOMP_LZMW_HASH_ENTRIES
 #define NVCOMP_LZMW_HASH_ENTRIES 3936
 #endif
-#ifndef NVCOMP_LZMW_EARLY_REQUEST
-#define NVCOMP_LZMW_EARLY_REQUEST 0
+/* After this many steps in a row without a single hit (incompressible stretches) only every fourth position's candidate
+ * is looked at -- a match found up to three positions late gets those bytes back by its growth backwards -- until a step
+ * has a hit again; 0 = never. Every position still goes into the table. Why: a candidate look is one scattered 12-byte
+ * load, and on noise every position has a (colliding) candidate: 1 GiB of noise asks the fabric for 10^9 lines. */
+#ifndef NVCOMP_LZMW_QUIET_STEPS
+#define NVCOMP_LZMW_QUIET_STEPS 2
 #endif
 constexpr uint32_t kEntries = NVCOMP_LZMW_HASH_ENTRIES; /* 2-byte entries: position mod 65536 */
 static_assert(kEntries % 2 == 0 && kEntries <= 65536, "the table is cleared a dword at a time");
@@ -262,7 +266,8 @@ struct Probed
 
 template <class Emitter>
 __device__ __forceinline__ void probe_step(
-    Probed& pr, Image& im, const uint8_t* __restrict__ src, uint32_t n, uint16_t* table, uint32_t ip, uint32_t last_start)
+    Probed& pr, Image& im, const uint8_t* __restrict__ src, uint32_t n, uint16_t* table, uint32_t ip, uint32_t last_start,
+    uint32_t look_limit)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   uint8_t* image = im.base;
@@ -309,7 +314,8 @@ __device__ __forceinline__ void probe_step(
   for (uint32_t k = 0; k < kSub; ++k) {
     const uint32_t pos = ip + 64 * k + lane;
     pr.cand[k] = near[k] ? pos - near[k] : pr.cand[k];
-    const bool has = (ok[k] || near[k] != 0) && pos <= last_start && pr.cand[k] >= 4 && pr.cand[k] + 8 <= n;
+    /* (look_limit: last_start, or less for the lanes that a quiet stretch leaves out) */
+    const bool has = (ok[k] || near[k] != 0) && pos <= look_limit && pr.cand[k] >= 4 && pr.cand[k] + 8 <= n;
     pr.has |= has ? 1u << k : 0u;
     /* word check: the candidate's bytes [c - 4, c + 8), ONE load per position with a candidate, the four loads of a lane
      * travel together (a lane without a candidate reads the chunk's first bytes: one address for all of them). Three
@@ -342,8 +348,9 @@ __device__ __forceinline__ uint32_t encode_chunk(
     im.lo = 0, im.hi = 0, im.coming = ~0u, im.piece = 0;
     uint32_t ip = 0;   /* multiple of kStep */
     uint32_t skip = 0; /* leading positions of the step that the last match already covers */
+    uint32_t hitless = 0; /* steps in a row without a hit */
     Probed pr;
-    probe_step<Emitter>(pr, im, src, n, table, ip, last_start);
+    probe_step<Emitter>(pr, im, src, n, table, ip, last_start, last_start);
     while (ip <= last_start) {
       LZM_T(0);
       /* ---- the step's hits: the candidates that hold the position's word (the loads were requested a step ago). A hit
@@ -377,12 +384,15 @@ __device__ __forceinline__ uint32_t encode_chunk(
       if (total_hits == 0) {
         skip = skip > kStep ? skip - kStep : 0;
         ip += kStep;
+        ++hitless;
         if (ip <= last_start) {
-          probe_step<Emitter>(pr, im, src, n, table, ip, last_start);
+          const bool quiet = NVCOMP_LZMW_QUIET_STEPS != 0 && hitless >= NVCOMP_LZMW_QUIET_STEPS;
+          probe_step<Emitter>(pr, im, src, n, table, ip, last_start, quiet && (lane & 3u) != 0 ? 0u : last_start);
         }
         LZM_T(1);
         continue;
       }
+      hitless = 0;
 
       /* ---- long first match (runs, periodic columns): one cooperative probe decides (lz_match.hip.h) ---- */
       {
@@ -432,7 +442,7 @@ __device__ __forceinline__ uint32_t encode_chunk(
             skip = next - ip;
             LZM_T(3);
             if (ip <= last_start) {
-              probe_step<Emitter>(pr, im, src, n, table, ip, last_start);
+              probe_step<Emitter>(pr, im, src, n, table, ip, last_start, last_start);
             }
             LZM_T(1);
             continue;
@@ -456,13 +466,6 @@ __device__ __forceinline__ uint32_t encode_chunk(
         total_long = base;
         wave::sync_wave();
       }
-#if NVCOMP_LZMW_EARLY_REQUEST
-      /* the first batch's candidate sides are requested in front of the next step's probe and looked at behind it */
-      const bool early_act = lane < total_long;
-      const uint32_t early_e = early_act ? queue[lane] : 8u << 8;
-      const uint32_t early_p = early_act ? ip + (early_e & 255u) : ip + 8;
-      const Pending early = measure_request(src, n, early_p, early_p - (early_e >> 8), early_act);
-#endif
       LZM_T(4);
 
       /* ---- the NEXT step's probe and word-check loads: they travel while this step is measured, selected and written.
@@ -470,30 +473,10 @@ __device__ __forceinline__ uint32_t encode_chunk(
        * table.) `pr` is free: what this step needs of it are the candidates and the hit masks ---- */
       const uint32_t nip = ip + kStep;
       if (nip <= last_start) {
-        probe_step<Emitter>(pr, im, src, n, table, nip, last_start);
+        probe_step<Emitter>(pr, im, src, n, table, nip, last_start, last_start);
       }
       LZM_T(1);
 
-#if NVCOMP_LZMW_EARLY_REQUEST
-      {
-        Pending m = early;
-        for (uint32_t b0 = 0; b0 < total_long; b0 += 64) {
-          const bool more = b0 + 64 < total_long;
-          Pending mn = m;
-          if (more) { /* the next batch travels while this one is looked at */
-            const bool act = b0 + 64 + lane < total_long;
-            const uint32_t e = act ? queue[b0 + 64 + lane] : 8u << 8;
-            const uint32_t p = act ? ip + (e & 255u) : ip + 8;
-            mn = measure_request(src, n, p, p - (e >> 8), act);
-          }
-          const uint32_t r = measure_finish(src, n, image, m, match_end);
-          if (m.active) {
-            results[m.p - ip] = (uint8_t)r;
-          }
-          m = mn;
-        }
-      }
-#else
       /* two batches a round: their loads travel together */
       for (uint32_t b0 = 0; b0 < total_long; b0 += 128) {
         const bool act0 = b0 + lane < total_long, act1 = b0 + 64 + lane < total_long;
@@ -515,7 +498,6 @@ __device__ __forceinline__ uint32_t encode_chunk(
           results[rel1] = (uint8_t)r1;
         }
       }
-#endif
       wave::sync_wave();
       uint64_t capped[kSub];
 #pragma unroll
@@ -640,7 +622,7 @@ __device__ __forceinline__ uint32_t encode_chunk(
         ip = next & ~(kStep - 1);
         skip = next - ip;
         if (ip <= last_start) {
-          probe_step<Emitter>(pr, im, src, n, table, ip, last_start);
+          probe_step<Emitter>(pr, im, src, n, table, ip, last_start, last_start);
         }
         LZM_T(1);
       } else {

@@ -409,13 +409,6 @@ __device__ __forceinline__ uint32_t popc64(uint64_t m)
   return (uint32_t)__builtin_popcountll(m);
 }
 
-/* "This value is used here": a loaded register whose only purpose was to bring its cache line closer (there is no
- * prefetch instruction on gfx950) is waited for at this point and nowhere earlier; no instruction is emitted. */
-__device__ __forceinline__ void keep(uint32_t v)
-{
-  asm volatile("" : : "v"(v));
-}
-
 /* a * b for operands below 2^24 (v_mul_u32_u24: full rate; a 32-bit v_mul_lo_u32 takes four times as long, and
  * __umul24 compiles to a mask and that). */
 __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b)

@@ -245,7 +245,6 @@ inline void nap_short() { sync(); } /* a rendezvous is where the coroutine sched
 
 inline uint32_t ctz64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
 inline uint32_t popc64(uint64_t m) { return (uint32_t)__builtin_popcountll(m); }
-inline void keep(uint32_t) {}
 inline uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 inline uint32_t align_bits(uint32_t hi, uint32_t lo, uint32_t shift)
 {

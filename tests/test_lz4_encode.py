@@ -153,6 +153,35 @@ def test_compress_fuzz_structured(backend, oracle, fmt):
 
 
 @pytest.mark.parametrize("fmt", ["LZ4", "Snappy"])
+def test_compress_after_a_quiet_stretch(backend, oracle, fmt):
+    """Steps without a single hit switch the match finder to every fourth position (NVCOMP_LZMW_QUIET_STEPS,
+    common/lz_match_wide.hip.h). What follows such a stretch must still be found: a repeat of an earlier kilobyte of the
+    noise (found up to three positions late, grown backwards), a run, text -- at every alignment of the repeat's start --
+    and the streams must decode with the CPU library."""
+    rng = np.random.RandomState(5)
+    text = datasets.text(8192, 3)
+    chunks = []
+    for shift in range(8):
+        noise = rng.randint(0, 256, 6000 + shift).astype(np.uint8)
+        chunks.append(np.concatenate([noise, noise[1000:2024], np.zeros(700, np.uint8), noise[:3], text]))
+    chunks.append(rng.randint(0, 256, 65536).astype(np.uint8))
+    codec = backend.codec(fmt)
+    comp = codec.compress(chunks, in_align=1)
+    for i, (cc, c) in enumerate(zip(comp, chunks)):
+        if fmt == "LZ4":
+            rc, out = (oracle.ref_lz4_decompress if oracle.have_ref() else oracle.lz4_decompress)(cc, c.size)
+        else:
+            rc, out = (oracle.ref_snappy_decompress if oracle.have_ref() else oracle.snappy_decompress)(cc, c.size)
+        assert rc == 0 and np.array_equal(out, c), (fmt, i, c.size)
+    for cc, c in zip(comp[:8], chunks[:8]):
+        # the kilobyte repeated out of the noise costs a few bytes, the run a few, the text at most what it costs alone
+        alone = codec.compress([text], in_align=1)[0].size
+        assert cc.size <= (c.size - 1024 - 700 - text.size) + alone + 160, (fmt, cc.size, c.size, alone)
+    outs, _, status = codec.decompress(comp, [c.size for c in chunks])
+    assert (status == 0).all() and all(np.array_equal(o, c) for o, c in zip(outs, chunks))
+
+
+@pytest.mark.parametrize("fmt", ["LZ4", "Snappy"])
 def test_compress_chunks_beyond_64k(backend, oracle, fmt):
     """Chunks larger than the 64 KiB the tables' two-byte positions cover (up to nvcomp*CompressionMaxAllowedChunkSize =
     16 MiB are legal): candidates are rebuilt modulo 65 536 and must stay within the formats' 65 535-byte reach; matches
