@@ -38,6 +38,9 @@ namespace wide {
  * is looked at -- a match found up to three positions late gets those bytes back by its growth backwards -- until a step
  * has a hit again; 0 = never. Every position still goes into the table. Why: a candidate look is one scattered 12-byte
  * load, and on noise every position has a (colliding) candidate: 1 GiB of noise asks the fabric for 10^9 lines. */
+#ifndef NVCOMP_LZMW_FIRST_BATCH_EARLY
+#define NVCOMP_LZMW_FIRST_BATCH_EARLY 1
+#endif
 #ifndef NVCOMP_LZMW_QUIET_STEPS
 #define NVCOMP_LZMW_QUIET_STEPS 2
 #endif
@@ -67,7 +70,8 @@ __device__ __forceinline__ uint32_t hashw(uint32_t v)
     constexpr uint32_t kBits = 32 - __builtin_clz(kEntries - 1);
     static_assert(2 * kEntries >= (1u << kBits), "one fold");
     const uint32_t x = h >> (32 - kBits);
-    return x < kEntries ? x : x - kEntries;
+    const uint32_t folded = x - kEntries; /* wraps to a huge value below kEntries */
+    return x < folded ? x : folded;
   }
 }
 
@@ -161,17 +165,36 @@ struct Pending
   bool active, whole;
 };
 
-__device__ __forceinline__ Pending measure_request(const uint8_t* __restrict__ src, uint32_t n, uint32_t p, uint32_t c, bool active)
+__device__ __forceinline__ Pending measure_describe(uint32_t n, uint32_t p, uint32_t c, bool active)
 {
   Pending m;
   m.p = p, m.c = c, m.active = active;
   m.whole = active && c + kCap <= n;
+  return m;
+}
+
+__device__ __forceinline__ Pending measure_request(const uint8_t* __restrict__ src, uint32_t n, uint32_t p, uint32_t c, bool active)
+{
+  Pending m = measure_describe(n, p, c, active);
   /* a lane that has nothing to measure (or goes the slow way) reads the chunk's first bytes: one address for all of them */
   m.b.x = m.b.y = m.b.z = m.b.w = 0;
   if (n >= 16) {
     m.b = wave::gload_u32x4(src + (m.whole ? c + 8 : 0u));
   }
   return m;
+}
+
+/* The first dword in which f and g differ (4: none) and the difference. */
+__device__ __forceinline__ void first_difference(
+    const uint32_t (&f)[4], uint32_t g0, uint32_t g1, uint32_t g2, uint32_t g3, uint32_t& idx, uint32_t& xv)
+{
+  const uint32_t x[4] = {f[0] ^ g0, f[1] ^ g1, f[2] ^ g2, f[3] ^ g3};
+  idx = 4, xv = 0;
+#pragma unroll
+  for (int i = 3; i >= 0; --i) {
+    idx = x[i] ? (uint32_t)i : idx;
+    xv = x[i] ? x[i] : xv;
+  }
 }
 
 /* What the measuring lane finds for position p and candidate c (c < p, their first 8 bytes are equal or the lane is idle):
@@ -195,8 +218,12 @@ __device__ __forceinline__ uint32_t measure_finish(
       f[i] = wave::align_bytes(v[i + 1], v[i], sh);
     }
   }
-  uint32_t g[4] = {m.b.x, m.b.y, m.b.z, m.b.w};
+  uint32_t idx, xv;
+  first_difference(f, m.b.x, m.b.y, m.b.z, m.b.w, idx, xv);
   if (m.active && !m.whole) {
+    /* (the loads AND what is done with them stay inside the branch: a use behind the join would make the common path wait
+     * for every load in flight, the next step's candidate loads included) */
+    uint32_t g[4];
 #pragma unroll
     for (uint32_t i = 0; i < 4; ++i) {
       g[i] = ~f[i];
@@ -204,13 +231,7 @@ __device__ __forceinline__ uint32_t measure_finish(
         g[i] = wave::gload_u32(src + c + 8 + 4 * i);
       }
     }
-  }
-  uint32_t idx = 4, xv = 0;
-#pragma unroll
-  for (int i = 3; i >= 0; --i) {
-    const uint32_t x = f[i] ^ g[i];
-    idx = x ? (uint32_t)i : idx;
-    xv = x ? x : xv;
+    first_difference(f, g[0], g[1], g[2], g[3], idx, xv);
   }
   uint32_t mlen = 8 + 4 * idx + (xv ? (uint32_t)__builtin_ctz(xv) >> 3 : 0u);
   const uint32_t room = match_end - p;
@@ -276,7 +297,7 @@ __device__ __forceinline__ void probe_step(
    * from 8 before the position on come out of the image as four aligned dwords, the five words are byte alignments of
    * neighbouring pairs. (Until the middle of round 5 the repeats were found by comparing with the neighbouring lanes'
    * words: seven or eight cross-lane fetches per sub-window through the LDS crossbar.) */
-  uint32_t word[kSub], slot[kSub], near[kSub];
+  uint32_t slot[kSub], near[kSub];
 #pragma unroll
   for (uint32_t k = 0; k < kSub; ++k) {
     const uint32_t pos = ip + 64 * k + lane;
@@ -284,11 +305,10 @@ __device__ __forceinline__ void probe_step(
     const uint32_t* q = (const uint32_t*)(image + (o & ~3u));
     const uint32_t qa = q[0], qb = q[1], qc = q[2], qd = q[3]; /* bytes [A - 8, A + 8), A = the position's dword */
     const uint32_t sh = pos & 3u;
-    word[k] = wave::align_bytes(qd, qc, sh);
+    const uint32_t w = wave::align_bytes(qd, qc, sh);
     const uint32_t w4 = wave::align_bytes(qc, qb, sh), w8 = wave::align_bytes(qb, qa, sh);
-    const uint32_t w1 = wave::align_bytes(sh >= 1 ? qd : qc, sh >= 1 ? qc : qb, sh + 3u);
-    const uint32_t w2 = wave::align_bytes(sh >= 2 ? qd : qc, sh >= 2 ? qc : qb, sh + 2u);
-    const uint32_t w = word[k];
+    /* (bytes [p - 1, p + 3) and [p - 2, p + 2) are alignments of the two words already at hand, by constants) */
+    const uint32_t w1 = wave::align_bytes(w, w4, 3u), w2 = wave::align_bytes(w, w4, 2u);
     uint32_t d = w8 == w ? 8u : 0u;
     d = w4 == w ? 4u : d;
     d = w2 == w ? 2u : d;
@@ -296,32 +316,39 @@ __device__ __forceinline__ void probe_step(
     near[k] = pos >= 8 ? d : 0u; /* (the chunk's first eight positions have nothing 8 bytes back) */
     slot[k] = hashw(w);
   }
-  /* table entry -> candidate, then this sub-window's positions go in: the LDS serves a wave's accesses in issue order, so
-   * that the next sub-window's probe sees them without a wait */
-  bool ok[kSub];
+  /* table entry (position mod 65 536) -> candidate = the nearest position below with these low bits, then this sub-window's
+   * positions go in: the LDS serves a wave's accesses in issue order, so that the next sub-window's probe sees them without
+   * a wait. dist = 0: the entry is the position's own low bits (an entry of 65 536 bytes ago, or the table's zeros at
+   * position 0); a candidate below the chunk's start comes out huge and fails the range test below. */
+  uint32_t dist[kSub];
 #pragma unroll
   for (uint32_t k = 0; k < kSub; ++k) {
     const uint32_t pos = ip + 64 * k + lane;
-    pr.cand[k] = table_candidate(pos, table[slot[k]], ok[k], Emitter::kReach);
+    dist[k] = (pos - table[slot[k]]) & 0xffffu;
     wave::sync_wave();
     if (pos <= last_start) {
       table[slot[k]] = (uint16_t)pos;
     }
     wave::sync_wave();
   }
+  /* the candidate's bytes [c - 4, c + 8) lie inside the chunk: 4 <= c <= n - 8, one unsigned compare of c - 4 */
+  const uint32_t span = n >= 12 ? n - 11u : 0u;
   pr.has = 0;
 #pragma unroll
   for (uint32_t k = 0; k < kSub; ++k) {
     const uint32_t pos = ip + 64 * k + lane;
-    pr.cand[k] = near[k] ? pos - near[k] : pr.cand[k];
+    const uint32_t back_by = near[k] ? near[k] : dist[k];
+    const bool found = (dist[k] - 1u < Emitter::kReach) | (near[k] != 0);
+    pr.cand[k] = pos - back_by;
+    const uint32_t from = pr.cand[k] - 4u;
     /* (look_limit: last_start, or less for the lanes that a quiet stretch leaves out) */
-    const bool has = (ok[k] || near[k] != 0) && pos <= look_limit && pr.cand[k] >= 4 && pr.cand[k] + 8 <= n;
+    const bool has = found & (pos <= look_limit) & (from < span);
     pr.has |= has ? 1u << k : 0u;
     /* word check: the candidate's bytes [c - 4, c + 8), ONE load per position with a candidate, the four loads of a lane
      * travel together (a lane without a candidate reads the chunk's first bytes: one address for all of them). Three
      * candidates in four are hash collisions and stop here; half of the rest end inside these bytes and are measured by
      * them, growth backwards included */
-    pr.cbytes[k] = wave::gload_u32x3(src + (has ? pr.cand[k] - 4 : 0u));
+    pr.cbytes[k] = wave::gload_u32x3(src + (has ? from : 0u));
   }
 }
 
@@ -466,12 +493,56 @@ __device__ __forceinline__ uint32_t encode_chunk(
         total_long = base;
         wave::sync_wave();
       }
+#if NVCOMP_LZMW_FIRST_BATCH_EARLY
+      /* (the lengths known so far wait in LDS, beside the ones the measurements will write: four registers less across the
+       * probe, whose spills would be reloaded -- and waited for, with everything else in flight -- on the way) */
+#pragma unroll
+      for (uint32_t k = 0; k < kSub; ++k) {
+        results[64 * k + lane] = (uint8_t)mlen[k];
+      }
+      wave::sync_wave();
+      /* The first 64 of them are asked for in FRONT of the next step's probe and looked at behind it. The vector-memory
+       * counter runs in issue order: what was asked for earlier can be waited for while what was asked for later -- the
+       * probe's candidate loads -- stays in flight, not the other way round. (Only the 16 loaded bytes live across the
+       * probe; the rest is read from the queue again.) */
+      wave::u32x4 first_bytes = {0, 0, 0, 0};
+      if (total_long != 0) {
+        const bool act = lane < total_long;
+        const uint32_t e = act ? queue[lane] : 8u << 8;
+        const uint32_t p = act ? ip + (e & 255u) : ip + 8;
+        first_bytes = measure_request(src, n, p, p - (e >> 8), act).b;
+      }
+#endif
       LZM_T(4);
 
       /* ---- the NEXT step's probe and word-check loads: they travel while this step is measured, selected and written.
        * (The step behind a long match starts elsewhere: then this probe only put positions inside that match into the
        * table.) `pr` is free: what this step needs of it are the candidates and the hit masks ---- */
       const uint32_t nip = ip + kStep;
+#if NVCOMP_LZMW_FIRST_BATCH_EARLY
+      const auto finish_first = [&]() {
+        if (total_long != 0) {
+          const bool act = lane < total_long;
+          const uint32_t e = act ? queue[lane] : 8u << 8;
+          const uint32_t rel = e & 255u;
+          const uint32_t p = act ? ip + rel : ip + 8;
+          Pending m = measure_describe(n, p, p - (e >> 8), act);
+          m.b = first_bytes;
+          const uint32_t r = measure_finish(src, n, image, m, match_end);
+          if (act) {
+            results[rel] = (uint8_t)r;
+          }
+        }
+      };
+      if (nip <= last_start) {
+        probe_step<Emitter>(pr, im, src, n, table, nip, last_start, last_start);
+        LZM_T(1);
+        finish_first(); /* (twice in the code: behind a join with the path that has no probe the wait would be for every load) */
+      } else {
+        finish_first();
+      }
+      for (uint32_t b0 = 64; b0 < total_long; b0 += 128) {
+#else
       if (nip <= last_start) {
         probe_step<Emitter>(pr, im, src, n, table, nip, last_start, last_start);
       }
@@ -479,6 +550,7 @@ __device__ __forceinline__ uint32_t encode_chunk(
 
       /* two batches a round: their loads travel together */
       for (uint32_t b0 = 0; b0 < total_long; b0 += 128) {
+#endif
         const bool act0 = b0 + lane < total_long, act1 = b0 + 64 + lane < total_long;
         const uint32_t e0 = act0 ? queue[b0 + lane] : 8u << 8;
         const uint32_t e1 = act1 ? queue[b0 + 64 + lane] : 8u << 8;
@@ -502,9 +574,13 @@ __device__ __forceinline__ uint32_t encode_chunk(
       uint64_t capped[kSub];
 #pragma unroll
       for (uint32_t k = 0; k < kSub; ++k) {
+#if NVCOMP_LZMW_FIRST_BATCH_EARLY
+        mlen[k] = results[64 * k + lane];
+#else
         if (longer[k]) {
           mlen[k] = results[64 * k + lane];
         }
+#endif
         hits[k] = wave::ballot(mlen[k] != 0);
         capped[k] = wave::ballot(mlen[k] >= kCap);
       }

@@ -58,10 +58,7 @@ struct __attribute__((packed)) PackedU32x3
 {
   uint32_t v[3];
 };
-struct u32x3
-{
-  uint32_t x, y, z;
-};
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ u32x3 gload_u32x3(const uint8_t* p) /* any alignment (global_load_dwordx3) */
 {
   const WAVE_GLOBAL PackedU32x3* q = (const WAVE_GLOBAL PackedU32x3*)p;
