@@ -182,6 +182,40 @@ def test_compress_after_a_quiet_stretch(backend, oracle, fmt):
 
 
 @pytest.mark.parametrize("fmt", ["LZ4", "Snappy"])
+def test_compress_many_measured_hits_a_step(backend, oracle, fmt):
+    """More than 64 hits a step that are still open after eight bytes -- the first 64 are measured around the next step's
+    probe, the others in the loop behind it (common/lz_match_wide.hip.h) -- with fewer than 60 hits in the step's first 64
+    positions (no whole-wave path): 192 bytes copied from further up with one byte in twelve changed, behind 64 fresh
+    bytes, step after step; also as the chunk's LAST step (no probe follows) and with the chunk ending inside the copy
+    (candidates whose 24 bytes reach past the end are read dword by dword)."""
+    rng = np.random.RandomState(11)
+    chunks = []
+    for tail in (0, 256, 256 + 100, 256 + 191, 256 + 250, 3 * 256 + 7):
+        base = rng.randint(0, 256, 1024).astype(np.uint8)
+        parts = [base]
+        steps = 1 + tail // 256 + 2
+        for sidx in range(steps):
+            fresh = rng.randint(0, 256, 64).astype(np.uint8)
+            a = 64 + 60 * sidx
+            copy = base[a: a + 192].copy()
+            copy[(3 + sidx) % 12::12] ^= 0x11 * (1 + sidx % 13)  # (its own places: no long match with an earlier copy)
+            parts += [fresh, copy]
+        c = np.concatenate(parts)
+        chunks.append(np.ascontiguousarray(c[: 1024 + 256 * (steps - 1) + (tail % 256 if tail % 256 else 256)]))
+    codec = backend.codec(fmt)
+    comp = codec.compress(chunks, in_align=1)
+    dec = ((oracle.ref_lz4_decompress if fmt == "LZ4" else oracle.ref_snappy_decompress) if oracle.have_ref()
+           else (oracle.lz4_decompress if fmt == "LZ4" else oracle.snappy_decompress))
+    for i, (cc, c) in enumerate(zip(comp, chunks)):
+        rc, out = dec(cc, c.size)
+        assert rc == 0 and np.array_equal(out, c), (fmt, i, c.size)
+        # the copied parts cost a few bytes per eleven: well under half of the chunk behind its first KiB
+        assert cc.size < 1024 + 16 + (c.size - 1024) * 0.62, (fmt, i, cc.size, c.size)
+    outs, _, status = codec.decompress(comp, [c.size for c in chunks])
+    assert (status == 0).all() and all(np.array_equal(o, c) for o, c in zip(outs, chunks))
+
+
+@pytest.mark.parametrize("fmt", ["LZ4", "Snappy"])
 def test_compress_chunks_beyond_64k(backend, oracle, fmt):
     """Chunks larger than the 64 KiB the tables' two-byte positions cover (up to nvcomp*CompressionMaxAllowedChunkSize =
     16 MiB are legal): candidates are rebuilt modulo 65 536 and must stay within the formats' 65 535-byte reach; matches
