@@ -366,13 +366,56 @@ __device__ __forceinline__ void copy_bytes(uint8_t* dst, const uint8_t* src, uin
 
 constexpr uint32_t kRleOverflow = 0xffffffffu;
 
-/* Number of run heads in A[0..c): elements that differ from their predecessor (A may be HBM or LDS). */
+/* v of the lane below (lane 0: unspecified) and of lane l (wave-uniform), for elements of any width: DPP / v_readlane, no
+ * memory access. */
+template <typename T>
+__device__ __forceinline__ T lane_below(T v)
+{
+  if constexpr (sizeof(T) <= 4) {
+    return (T)wave::prev_lane((uint32_t)v);
+  } else {
+    const uint32_t lo = wave::prev_lane((uint32_t)v), hi = wave::prev_lane((uint32_t)((uint64_t)v >> 32));
+    return (T)(((uint64_t)hi << 32) | lo);
+  }
+}
+template <typename T>
+__device__ __forceinline__ T lane_value(T v, uint32_t l)
+{
+  if constexpr (sizeof(T) <= 4) {
+    return (T)wave::read_lane((uint32_t)v, l);
+  } else {
+    const uint32_t lo = wave::read_lane((uint32_t)v, l), hi = wave::read_lane((uint32_t)((uint64_t)v >> 32), l);
+    return (T)(((uint64_t)hi << 32) | lo);
+  }
+}
+
+/* Number of run heads in A[0..c): elements that differ from their predecessor (A may be HBM or LDS). Whole groups of 256
+ * elements: four loads in flight, the predecessor is the value of the lane below (a tile's first element: the last one of
+ * the tile before) -- one load and three or four vector instructions a tile where the plain loop (the tail's) has two
+ * loads, their addresses and bounds: the count ran at 31 % of the compressor's time on run-poor data (phase clock). */
 template <typename T>
 __device__ __forceinline__ uint32_t count_heads(const T* A, uint32_t c)
 {
   const uint32_t lane = (uint32_t)wave::fresh_lane_id();
   uint32_t m = 0;
-  for (uint32_t base = 0; base < c; base += 64) {
+  uint32_t base = 0;
+  T before = (T)0; /* element base - 1 */
+  for (; base + 256 <= c; base += 256) {
+    T v[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      v[u] = A[base + 64 * u + lane];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      const T below = lane_below(v[u]);
+      const T prev = lane == 0 ? before : below;
+      const bool head = v[u] != prev || (u == 0 && base + lane == 0);
+      m += wave::popc64(wave::ballot(head));
+      before = lane_value(v[u], 63);
+    }
+  }
+  for (; base < c; base += 64) {
     const uint32_t i = base + lane;
     const bool in = i < c;
     const T v = in ? A[i] : (T)0;

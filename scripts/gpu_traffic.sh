@@ -10,8 +10,9 @@ export TMPDIR=/tmp
 OUT=gpurun_out/${1:-traffic}
 mkdir -p "$OUT"
 B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-riders"
-run() { # name, bench args...
+run() { # name, bench args...   (ONLY="name name": just these, and the result is merged into the committed record)
   local name=$1; shift
+  if [ -n "${ONLY:-}" ] && ! echo " $ONLY " | grep -q " $name "; then return; fi
   for ctr in FETCH_SIZE WRITE_SIZE INSTS; do
     local pmc=$ctr; [ $ctr = INSTS ] && pmc="SQ_INSTS_VALU SQ_INSTS_SALU"
     timeout 400 rocprofv3 --pmc $pmc --output-format csv -d "$OUT/${name}_$ctr" -o r -- $B "$@" > "$OUT/${name}_$ctr.log" 2>&1
@@ -35,6 +36,16 @@ if [ "${LINES:-0}" = 1 ]; then # the other codecs' own lines at their default si
   run deflate_line --algo deflate --no-extras
 fi
 find "$OUT" -name "*.csv" -size +16M -delete
-python scripts/collect_traffic.py "$OUT" > "$OUT/pmc_traffic_r05.json" && python -c "
+python scripts/collect_traffic.py "$OUT" > "$OUT/pmc_traffic_r05.json" || exit 1
+if [ -n "${ONLY:-}" ]; then # the other codecs' records stay as committed (their kernel sources have not changed: bench.py checks the digest)
+  python - "$OUT/pmc_traffic_r05.json" <<'PY'
+import json, sys
+new = json.load(open(sys.argv[1])); old = json.load(open("profiles/pmc_traffic_r05.json"))
+key = lambda r: (r["algo"], r["kind"], r["dataset"], r["chunks_per_gpu"])
+fresh = {key(r) for r in new}
+json.dump([r for r in old if key(r) not in fresh] + new, open(sys.argv[1], "w"), indent=1)
+PY
+fi
+python -c "
 import json; r=json.load(open('$OUT/pmc_traffic_r05.json'))
 for x in r: print(x['algo'], x['kind'], x['dataset'], x['chunks_per_gpu'], 'traffic x', round(x['hbm_bytes_per_launch']/x['algorithmic_bytes'],2), 'valu', x.get('valu_wave_insts'))"
