@@ -2,7 +2,7 @@
 # Counters of the kernels behind the driver's bench line (the headline, its riders, the compress legs): FETCH_SIZE, WRITE_SIZE
 # and the vector / scalar instruction counts per launch, SEPARATE rocprofv3 --pmc passes of the same commands
 # (MI355X_MICROARCH.md: FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2; never together with trace domains).
-# scripts/collect_traffic.py turns the CSVs into profiles/pmc_traffic_r05.json, which bench.py replays for the same workload
+# scripts/collect_traffic.py turns the CSVs into profiles/pmc_traffic_r06.json, which bench.py replays for the same workload
 # AND the same kernel sources only.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -36,16 +36,16 @@ if [ "${LINES:-0}" = 1 ]; then # the other codecs' own lines at their default si
   run deflate_line --algo deflate --no-extras
 fi
 find "$OUT" -name "*.csv" -size +16M -delete
-python scripts/collect_traffic.py "$OUT" > "$OUT/pmc_traffic_r05.json" || exit 1
+python scripts/collect_traffic.py "$OUT" > "$OUT/pmc_traffic_r06.json" || exit 1
 if [ -n "${ONLY:-}" ]; then # the other codecs' records stay as committed (their kernel sources have not changed: bench.py checks the digest)
-  python - "$OUT/pmc_traffic_r05.json" <<'PY'
+  python - "$OUT/pmc_traffic_r06.json" <<'PY'
 import json, sys
-new = json.load(open(sys.argv[1])); old = json.load(open("profiles/pmc_traffic_r05.json"))
+new = json.load(open(sys.argv[1])); old = json.load(open("profiles/pmc_traffic_r06.json"))
 key = lambda r: (r["algo"], r["kind"], r["dataset"], r["chunks_per_gpu"])
 fresh = {key(r) for r in new}
 json.dump([r for r in old if key(r) not in fresh] + new, open(sys.argv[1], "w"), indent=1)
 PY
 fi
 python -c "
-import json; r=json.load(open('$OUT/pmc_traffic_r05.json'))
+import json; r=json.load(open('$OUT/pmc_traffic_r06.json'))
 for x in r: print(x['algo'], x['kind'], x['dataset'], x['chunks_per_gpu'], 'traffic x', round(x['hbm_bytes_per_launch']/x['algorithmic_bytes'],2), 'valu', x.get('valu_wave_insts'))"
