@@ -193,7 +193,9 @@ __device__ __forceinline__ uint32_t encode_chunk_wide(
     const uint8_t* __restrict__ src, uint32_t n, uint8_t* dst, uint16_t* table, uint8_t* image, uint8_t* scratch)
 {
   const uint32_t hdr = put_preamble(dst, n);
-  const bool any = n >= 8;
+  /* the wide probe's word check reads 12 bytes at a time (lz_match_wide.hip.h probe_step: a lane without a candidate reads
+   * the chunk's first twelve): a chunk of 8 .. 11 bytes is written as literals, never probed */
+  const bool any = n >= 12;
   return hdr + lzm::wide::encode_chunk<Emitter>(src, n, dst + hdr, table, image, scratch, any ? n - 4 : 0, n, any);
 }
 

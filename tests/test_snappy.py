@@ -327,3 +327,42 @@ def test_stream_that_grows_behind_a_compressible_front(backend, lz_path, oracle)
             rc, ref = oracle.ref_snappy_decompress(cc, c.size)
             assert rc == 0 and np.array_equal(ref, c)  # libsnappy reads it
     check_decode(backend, oracle, chunks, comp)
+
+
+@pytest.mark.parametrize("fmt", ["Snappy", "LZ4"])
+def test_compress_small_chunk_at_the_end_of_a_mapping(emu, oracle, fmt):
+    """the wide compressor's 12-byte word-check load ran past a chunk of 8 .. 11 bytes (Snappy looks for
+    matches from 8 bytes on). On the emulator the kernels are host code: chunks of 1 .. 16 bytes that END on the last byte in
+    front of a PROT_NONE page are compressed in place -- a read past the end is a segfault."""
+    import ctypes as C
+    import mmap
+
+    libc = C.CDLL(None, use_errno=True)
+    libc.mmap.restype = C.c_void_p
+    libc.mmap.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_long]
+    libc.mprotect.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    page = mmap.PAGESIZE
+    base = libc.mmap(None, 2 * page, mmap.PROT_READ | mmap.PROT_WRITE, mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS, -1, 0)
+    assert base not in (None, C.c_void_p(-1).value)
+    assert libc.mprotect(base + page, page, 0) == 0  # PROT_NONE
+    codec = emu.codec(fmt)
+    lib = emu.lib
+    sizes = list(range(1, 17))
+    for n in sizes:
+        raw = (np.arange(n, dtype=np.uint8) % 3 + 65).astype(np.uint8)  # compressible: "ABCABC..."
+        C.memmove(base + page - n, raw.ctypes.data, n)
+        in_ptrs = np.array([base + page - n], dtype=np.uint64)
+        in_sizes = np.array([n], dtype=np.uint64)
+        max_out = codec.max_compressed_size(64)
+        out = np.zeros(max_out, dtype=np.uint8)
+        out_ptrs = np.array([out.ctypes.data], dtype=np.uint64)
+        out_sizes = np.zeros(1, dtype=np.uint64)
+        tb = codec.compress_temp_size(1, 64)
+        temp = np.zeros(max(tb, 1), dtype=np.uint8)
+        fn = getattr(lib, f"nvcompBatched{fmt}CompressAsync")
+        rc = fn(in_ptrs.ctypes.data, in_sizes.ctypes.data, 64, 1, temp.ctypes.data, tb, out_ptrs.ctypes.data,
+                out_sizes.ctypes.data, codec.opts, None)
+        assert rc == 0
+        dec = oracle.ref_snappy_decompress if fmt == "Snappy" else oracle.ref_lz4_decompress
+        code, back = dec(out[: int(out_sizes[0])], n)
+        assert code == 0 and np.array_equal(back, raw), (fmt, n)
