@@ -1049,7 +1049,7 @@ def main():
         slots = (ctypes.c_ulonglong * 16)()
         names = ["in_ensure", "chase_build", "chase_enum", "parse", "exec_prep", "make_room", "literals_4_32",
                  "far_store", "match_rounds", "flush", "loop_top", "far_issue", "literals_1_3", "literals_long",
-                 "matches_whole_wave", "-"]
+                 "matches_whole_wave", "token_index"]
         reader = "nvcompAmdProfReadSnappy" if args.algo == "snappy" else "nvcompAmdProfRead"
         if args.algo == "snappy":
             names[15] = "copy_trains"

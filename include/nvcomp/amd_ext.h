@@ -32,29 +32,20 @@ nvcompStatus_t nvcompAmdBatchedPackAsync(
     size_t* device_offsets,
     hipStream_t stream);
 
-/* The order in which nvcompBatched{LZ4,Snappy}DecompressAsync hands the chunks of a batch to its persistent waves when
- * the batch is large enough for them (more chunks than waves stay resident) and the temp buffer has the size
- * nvcompBatched<Fmt>DecompressGetTempSize reports: the chunks that will take longest first. The cost of a chunk is
- * estimated from the first tokens of its stream. Exposed for inspection and tests: after the call (on `stream`)
- * `device_order[0 .. batch_size)` is a permutation of the chunk indices and `device_cost_class[i]` the class (0 ... 15,
- * a power-of-two scale of the estimated sequence count) of chunk i. `device_temp_ptr` as for the decompress call. */
-nvcompStatus_t nvcompAmdBatchedLZ4DecompressOrderAsync(
+/* The token index that nvcompBatched{LZ4,Snappy}DecompressAsync builds per chunk when a batch runs on its persistent
+ * one-wave-per-chunk kernels and the temp buffer has the size nvcompBatched<Fmt>DecompressGetTempSize reports
+ * (csrc/common/lz_index.hip.h): the stream offsets of a PREFIX of the chunk's sequences, found by 64 joined serial walks,
+ * and the offset where the decoder's classic token chase takes over. Exposed for inspection and tests: after the call (on
+ * `stream`) chunk i has device_info[2 i] positions in device_lists[22016 i ...] (16 bits each, increasing; 22 016 =
+ * 64 x 344 entries of room per chunk) and
+ * device_info[2 i + 1] = the offset of the first sequence that is not in the list (0 entries, offset 0: a stream the
+ * index is not made for -- shorter than 2 KiB, longer than 65 535 bytes). */
+nvcompStatus_t nvcompAmdBatchedLZ4TokenIndexAsync(
     const void* const* device_compressed_ptrs,
     const size_t* device_compressed_bytes,
     size_t batch_size,
-    void* device_temp_ptr,
-    size_t temp_bytes,
-    unsigned* device_order,
-    unsigned char* device_cost_class,
-    hipStream_t stream);
-nvcompStatus_t nvcompAmdBatchedSnappyDecompressOrderAsync(
-    const void* const* device_compressed_ptrs,
-    const size_t* device_compressed_bytes,
-    size_t batch_size,
-    void* device_temp_ptr,
-    size_t temp_bytes,
-    unsigned* device_order,
-    unsigned char* device_cost_class,
+    unsigned short* device_lists,
+    unsigned* device_info,
     hipStream_t stream);
 
 #ifdef __cplusplus

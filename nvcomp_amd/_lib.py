@@ -124,9 +124,9 @@ def declare(lib: C.CDLL, formats=FORMATS) -> C.CDLL:
     if hasattr(lib, "nvcompAmdBatchedPackAsync"):  # include/nvcomp/amd_ext.h
         lib.nvcompAmdBatchedPackAsync.argtypes = [vp, vp, sz, vp, sz, vp, vp]
     for fmt in ("LZ4", "Snappy"):
-        fn = getattr(lib, f"nvcompAmdBatched{fmt}DecompressOrderAsync", None)
+        fn = getattr(lib, f"nvcompAmdBatched{fmt}TokenIndexAsync", None)
         if fn is not None:
-            fn.argtypes, fn.restype = [vp, vp, sz, vp, sz, vp, vp, vp], C.c_int
+            fn.argtypes, fn.restype = [vp, vp, sz, vp, vp, vp], C.c_int
     return lib
 
 

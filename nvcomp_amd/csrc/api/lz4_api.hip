@@ -17,7 +17,6 @@
 #include "lz4/lz4_decode.hip.h"
 #include "lz4/lz4_decode_window.hip.h"
 #include "common/lz_team.hip.h"
-#include "common/lz_order.hip.h"
 #include "lz4/lz4_encode.hip.h"
 
 namespace {
@@ -43,6 +42,15 @@ constexpr unsigned kWideWaves = NVCOMP_LZMW_WAVES_PER_BLOCK;
 #define NVCOMP_LZMW_WAVES_PER_SIMD 4 /* what the wave's LDS allows (15-16 waves per CU): a budget of 128 registers */
 #endif
 using lzl::kMaxOutCap;
+#ifndef NVCOMP_LZ_INDEX
+#define NVCOMP_LZ_INDEX 0 /* 1: the persistent one-wave-per-chunk kernel finds its sequences with the token index
+                           * (common/lz_index.hip.h). Built, parity-green and measured in round 6 (profiles/r06_token_index.json,
+                           * gpurun r6e ... r6k): 26 % fewer vector instructions per launch, and SLOWER -- 494 against 643 GB/s on the
+                           * headline batch: the index costs what the chase it replaces cost (built and thrown away: 500 GB/s), its
+                           * 310 wave-steps of ~55 instructions a chunk run with half the lanes idle. Off; the A/B build
+                           * lib/alt/libnvcomp_index.so and the tests keep it alive. */
+#endif
+static_assert(lzl::kIndexBytesPerWave >= lzx::kScratchPerWave, "a wave's slice of the temp buffer holds its token list");
 
 /* Profiling builds only (wrong output by construction): 1 = stop after the token chase, 2 = after the parse. */
 #ifndef NVCOMP_LZ4W_ABLATE
@@ -51,7 +59,7 @@ using lzl::kMaxOutCap;
 
 /* Decode chunk `chunk` of the batch with the calling wave and report its size and status. */
 template <bool CHECKED, class BatchPtr>
-__device__ __forceinline__ void decode_one(BatchPtr b, size_t chunk, uint8_t* lds)
+__device__ __forceinline__ void decode_one(BatchPtr b, size_t chunk, uint8_t* lds, uint8_t* index_scratch)
 {
   const uint8_t* in = wave::uniform_ptr((const uint8_t*)b->comp_ptrs[chunk]);
   uint8_t* out = wave::uniform_ptr((uint8_t*)b->out_ptrs[chunk]);
@@ -65,7 +73,7 @@ __device__ __forceinline__ void decode_one(BatchPtr b, size_t chunk, uint8_t* ld
   if (in_len64 > 0xffffffffull - 64) {
     err = lz::kErrInput;
   } else {
-    produced = lz4w::decode_chunk<CHECKED, NVCOMP_LZ4W_ABLATE>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err);
+    produced = lz4w::decode_chunk<CHECKED, NVCOMP_LZ4W_ABLATE>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err, index_scratch);
   }
   if (wave::lane_id() == 0) {
     size_t* actual_bytes = b->actual_bytes;
@@ -84,7 +92,7 @@ __global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_WAVES_PER_SIMD) lz4
 {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kDecWaves][lzw::kLdsPerWave];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
-  size_t place = (size_t)blockIdx.x * kDecWaves + w; /* the wave's place in the launch: chunk order[place] */
+  size_t place = (size_t)blockIdx.x * kDecWaves + w; /* the wave's place in the launch = its first chunk */
 #ifdef NVCOMP_LZW_PROF
   lzw::prof_begin();
 #endif
@@ -94,9 +102,13 @@ __global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_WAVES_PER_SIMD) lz4
     if (place >= a->b.batch_size) {
       break;
     }
-    const uint32_t* order = a->order;
-    const size_t chunk = order != nullptr ? (size_t)wave::uniform(order[place]) : place;
-    decode_one<CHECKED>(&a->b, chunk, lds[w]);
+    const size_t chunk = place;
+    /* the wave's slice of the temp buffer for the token index (the same for every chunk it decodes) */
+    uint8_t* index = a->index;
+    if (index != nullptr) {
+      index += ((size_t)blockIdx.x * kDecWaves + w) * lzl::kIndexBytesPerWave;
+    }
+    decode_one<CHECKED>(&a->b, chunk, lds[w], index);
     a = wave::kernel_args(launch);
     uint32_t* ticket = a->ticket;
     if (ticket == nullptr) {
@@ -215,6 +227,42 @@ __global__ void __launch_bounds__(64 * WAVES, 4) lz4_decompress_team_kernel(cons
 #ifdef NVCOMP_LZW_PROF
   lzw::prof_end();
 #endif
+}
+
+/* Inspection (include/nvcomp/amd_ext.h): the token index of every chunk, one wave each. */
+__global__ void __launch_bounds__(64) lz4_token_index_kernel(
+    const void* const* __restrict__ comp_ptrs, const size_t* __restrict__ comp_bytes, size_t batch_size, uint16_t* lists,
+    uint32_t* info)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t lds[lzx::kLdsBytes];
+  const size_t chunk = blockIdx.x;
+  if (chunk >= batch_size) {
+    return;
+  }
+  const uint8_t* in = wave::uniform_ptr((const uint8_t*)comp_ptrs[chunk]);
+  const size_t in_len64 = wave::uniform64(comp_bytes[chunk]);
+  /* the lists are built in the caller's buffer (64 x kLaneCap entries per chunk) and compacted in place: list k moves
+   * down behind list k - 1 (its destination never lies behind its source) */
+  uint16_t* mine = lists + chunk * (64 * (size_t)lzx::kLaneCap);
+  lzx::Index ix = lzx::build<lz4w::IndexFormat>(in, in_len64 <= lzx::kMaxStream ? (uint32_t)in_len64 : 0u, lds, (uint8_t*)mine);
+  uint32_t total = 0;
+  for (uint32_t k = 0; k < ix.lanes; ++k) {
+    const uint32_t nk = wave::read_lane(ix.n, k);
+    for (uint32_t base = 0; base < nk; base += 64) {
+      const uint32_t i = base + (uint32_t)wave::lane_id();
+      const uint32_t v = i < nk ? mine[k * lzx::kLaneCap + i] : 0u;
+      wave::sync();
+      if (i < nk) {
+        mine[total + i] = (uint16_t)v;
+      }
+      wave::sync();
+    }
+    total += nk;
+  }
+  if (wave::lane_id() == 0) {
+    info[2 * chunk] = total;
+    info[2 * chunk + 1] = ix.resume;
+  }
 }
 
 __global__ void __launch_bounds__(64 * kWavesPerBlock) lz4_decompress_size_kernel(
@@ -342,7 +390,7 @@ nvcompStatus_t nvcompBatchedLZ4DecompressGetTempSize(
   }
   /* the ticket counter of the persistent waves / workgroups (common/lz_launch.hip.h) */
   (void)max_uncompressed_chunk_bytes;
-  *temp_bytes = num_chunks == 0 ? 0 : num_chunks > lzl::kPairMaxBatch && NVCOMP_LZ_ORDERED ? lzo::temp_bytes(num_chunks) : lzl::kTicketBytes;
+  *temp_bytes = num_chunks == 0 ? 0 : num_chunks > lzl::kPairMaxBatch && NVCOMP_LZ_INDEX ? lzl::index_temp_bytes(num_chunks) : lzl::kTicketBytes;
   return nvcompSuccess;
 }
 
@@ -425,31 +473,30 @@ nvcompStatus_t nvcompBatchedLZ4DecompressAsync(
     }
   }
 #endif
-  /* ... and the expensive chunks first (common/lz_order.hip.h), when the temp buffer has room for the order */
-  const uint32_t* order = nullptr;
-  if (ticket != nullptr && NVCOMP_LZ_ORDERED) {
-    order = NVCOMP_LZ_ORDERED == 2 ? lzo::make_order_by_sizes<lzo::Lz4Cost>(b, device_temp_ptr, temp_bytes, stream)
-                                   : lzo::make_order<lzo::Lz4Cost>(b, device_temp_ptr, temp_bytes, stream);
-  }
-  const lzl::Launch launch = {b, ticket, (size_t)groups * kDecWaves, order};
+  uint8_t* index = NVCOMP_LZ_INDEX ? lzl::index_base(device_temp_ptr, temp_bytes, (size_t)groups * kDecWaves) : nullptr;
+  const lzl::Launch launch = {b, ticket, (size_t)groups * kDecWaves, index};
   hipLaunchKernelGGL((lz4_decompress_window_kernel<true>), dim3(groups), dim3(64 * kDecWaves), 0, stream, launch);
   return launch_status();
 }
 
-nvcompStatus_t nvcompAmdBatchedLZ4DecompressOrderAsync(
+nvcompStatus_t nvcompAmdBatchedLZ4TokenIndexAsync(
     const void* const* device_compressed_ptrs,
     const size_t* device_compressed_bytes,
     size_t batch_size,
-    void* device_temp_ptr,
-    size_t temp_bytes,
-    unsigned* device_order,
-    unsigned char* device_cost_class,
+    unsigned short* device_lists,
+    unsigned* device_info,
     hipStream_t stream)
 {
+  if (batch_size == 0) {
+    return nvcompSuccess;
+  }
+  if (device_compressed_ptrs == nullptr || device_compressed_bytes == nullptr || device_lists == nullptr || device_info == nullptr) {
+    return nvcompErrorInvalidValue;
+  }
   clear_stale_error();
-  const nvcompStatus_t st = lzo::order_for_inspection<lzo::Lz4Cost>(
-      device_compressed_ptrs, device_compressed_bytes, batch_size, device_temp_ptr, temp_bytes, device_order, device_cost_class, stream);
-  return st != nvcompSuccess ? st : launch_status();
+  hipLaunchKernelGGL(lz4_token_index_kernel, dim3((unsigned)batch_size), dim3(64), 0, stream, device_compressed_ptrs,
+                     device_compressed_bytes, batch_size, (uint16_t*)device_lists, (uint32_t*)device_info);
+  return launch_status();
 }
 
 nvcompStatus_t nvcompBatchedLZ4GetDecompressSizeAsync(

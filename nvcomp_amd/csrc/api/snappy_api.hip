@@ -17,7 +17,6 @@
 #include "snappy/snappy_decode.hip.h"
 #include "snappy/snappy_decode_window.hip.h"
 #include "common/lz_team.hip.h"
-#include "common/lz_order.hip.h"
 #include "snappy/snappy_encode.hip.h"
 
 namespace {
@@ -79,7 +78,7 @@ __global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_WAVES_PER_SIMD) sna
 {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kDecWaves][lzw::kLdsPerWave];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
-  size_t place = (size_t)blockIdx.x * kDecWaves + w; /* the wave's place in the launch: chunk order[place] */
+  size_t place = (size_t)blockIdx.x * kDecWaves + w; /* the wave's place in the launch = its first chunk */
 #ifdef NVCOMP_LZW_PROF
   lzw::prof_begin();
 #endif
@@ -89,8 +88,7 @@ __global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_WAVES_PER_SIMD) sna
     if (place >= a->b.batch_size) {
       break;
     }
-    const uint32_t* order = a->order;
-    const size_t chunk = order != nullptr ? (size_t)wave::uniform(order[place]) : place;
+    const size_t chunk = place;
     decode_one<CHECKED>(&a->b, chunk, lds[w]);
     a = wave::kernel_args(launch);
     uint32_t* ticket = a->ticket;
@@ -321,7 +319,7 @@ nvcompStatus_t nvcompBatchedSnappyDecompressGetTempSize(
   }
   /* the ticket counter of the persistent waves / workgroups (common/lz_launch.hip.h); the decoder itself keeps all state in
    * registers and LDS */
-  *temp_bytes = num_chunks == 0 ? 0 : num_chunks > lzl::kPairMaxBatch && NVCOMP_LZ_ORDERED ? lzo::temp_bytes(num_chunks) : lzl::kTicketBytes;
+  *temp_bytes = num_chunks == 0 ? 0 : lzl::kTicketBytes;
   return nvcompSuccess;
 }
 
@@ -404,31 +402,9 @@ nvcompStatus_t nvcompBatchedSnappyDecompressAsync(
     }
   }
 #endif
-  /* ... and the expensive chunks first (common/lz_order.hip.h), when the temp buffer has room for the order */
-  const uint32_t* order = nullptr;
-  if (ticket != nullptr && NVCOMP_LZ_ORDERED) {
-    order = NVCOMP_LZ_ORDERED == 2 ? lzo::make_order_by_sizes<lzo::SnappyCost>(b, device_temp_ptr, temp_bytes, stream)
-                                   : lzo::make_order<lzo::SnappyCost>(b, device_temp_ptr, temp_bytes, stream);
-  }
-  const lzl::Launch launch = {b, ticket, (size_t)groups * kDecWaves, order};
+  const lzl::Launch launch = {b, ticket, (size_t)groups * kDecWaves, nullptr};
   hipLaunchKernelGGL((snappy_decompress_window_kernel<true>), dim3(groups), dim3(64 * kDecWaves), 0, stream, launch);
   return launch_status();
-}
-
-nvcompStatus_t nvcompAmdBatchedSnappyDecompressOrderAsync(
-    const void* const* device_compressed_ptrs,
-    const size_t* device_compressed_bytes,
-    size_t batch_size,
-    void* device_temp_ptr,
-    size_t temp_bytes,
-    unsigned* device_order,
-    unsigned char* device_cost_class,
-    hipStream_t stream)
-{
-  clear_stale_error();
-  const nvcompStatus_t st = lzo::order_for_inspection<lzo::SnappyCost>(
-      device_compressed_ptrs, device_compressed_bytes, batch_size, device_temp_ptr, temp_bytes, device_order, device_cost_class, stream);
-  return st != nvcompSuccess ? st : launch_status();
 }
 
 nvcompStatus_t nvcompBatchedSnappyGetDecompressSizeAsync(

@@ -42,17 +42,6 @@
                                    * 750): 28 waves per CU already keep the vector, scalar and LDS pipes two thirds busy, four more
                                    * only add contention for L1 / L2 and the LDS pipe; 6 is worse again (607). */
 #endif
-#ifndef NVCOMP_LZ_ORDERED
-#define NVCOMP_LZ_ORDERED 0 /* 1: the persistent waves take the expensive chunks first (common/lz_order.hip.h). Built, parity-green and
-                             * measured in round 5 (gpurun r5j, mix, ordered against the caller's order): 65 536 chunks 676 = 675,
-                             * 32 768: 613 = 615, 16 384: 529 against 512 (+3 %), 8 192: 432 against 458 (-6 %), uniform text and the
-                             * sorted-key column -6 ... -7 % (the two kernels in front cost ~0.1 ms): the end of a launch is not
-                             * where medium batches lose their time. 2: the cheap variant, one kernel that looks at the sizes only and
-                             * hands the (nearly) incompressible and the highly compressible chunks out last (gpurun r5l, interleaved
-                             * A/B): 16 384 chunks +4 % (496-504 -> 514-524), 8 192 / 32 768 / 65 536 chunks and uniform batches +-1 %.
-                             * Off. (Nor is it the waves starting in the same phase: starts staggered by up to one batch period --
-                             * 16 K or 64 K cycles -- change nothing, gpurun r5m.) */
-#endif
 #ifndef NVCOMP_LZ_PERSISTENT
 #define NVCOMP_LZ_PERSISTENT 1 /* A/B: 0 = one wave per chunk, static mapping (round 2) */
 #endif
@@ -64,6 +53,26 @@ constexpr size_t kTeamMaxBatch = (size_t)(NVCOMP_LZ_TEAM_MAX_BATCH);
 constexpr size_t kTeam16MaxBatch = (size_t)(NVCOMP_LZ_TEAM16_MAX_BATCH) < kTeamMaxBatch ? (size_t)(NVCOMP_LZ_TEAM16_MAX_BATCH) : kTeamMaxBatch;
 constexpr uint32_t kMaxOutCap = 1u << 26;
 constexpr size_t kTicketBytes = 16; /* what the temp-size queries ask for: one u32 counter, padded */
+/* ... and, for the persistent one-wave-per-chunk launches, room for every wave's token index (common/lz_index.hip.h:
+ * 64 lists of 344 positions of 16 bits) behind it. The queries cannot ask the device how many waves stay resident: they assume at
+ * most kIndexMaxWaves (MI355X: 256 CUs x 28 = 7 168); a launch with more waves, or a caller with a smaller buffer, decodes
+ * without the index (same bytes, the round-5 speed). */
+constexpr size_t kIndexOffset = 64;
+constexpr size_t kIndexBytesPerWave = 45056;
+constexpr size_t kIndexMaxWaves = 8192;
+inline size_t index_temp_bytes(size_t num_chunks)
+{
+  const size_t waves = (num_chunks + 3) & ~(size_t)3;
+  return kIndexOffset + (waves < kIndexMaxWaves ? waves : kIndexMaxWaves) * kIndexBytesPerWave;
+}
+/* the index slices of a launch of `waves` waves inside the caller's temp buffer, or NULL when it has no room for them */
+inline uint8_t* index_base(void* temp, size_t temp_bytes, size_t waves)
+{
+  if (temp == nullptr || ((uintptr_t)temp & 7u) != 0 || temp_bytes < kIndexOffset + waves * kIndexBytesPerWave) {
+    return nullptr;
+  }
+  return (uint8_t*)temp + kIndexOffset;
+}
 
 /* The caller's arrays of one nvcompBatched<Fmt>DecompressAsync call. */
 struct Batch
@@ -84,7 +93,7 @@ struct Launch
   Batch b;
   uint32_t* ticket;
   size_t first_dynamic;
-  const uint32_t* order; /* place in the launch -> chunk (common/lz_order.hip.h: expensive chunks first); NULL: the caller's order */
+  uint8_t* index;        /* kIndexBytesPerWave bytes per wave of the launch for the token index (common/lz_index.hip.h); NULL: no index */
 };
 
 /* The same for the compressors: the caller's arrays of one nvcompBatched<Fmt>CompressAsync call. */

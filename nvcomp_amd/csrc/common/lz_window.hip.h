@@ -1063,9 +1063,17 @@ __device__ __forceinline__ void coop_match(OutWindow& ow, uint32_t hw, uint32_t 
  * compare ((x - lo) <= hi - lo), conditions that grow with the lane are tested once for the wave, and nothing is
  * masked that the callers' invariant already zeroes.
  */
-template <bool CHECKED, bool RING_LITERALS = false>
+struct NoHook
+{
+  __device__ __forceinline__ void operator()() const {}
+};
+
+/* `after_far`: called once per batch behind the point where the far matches' loads have been waited for (the decoders
+ * with a token index settle their prefetched positions there: common/lz_index.hip.h). */
+template <bool CHECKED, bool RING_LITERALS = false, class AfterFar = NoHook>
 __device__ __forceinline__ uint32_t execute_window_batch(
-    InRing& ir, OutWindow& ow, uint32_t out_cap, uint32_t& op, uint32_t n, const lz::Seq& s, uint32_t& err, bool& big)
+    InRing& ir, OutWindow& ow, uint32_t out_cap, uint32_t& op, uint32_t n, const lz::Seq& s, uint32_t& err, bool& big,
+    AfterFar after_far = AfterFar())
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   const uint32_t len = s.lit_len + s.match_len;
@@ -1233,6 +1241,7 @@ __device__ __forceinline__ uint32_t execute_window_batch(
     }
   }
   wave::sync();
+  after_far();
   LZW_T(7);
 
   /* ---- remaining matches, oldest first: multi-round resolution in LDS ---- */

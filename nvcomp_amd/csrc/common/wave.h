@@ -116,6 +116,13 @@ __device__ __forceinline__ int fresh_lane_id()
   return l;
 }
 
+/* "This value is used here": a register that a load is still filling is waited for at this point, not at its real use
+ * further down (the compiler places s_waitcnt in front of the first use). */
+__device__ __forceinline__ void touch(uint32_t& v)
+{
+  asm volatile("" : "+v"(v));
+}
+
 /* Is the calling lane's bit set in the wave-uniform mask? (v_cndmask with the mask as its condition: no 1ull << lane) */
 __device__ __forceinline__ bool lane_in(uint64_t mask)
 {

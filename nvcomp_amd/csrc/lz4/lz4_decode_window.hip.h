@@ -13,6 +13,7 @@
 #pragma once
 
 #include "common/lz_window.hip.h"
+#include "common/lz_index.hip.h"
 
 namespace lz4w {
 
@@ -332,6 +333,33 @@ __device__ __forceinline__ void parse_batch(const R& r, uint32_t p, uint32_t fro
   }
 }
 
+/* What the token index (common/lz_index.hip.h) needs to know of the format: the size of ONE sequence in the stream, from
+ * the 64 bytes a lane holds in its LDS block. Straight-line like DeltaFn::fast: one extension byte of the literal length,
+ * up to two of the match length (matches to 528 bytes); anything longer is "cannot tell" -- the index ends there and the
+ * chase above takes over. The bytes behind the literals are read whatever the token says (a read behind the block lands in
+ * the wave's own LDS and is not used). */
+struct IndexFormat
+{
+  static __device__ __forceinline__ uint32_t first_token(const uint8_t*, uint32_t) { return 0; }
+  /* the token at block offset o (o + 1 < kBlock): true = its successor starts at next_o (which may lie behind the block:
+   * the walk refills there); false = the block does not hold what it takes (ok: a refill at the token will; !ok: never) */
+  static __device__ __forceinline__ bool step(const uint8_t* blk, uint32_t o, uint32_t& next_o, bool& ok)
+  {
+    const uint32_t t = blk[o], e1 = blk[o + 1];
+    const uint32_t code = t >> 4;
+    const bool c15 = code == 15;
+    const uint32_t d0 = 3 + code + (c15 ? e1 + 1u : 0u); /* to the byte a match-length extension would use */
+    const uint32_t o2 = o + d0;
+    const uint32_t e2 = blk[o2], e3 = blk[o2 + 1];
+    const bool m15 = (t & 15u) == 15u;
+    const bool fits = !m15 | (o2 + 1 < lzx::kBlock); /* only a long match looks at the bytes behind the offset */
+    const bool m2 = m15 & fits & (e2 == 255);
+    next_o = o2 + (m15 ? (m2 ? 2u : 1u) : 0u);
+    ok = !((c15 & (e1 == 255)) | (m2 & (e3 == 255)));
+    return ok & fits;
+  }
+};
+
 /* What the workgroup-per-chunk decoder (common/lz_team.hip.h) needs to know of the format. */
 struct TeamFrontEnd
 {
@@ -362,19 +390,30 @@ struct TeamFrontEnd
  * token chase, 2 = after the parse, 0 = the real decoder. */
 template <bool CHECKED, int ABLATE = 0>
 __device__ __forceinline__ uint32_t decode_chunk(
-    const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_cap, uint8_t* lds, uint32_t& err)
+    const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_cap, uint8_t* lds, uint32_t& err,
+    uint8_t* index_scratch = nullptr)
 {
   const uint32_t lane = (uint32_t)wave::lane_id();
   err = lz::kErrNone;
   if (in_len == 0) {
     return 0;
   }
+  /* where the sequences start: the token index (common/lz_index.hip.h) when the caller's temp buffer has room for it --
+   * a prefix of the chunk's tokens; the chase below takes over where it ends (at once without an index). The index is
+   * built in the LDS that the ring, the window and the jump tables use afterwards. */
+  static_assert(lzx::kLdsBytes <= lzw::kLdsPerWave, "the index is built in the wave's own LDS");
+  LZW_T(9);
+  lzx::Index ix = lzx::build<IndexFormat>(in, in_len, lds, index_scratch);
+  LZW_T(15); /* the token index */
+#ifdef NVCOMP_LZX_BUILD_ONLY /* profiling builds only: the index is built and thrown away (what the walk costs in place) */
+  ix.lanes = 0, ix.ahead_n = 0, ix.resume = 0;
+#endif
   lzw::InRing ir;
   lzw::OutWindow ow;
   lzw::in_init(ir, in, in_len, lds + lzw::kOutLds);
   lzw::out_init(ow, out, lds);
   lzw::Chase c;
-  lzw::chase_init(c, ir.vbeg, lds + lzw::kOutLds + lzw::kInLds);
+  lzw::chase_init(c, ir.vbeg + ix.resume, lds + lzw::kOutLds + lzw::kInLds);
   uint32_t op = 0;
   uint32_t seqpos = 0;
   uint32_t count = 0; /* sequences recorded in seqpos lanes [0, count) and not yet executed */
@@ -394,12 +433,23 @@ __device__ __forceinline__ uint32_t decode_chunk(
   s.match_off = 0;
   s.match_len = 0;
   for (;;) {
-    if (count == 0 && c.q >= ir.vend) {
+    const bool indexed = lzx::more(ix);
+    if (count == 0 && !indexed && c.q >= ir.vend) {
       break;
     }
     uint32_t before = NVCOMP_LZ4W_KEEP_PARSED ? count : 0u; /* lanes [before, count) are parsed this round */
-    const bool refill = count < kRefillBelow && c.q < ir.vend;
-    if (refill) {
+    const bool refill = count < kRefillBelow && (indexed || c.q < ir.vend);
+    if (refill && indexed) {
+      /* the next token positions out of the index */
+      LZW_T(10);
+      count = lzx::read(ix, seqpos, count, ir.vbeg);
+      if (count == 0) {
+        continue; /* (the lists that were left held nothing: the chase takes over) */
+      }
+      const uint32_t oldest = wave::read_lane(seqpos, 0);
+      lzw::in_ensure(ir, oldest, (oldest & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
+      LZW_T(0);
+    } else if (refill) {
       /* keep the stream resident from the oldest unexecuted token to well past the chase */
       const uint32_t oldest = count ? wave::read_lane(seqpos, 0) : c.q;
       LZW_T(10);
@@ -431,7 +481,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
       }
     }
     bool big;
-    uint32_t take = lzw::execute_window_batch<CHECKED>(ir, ow, out_cap, op, count, s, err, big);
+    uint32_t take = lzw::execute_window_batch<CHECKED, false>(ir, ow, out_cap, op, count, s, err, big, [&ix]() { lzx::settle(ix); });
     if (CHECKED && err) {
       return 0;
     }

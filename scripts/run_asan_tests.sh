@@ -9,7 +9,7 @@ ASAN=$(gcc -print-file-name=libasan.so)
 rm -f /tmp/nvcomp_asan.*
 rc=0
 for t in tests/test_fuzz_corrupt.py tests/test_fuzz_decode.py tests/test_bitcomp.py tests/test_ans.py tests/test_cascaded.py \
-         tests/test_lz4_decode.py tests/test_lz4_encode.py tests/test_snappy.py tests/test_golden_decode.py tests/test_deflate.py tests/test_chunk_order.py; do
+         tests/test_lz4_decode.py tests/test_lz4_encode.py tests/test_snappy.py tests/test_golden_decode.py tests/test_deflate.py tests/test_token_index.py; do
   LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:log_path=/tmp/nvcomp_asan \
     python -m pytest $t -x -q -m "not gpu" 2>&1 | grep -v "^Extension" | tail -1
 done
