@@ -1032,6 +1032,11 @@ __device__ __forceinline__ bool stream_sequence(
   return true;
 }
 
+/* (Round 6 measured a path of its own for "a few literals, then a long match of period 1 .. 16" -- the sequences of sorted
+ * key columns --: the whole wave executed such a sequence alone, sources in LDS, the run's aligned block stored straight to HBM,
+ * no batch around it. ~150 instructions a sequence against the ~100 the batch executor spends on it amortised: sorted-key
+ * column (HC) 2 166 -> 1 720 GB/s, int32 column 1 476 -> 1 262, gpurun r6l. Gone; what these chunks need is several runs in
+ * flight at once, not a shorter path for one.) */
 /* A match copied by the whole wave into the window at output position hw (everything below hw is final): its source
  * may start in front of what the window holds -- those bytes are in HBM (flushed before the window let go of them). */
 __device__ __forceinline__ void coop_match(OutWindow& ow, uint32_t hw, uint32_t foff, uint32_t flen)

@@ -347,3 +347,34 @@ def test_get_decompress_size(backend, oracle):
     sizes = backend.codec("LZ4").get_decompress_size(comp)
     assert sizes.tolist() == [c.size for c in chunks]
     assert sizes.tolist() == [oracle.lz4_decompressed_size(c) for c in comp]
+
+
+def test_runs_executed_by_the_whole_wave(backend, lz_path, oracle):
+    """A few literals and a long match of period 1 .. 16 -- the shape of sorted key columns: trains of such sequences, runs at
+    the very start of a chunk, runs whose literals are 0 .. 32 bytes, ordinary sequences in between; a run that ends behind
+    the capacity or points in front of the chunk fails the chunk and nothing is written behind the slot."""
+    rng = np.random.RandomState(31)
+    blocks, raws = [], []
+    for off in (1, 2, 4, 8, 16):
+        seqs = [(rng.randint(0, 256, size=off).astype(np.uint8).tobytes(), off, 200)]  # the chunk opens with a run
+        for j in range(60):
+            lit = rng.randint(0, 256, size=(j * 5) % 33).astype(np.uint8).tobytes()
+            seqs.append((lit, off, 128 + (j * 37) % 900))
+            if j % 7 == 3:
+                seqs.append((b"xy", 3, 9))  # an ordinary sequence between two runs
+        tail = b"the end"
+        blocks.append(_lz4_block(seqs, tail))
+        raws.append(_lz4_expand(seqs, tail))
+    for cc, c in zip(blocks, raws):
+        rc, ref = oracle.lz4_decompress(cc, c.size)
+        assert rc == 0 and np.array_equal(ref, c)
+    for mis in (0, 3, 9):
+        check_roundtrip(backend, oracle, raws, blocks, base_misalign=mis)
+    codec = backend.codec("LZ4")
+    # capacity 50 bytes short of a run's end; an offset of 16 with 8 bytes produced
+    short = _lz4_block([(b"abcdefgh", 8, 400), (b"ij", 8, 300)], b"tail!")
+    wrong = _lz4_block([(b"abcdefgh", 16, 400)], b"tail!")
+    good = _lz4_block([(b"abcdefgh", 8, 400)], b"tail!")
+    outs, actual, status = codec.decompress([short, wrong, good], [8 + 400 + 2 + 250, 1000, 8 + 400 + 5])
+    assert status[0] != 0 and status[1] != 0 and status[2] == 0
+    assert np.array_equal(outs[2], _lz4_expand([(b"abcdefgh", 8, 400)], b"tail!"))
