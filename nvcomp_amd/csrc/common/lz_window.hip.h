@@ -337,7 +337,11 @@ __device__ __forceinline__ void chase_build(Chase& c, const R& r, Delta delta, u
 }
 
 /* Append token positions to seqpos lanes [k, 64); returns the new count. `slow(r, p)`
- * gives the successor of the token at p when its delta is kUnknownDelta. */
+ * gives the successor of the token at p when its delta is kUnknownDelta.
+ * (A window's ~54 tokens and a batch's 64 never line up: every batch enumerates 2.2 times. Round 6 kept what an
+ * enumeration found and the batch had no room for in a register and handed it to the next batch with a shuffle -- 36 vector
+ * instructions fewer per batch, and slower: mix 648 -> 646 GB/s, Snappy 481 -> 473, text 596 -> 558 (gpurun r6n); one more
+ * live register and two more branches in this loop cost more than the table walk they save. Not kept.) */
 template <class R, class Delta, class Slow>
 __device__ __forceinline__ uint32_t chase_tokens(
     Chase& c, const R& r, uint32_t& seqpos, uint32_t k, Delta delta, Slow slow)
