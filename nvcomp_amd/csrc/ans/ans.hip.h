@@ -34,7 +34,7 @@
 namespace ans {
 
 #ifndef NVCOMP_ANS_PROB_BITS
-#define NVCOMP_ANS_PROB_BITS 10 /* format constant (profiles/r01_ans_prob_bits.json); other values are for A/B builds only */
+#define NVCOMP_ANS_PROB_BITS 10 /* format constant (profiles/archive/r01_ans_prob_bits.json); other values are for A/B builds only */
 #endif
 constexpr uint32_t kProbBits = NVCOMP_ANS_PROB_BITS;
 constexpr uint32_t kProbScale = 1u << kProbBits;

@@ -20,7 +20,7 @@ constexpr uint32_t kHeaderBytes = 20;
 /* Decode runs three passes with growing LDS per wave; a sub-chunk's need follows from its actual stream counts
  * (casc::decompress_sub), so compressible data is decoded by the first pass at full occupancy. */
 /* The first pass of each direction: 4 waves per workgroup, its own LDS slice per wave and register budget (workgroups
- * per CU in __launch_bounds__). Swept on hardware in round 3 (profiles/r03_cascaded_passes.jsonl, 1 GiB, compress /
+ * per CU in __launch_bounds__). Swept on hardware in round 3 (profiles/archive/r03_cascaded_passes.jsonl, 1 GiB, compress /
  * decompress GB/s):
  *   compress   8 workgroups x 5 KiB (64 VGPRs, 16 spilled): float columns 690, int32 column 1 670, int64 key column 2 485
  *              6 workgroups x 6.25 KiB (85 VGPRs, 2 spilled): 785 / 1 666 / 2 712 -- and the float columns, whose sub-chunks

@@ -798,9 +798,11 @@ struct LayerMeta
 
 /* Compress one sub-chunk with the calling wave into dst; returns its size, or kSubNeedsLds when the
  * intermediate streams do not fit the `budget` bytes of LDS at `lds` (nothing final has been decided then:
- * the caller repeats the whole chunk in a pass with a larger slice). With at least one RLE layer the input is
- * never staged: the first layer reads it from HBM and only its (values, runs) output lives in LDS, so a
- * compressible sub-chunk needs a fraction of the worst case.
+ * the caller repeats the whole chunk in a pass with a larger slice). With any layer at all the sub-chunk is staged into
+ * V once (round 5) and every layer works on LDS; what a compressible sub-chunk saves is the run pool, not the staging.
+ * Since round 5 an RLE layer that would take out fewer than one element in eight is written as an identity layer (run
+ * lengths of 1): streams of that rule decode with every earlier build of the decoder -- an identity layer is an ordinary
+ * run-length stream -- but they are not the bytes the earlier compressors wrote.
  * Every layer's run stream is packed into dst as soon as the layer has run -- the streams are laid out in layer
  * order, so its position is known -- which leaves ONE run pool, reused by every layer: the worst case is the value
  * buffer plus 2 bytes per element, whatever num_RLEs is. A sub-chunk that stops shrinking is stored raw; the
@@ -907,14 +909,7 @@ __device__ __forceinline__ uint32_t compress_sub(
       CASC_T(10); /* compress: run stream ranged and packed */
     }
     if (l < p.num_deltas) {
-      if (cur == in) { /* nothing has moved the data into V yet */
-        for (uint32_t i = lane; i < n; i += 64) {
-          V[i] = in[i];
-        }
-        wave::sync();
-        cur = V;
-      }
-      delta_encode(V, c);
+      delta_encode(V, c); /* (the sub-chunk has been in V since the staging above) */
       CASC_T(11); /* compress: staging + delta */
     }
   }

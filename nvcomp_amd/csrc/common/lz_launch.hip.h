@@ -37,7 +37,7 @@
 #endif
 #ifndef NVCOMP_LZ_MAX_WG_PER_CU
 #define NVCOMP_LZ_MAX_WG_PER_CU 7 /* cap on the persistent workgroups (of four waves) per CU; 0 = as many as stay resident.
-                                   * Measured on MI355X (profiles/r03_ab_g.jsonl): the decoders fit 8 waves/SIMD since they stopped
+                                   * Measured on MI355X (profiles/archive/r03_ab_g.jsonl): the decoders fit 8 waves/SIMD since they stopped
                                    * spilling, and run SLOWER there than at 7 (LZ4 mix 632 vs 644 GB/s, sorted-key column 686 vs
                                    * 750): 28 waves per CU already keep the vector, scalar and LDS pipes two thirds busy, four more
                                    * only add contention for L1 / L2 and the LDS pipe; 6 is worse again (607). */

@@ -41,19 +41,19 @@ namespace lzm {
 #define NVCOMP_LZM_HASH_BITS 12
 #endif
 /* One-byte tags beside the positions (A/B build): a probe would look at the candidate's bytes in memory only when eight
- * more hash bits agree. Measured (profiles/r02_lz_compress.json): no gain -- the compressor is bound by the LENGTH of its
+ * more hash bits agree. Measured (profiles/archive/r02_lz_compress.json): no gain -- the compressor is bound by the LENGTH of its
  * dependent chain per window, not by the candidate fetches -- and the extra 4 KiB of LDS per wave cost occupancy. Off. */
 /* The position side of a window (the 40 bytes around each of its 64 positions) comes out of a per-wave LDS image of the
  * input, filled 512 bytes at a time by ONE coalesced load per lane, instead of four byte-strided lane loads per window:
  * those cost the L1 (TCP) one tag lookup per lane and instruction -- 10.3 G lookups per GiB, one per cycle and CU for
- * the whole kernel (profiles/r02_lz_compress.json, counters). 0 = the round-2 register path (A/B build). */
+ * the whole kernel (profiles/archive/r02_lz_compress.json, counters). 0 = the round-2 register path (A/B build). */
 #ifndef NVCOMP_LZM_STAGE
 #define NVCOMP_LZM_STAGE 1
 #endif
 /* ---- the output staging (NVCOMP_LZM_STAGE_OUT, A/B build) ----
  * The sequences of a window composed in LDS and written with ONE coalesced store of consecutive dwords (up to three bytes
  * wait for the next window) instead of five or six scattered store instructions. Built and measured in round 3
- * (profiles/r03_compress_ab.jsonl): 115.9 against 117.9 GB/s on the mix, 111.3 against 113.7 for Snappy -- the scattered
+ * (profiles/archive/r03_compress_ab.jsonl): 115.9 against 117.9 GB/s on the mix, 111.3 against 113.7 for Snappy -- the scattered
  * stores of ten lanes are not what the address unit is busy with (the candidate loads of 64 lanes are), and the 256 bytes
  * come out of the hash table. Off. */
 #ifndef NVCOMP_LZM_STAGE_OUT

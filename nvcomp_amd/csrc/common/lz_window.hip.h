@@ -2,7 +2,7 @@
  * common/lz_window.hip.h -- LDS-staged, sequence-parallel LZ77 batch executor
  * shared by the LZ4 and Snappy decoders (one wavefront per chunk).
  *
- * Measured on MI355X (profiles/r01_v1_direct_pmc.json): decoding straight to
+ * Measured on MI355X (profiles/archive/r01_v1_direct_pmc.json): decoding straight to
  * HBM leaves a wave waiting on memory 62 % of its cycles -- every literal/match
  * step is a dependent global load->store round trip -- and reads 10x the
  * algorithmic bytes (partial-line writes and far match sources miss the L2).
@@ -28,14 +28,14 @@ namespace lzw {
 
 /* Tunables (overridable with -D for the A/B builds of scripts/build_variants.sh). */
 /* The output window holds ONE BATCH: the bytes a batch produces (at most kBatchMax) plus the tail of the previous one
- * that still waits for its 16-byte block to fill up -- and 32 bytes of history, no more. Measured on MI355X (profiles/r03_ab_*.jsonl): 84 % of
+ * that still waits for its 16-byte block to fill up -- and 32 bytes of history, no more. Measured on MI355X (profiles/archive/r03_ab_*.jsonl): 84 % of
  * the matches of the headline workload reach further back than any window that fits the LDS budget (61 % further than
  * 4 KiB), so history only turned a twentieth of the far matches into near ones, and paid for it with 1 KiB of LDS per
  * wave and a slide of 768 bytes every other batch: without it +1.6 % (LZ4 mix), +2.4 % (Snappy), +7 % (text, 1 GiB
- * batches). Rounds 1-2 kept 768 bytes of a 2 KiB window (profiles/r01_window_variants.json). A batch may produce up to
+ * batches). Rounds 1-2 kept 768 bytes of a 2 KiB window (profiles/archive/r01_window_variants.json). A batch may produce up to
  * 2 KiB: 5 712 B of LDS per wave still fit seven waves per SIMD (163 840 / 28), 64 sequences of text never get there,
  * and data with long matches pays the per-batch costs half as often (sorted-key column 749 -> 887 GB/s, int32 column
- * 684 -> 778, profiles/r03_ab_h.jsonl). */
+ * 684 -> 778, profiles/archive/r03_ab_h.jsonl). */
 #ifndef NVCOMP_LZW_BATCHMAX
 #define NVCOMP_LZW_BATCHMAX 2048
 #endif
@@ -1128,7 +1128,7 @@ __device__ __forceinline__ uint32_t execute_window_batch(
   /* ---- far matches: sources the window no longer holds, read from HBM ---- */
   const uint32_t match_src = match_dst - s.match_off;
   /* DEFLATE (RING_LITERALS) has matches of THREE bytes -- a sixth of all matches of a zlib stream, and as whole-wave
-   * copies, one after the other, they were 18 % of that decoder's time (phase clock, profiles/r03_deflate_phases.json) */
+   * copies, one after the other, they were 18 % of that decoder's time (phase clock, profiles/archive/r03_deflate_phases.json) */
   constexpr uint32_t kMinShort = RING_LITERALS ? 3 : 4;
   const bool short_match = my_match - kMinShort <= kMatchShort - kMinShort; /* kMinShort .. kMatchShort */
   const bool is_near = my_match != 0 && match_src >= ow.valid_lo;
@@ -1144,7 +1144,7 @@ __device__ __forceinline__ uint32_t execute_window_batch(
 #else
     const uint8_t* src = ow.out + match_src;
 #endif
-    /* A scattered load costs the CU's address unit a slot per lane whatever its width (profiles/r02_decode_phases.json:
+    /* A scattered load costs the CU's address unit a slot per lane whatever its width (profiles/archive/r02_decode_phases.json:
      * issuing 3-9 dword loads per batch was 11 % of the wave's time): 16 bytes per load, two loads at most, plus the
      * match's last dword. */
     const wave::u32x4 f0 = wave::gload_u32x4(src);

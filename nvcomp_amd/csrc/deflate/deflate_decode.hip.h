@@ -17,7 +17,7 @@
  *              an illegal symbol) is left to a wave-uniform decoder that takes one symbol at a time (the scalar
  *              unit: a 64-bit bit buffer in SGPRs); block headers and table construction are wave-uniform /
  *              wave-cooperative too. The symbol-at-a-time decoder alone runs at 23 GB/s: the CU's single scalar
- *              unit is the bound (profiles/r02_deflate.json);
+ *              unit is the bound (profiles/archive/r02_deflate.json);
  *   back end   64 records at a time (at most lzw::kBatchMax output bytes) are executed by the LZ window executor the
  *              LZ4 and Snappy decoders use (common/lz_window.hip.h): lane k copies sequence k inside the LDS output
  *              window, far matches (up to 32 KiB back) come from HBM, the window is flushed in aligned 16-byte stores.
@@ -59,7 +59,7 @@ constexpr uint32_t kRunMax = 255;  /* literal bytes per sequence record (8 bits 
 constexpr uint32_t kRunClose = 192; /* a pending run this long is closed as a record of its own between rounds */
 /* 512 positions per window (8 per lane) halve the table builds and cut the enumerations by a third (counted on the host
  * emulation: 2.3 -> 1.16 builds and 3.7 -> 2.6 enumerations per round of 49 symbols). On the card that is worth 2-3 %
- * (profiles/r03_deflate_scan.jsonl: at 10 KiB + 1.25 KiB of LDS per wave it was neutral against 256 at 10 KiB; with the
+ * (profiles/archive/r03_deflate_scan.jsonl: at 10 KiB + 1.25 KiB of LDS per wave it was neutral against 256 at 10 KiB; with the
  * rings at 1 KiB, 512 at 9.1 KiB = 17 waves per CU reads 80.1 / 97.3 GB/s at 1 / 4 GiB against 77.7 / 95.8 for 256 at
  * 7.8 KiB = 20 waves): the decoder is bound by the NUMBER of instructions per symbol -- 17 vector + 14 scalar, of which
  * the speculative decode of every bit position is the largest part and does not depend on the window -- more than by the

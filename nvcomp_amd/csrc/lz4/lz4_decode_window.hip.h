@@ -58,7 +58,7 @@ __device__ __forceinline__ uint32_t leading_255(uint64_t f)
  * straight-line DeltaFn::fast() gave up on. Up to two extension bytes of the literal length (runs to 524 bytes) and SIX
  * of the match length (to 1 548 bytes): a sorted key column compressed by liblz4 -- the reference's published shape --
  * is all matches of 170 .. 680 bytes, and with one extension byte every one of its tokens left the chase through the
- * scalar slow path, one enumeration per token (profiles/r03_pmc_mortgage.json: 155 scalar instructions per sequence).
+ * scalar slow path, one enumeration per token (profiles/archive/r03_pmc_mortgage.json: 155 scalar instructions per sequence).
  * Longer fields -> kUnknown -> chase_slow_next(). */
 template <class R>
 __device__ __forceinline__ uint32_t token_delta(const R& r, uint32_t p)
@@ -419,7 +419,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
   uint32_t count = 0; /* sequences recorded in seqpos lanes [0, count) and not yet executed */
   /* A batch ends at 1 KiB of output, so on data with long matches (runs, sorted key columns: 200-400 bytes per
    * sequence) a round executes only a handful of the 64 sequences a chase delivers: chasing again for the rest every
-   * round was 5 000 cycles per SEQUENCE on the reference's own published shape (profiles/r02_mortgage_like.json).
+   * round was 5 000 cycles per SEQUENCE on the reference's own published shape (profiles/archive/r02_mortgage_like.json).
    * The chase runs only when fewer than kRefillBelow token positions are left; on text a round takes all 64 and
    * every round refills, as before. NVCOMP_LZ4W_KEEP_PARSED = 1 also keeps the parsed FIELDS in registers across
    * rounds (four more live registers); 0 parses the positions in hand again every round (two LDS round trips). */
@@ -511,7 +511,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
  *
  * One wave per chunk leaves the card under-filled below ~7 000 chunks, and a 64 KiB chunk takes a wave ~0.75 ms
  * however idle the CU is: the wave's own dependent chain -- chase, parse, far loads, copy rounds, flush -- is what
- * takes the time (profiles/r02_decode_phases.json). For small batches the chain is cut in two: wave 0 of a 128-thread
+ * takes the time (profiles/archive/r02_decode_phases.json). For small batches the chain is cut in two: wave 0 of a 128-thread
  * workgroup (the PRODUCER) runs the token chase and the parse and hands batches of parsed sequences to wave 1 (the
  * CONSUMER), which executes them; the two overlap, a chunk takes about as long as its slower half. Hand-over is a
  * two-slot queue in LDS with one flag word per slot (wave::lds_store_release / lds_load_acquire). The producer never

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 evidence run: smoke + full GPU test tier, HBM traffic passes FIRST (scripts/gpu_traffic.sh -> profiles/pmc_traffic_r03.json,
+# Round-3 evidence run: smoke + full GPU test tier, HBM traffic passes FIRST (scripts/gpu_traffic.sh -> profiles/archive/pmc_traffic_r03.json,
 # which the bench lines below then replay), the driver's bench line and the other codecs' lines, rocprofv3 kernel stats of
 # the same commands, PMC instruction / stall passes (LZ4, Snappy, mortgage-like), N sweep, data-class sweep, HLIF.
 # usage: gpu_r3_final.sh <tag> [notests]
@@ -15,7 +15,7 @@ if [ "${2:-}" != "notests" ]; then
   timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$OUT/rc.txt"
 fi
 bash scripts/gpu_traffic.sh "$TAG/traffic" > "$OUT/traffic.log" 2>&1; echo "traffic rc=$?" >> "$OUT/rc.txt"
-[ -s "$OUT/traffic/pmc_traffic_r03.json" ] && cp "$OUT/traffic/pmc_traffic_r03.json" profiles/pmc_traffic_r03.json
+[ -s "$OUT/traffic/pmc_traffic_r03.json" ] && cp "$OUT/traffic/pmc_traffic_r03.json" profiles/archive/pmc_traffic_r03.json
 timeout 600 python bench.py > "$OUT/bench_lz4.json" 2> "$OUT/bench_lz4.err"; echo "bench lz4 rc=$?" >> "$OUT/rc.txt"
 for a in snappy cascaded bitcomp ans deflate; do
   timeout 400 python bench.py --algo $a --no-riders > "$OUT/bench_$a.json" 2> "$OUT/bench_$a.err"; echo "bench $a rc=$?" >> "$OUT/rc.txt"

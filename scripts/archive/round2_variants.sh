@@ -1,6 +1,6 @@
 #!/bin/bash
 # Local build of the A/B libraries prepared (not yet measured) at the end of round 1; run before
-# `gpurun -- 'bash scripts/gpu_round2_ab.sh <tag>'`. See DESIGN.md section 6 and profiles/r01_occupancy_variants.json.
+# `gpurun -- 'bash scripts/gpu_round2_ab.sh <tag>'`. See DESIGN.md section 6 and profiles/archive/r01_occupancy_variants.json.
 set -e
 cd "$(dirname "$0")/.."
 rm -f nvcomp_amd/lib/alt/*.so

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5: counters of the LZ compressors (instructions, L1 lookups, fabric traffic: separate --pmc passes) and the round
 # trip of the GPU-compressed mix at 16 384 chunks beside the HC-compressed one (scripts/ab_decode.py case mix1g).
-# usage: gpu_r5c.sh <tag>
+# usage: gpu_compress_counters.sh <tag>
 set -u
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$REPO"

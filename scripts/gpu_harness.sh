@@ -6,7 +6,7 @@
 #   benchmark_snappy_synth (4 000 chunks of gen_data(3), the reference's defaults)              benchmark_snappy_synth.cpp:161-193
 #   benchmark_lz4_synth (zeros / noise, 64 KiB x 2^b, b = 0 .. 13)                              benchmark_lz4_synth.cpp:64-72
 #   examples/lz4_cpu_compression on ExampleFloatData.csv (config 1: liblz4 HC on the host, ratio = BASELINE.md section 2)
-# usage: gpu_r4_harness.sh <tag>   (scripts/stage_fixtures.sh must have run in the container: benchmarks/data/)
+# usage: gpu_harness.sh <tag>   (scripts/stage_fixtures.sh must have run in the container: benchmarks/data/)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp

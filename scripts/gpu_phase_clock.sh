@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6: phase clocks (-DNVCOMP_LZW_PROF builds under nvcomp_amd/lib/alt: scripts/build_variants.sh prof "-DNVCOMP_LZW_PROF" ...)
-# usage: gpu_r6_prof.sh <tag> "<lib tags>" "<algos>" [bench args]
+# usage: gpu_phase_clock.sh <tag> "<lib tags>" "<algos>" [bench args]
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
