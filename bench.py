@@ -1046,10 +1046,10 @@ def main():
         import ctypes
         import nvcomp_amd
         lib = nvcomp_amd.load_library()
-        slots = (ctypes.c_ulonglong * 16)()
+        slots = (ctypes.c_ulonglong * 20)()
         names = ["in_ensure", "chase_build", "chase_enum", "parse", "exec_prep", "make_room", "literals_4_32",
                  "far_store", "match_rounds", "flush", "loop_top", "far_issue", "literals_1_3", "literals_long",
-                 "matches_whole_wave", "token_index"]
+                 "matches_whole_wave", "token_index", "run_patterns", "run_joints", "run_bodies", "run_restart"]
         reader = "nvcompAmdProfReadSnappy" if args.algo == "snappy" else "nvcompAmdProfRead"
         if args.algo == "snappy":
             names[15] = "copy_trains"
@@ -1058,7 +1058,7 @@ def main():
             for i, n in ((0, "headers_and_code_tables"), (1, "window_tables"), (2, "enumerations"), (3, "round_decode_and_records"),
                          (10, "symbols_one_at_a_time"), (15, "front_end_rest")):
                 names[i] = n
-        if hasattr(lib, reader) and getattr(lib, reader)(slots, 16) > 0:
+        if hasattr(lib, reader) and getattr(lib, reader)(slots, 20) > 0:
             tot = float(sum(slots)) or 1.0
             print(json.dumps({"phase_share": {n: round(v / tot, 4) for n, v in zip(names, slots)},
                               "cycles_total": tot}), file=sys.stderr, flush=True)

@@ -42,6 +42,10 @@ constexpr unsigned kWideWaves = NVCOMP_LZMW_WAVES_PER_BLOCK;
 #define NVCOMP_LZMW_WAVES_PER_SIMD 4 /* what the wave's LDS allows (15-16 waves per CU): a budget of 128 registers */
 #endif
 using lzl::kMaxOutCap;
+#ifndef NVCOMP_LZ4_RUNS_RATIO
+#define NVCOMP_LZ4_RUNS_RATIO 8
+#endif
+constexpr size_t kRunsRatio = NVCOMP_LZ4_RUNS_RATIO;
 #ifndef NVCOMP_LZ_INDEX
 #define NVCOMP_LZ_INDEX 0 /* 1: the persistent one-wave-per-chunk kernel finds its sequences with the token index
                            * (common/lz_index.hip.h). Built, parity-green and measured in round 6 (profiles/r06_token_index.json,
@@ -73,7 +77,13 @@ __device__ __forceinline__ void decode_one(BatchPtr b, size_t chunk, uint8_t* ld
   if (in_len64 > 0xffffffffull - 64) {
     err = lz::kErrInput;
   } else {
-    produced = lz4w::decode_chunk<CHECKED, NVCOMP_LZ4W_ABLATE>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err, index_scratch);
+    /* a chunk that shrank 8 x or more (by the caller's capacity: an LZ4 block does not say what it decodes to) takes the
+     * instance of the loop that tries the run executor; everything else the one without it (lz4w::decode_chunk) */
+    if (NVCOMP_LZW_RUNS && in_len64 * kRunsRatio <= cap64) {
+      produced = lz4w::decode_chunk<CHECKED, NVCOMP_LZ4W_ABLATE, true>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err, index_scratch);
+    } else {
+      produced = lz4w::decode_chunk<CHECKED, NVCOMP_LZ4W_ABLATE, false>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err, index_scratch);
+    }
   }
   if (wave::lane_id() == 0) {
     size_t* actual_bytes = b->actual_bytes;
@@ -153,7 +163,8 @@ __global__ void __launch_bounds__(128, 4) lz4_decompress_pair_kernel(const lzl::
   uint32_t err = too_long ? lz::kErrInput : lz::kErrNone;
   uint32_t produced = 0;
   if (work) {
-    produced = lz4w::pair::consume<CHECKED>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err);
+    /* (without the run executor: two instances of the consumer cost this kernel its eighth wave per SIMD -- 102 scalar registers) */
+    produced = lz4w::pair::consume<CHECKED, false>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err);
   }
   if (wave::lane_id() == 0) {
     if (b.actual_bytes != nullptr) {
@@ -199,7 +210,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) lz4_decompress_team_kernel(cons
               lz4w::pair::produce(i, n, scratch);
               return 0u;
             }
-            return lz4w::pair::consume<true>(i, n, o, cap, scratch, e);
+            return lz4w::pair::consume<true, NVCOMP_LZW_RUNS != 0>(i, n, o, cap, scratch, e); /* chunks that shrank 16 x: runs */
           });
     }
     a = wave::kernel_args(launch);

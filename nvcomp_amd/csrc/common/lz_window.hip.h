@@ -90,7 +90,7 @@ constexpr uint32_t kMatchShort = 32; /* lane-parallel matches:      up to 8 dwor
 
 /* ---- phase clock (profiling builds only: -DNVCOMP_LZW_PROF) ------------------ */
 #ifdef NVCOMP_LZW_PROF
-constexpr uint32_t kProfSlots = 16;
+constexpr uint32_t kProfSlots = 20;
 __device__ unsigned long long g_prof[kProfSlots];
 __device__ __forceinline__ unsigned long long* prof_slots()
 {
@@ -1056,6 +1056,364 @@ __device__ __forceinline__ void coop_match(OutWindow& ow, uint32_t hw, uint32_t 
       lds_match_copy(out_at(ow, hw + n_hbm), foff, flen - n_hbm);
     }
   }
+}
+
+/* ---- runs: sequences that are "a few literals, then a match of period 1, 2, 4, 8 or 16" ---------------------------------
+ *
+ * Sorted key columns, typed columns, runs -- the reference's only published LZ4 number is of this shape
+ * (doc/Benchmarks.md:88-95) -- decode to a few hundred such sequences a chunk, 200-400 bytes each. The batch executor
+ * below takes five of them per batch (2 KiB of window) and copies every match with the whole wave, one after the other:
+ * ~65 vector and ~80 scalar instructions a sequence, 0.28 of the memory roofline with neither the memory system nor the
+ * vector units busy. Here up to 64 of them are executed at once and never pass through the window:
+ *
+ *   pattern   With a period that divides 16, every ALIGNED 16-byte block of a run holds the same 16 bytes Q (byte i = the
+ *             byte of every output address congruent to i). Q of sequence k is Q of sequence k - 1 with the literals of k
+ *             written over it at their address residues: a "last writer" scan across the lanes
+ *             (wave::scan_last_writer), seeded with the 16 bytes in front of the batch from the window.
+ *   joints    The blocks that are not all run -- the end of run k - 1, the literals of k, the head of run k: at most two
+ *             blocks a sequence with up to 16 literals -- are assembled in a 32-byte slot per lane (the window's LDS, which
+ *             nothing else needs meanwhile) and stored by their lane.
+ *   bodies    The whole blocks of a run are stores of Q, 1 KiB per instruction, a short scalar loop per run.
+ *
+ * Sequences without literals behind a match of the same period continue its run (liblz4's fast compressor cuts a run in
+ * two, Snappy's copies end at 64 bytes): they are merged into it. The window restarts behind the batch with the last 16
+ * bytes as its history. Returns the number of sequences executed; 0 = not this kind of batch, nothing touched: the
+ * caller goes on with execute_window_batch (which also reports what is wrong with a corrupt stream).
+ */
+#ifndef NVCOMP_LZW_RUNS
+#define NVCOMP_LZW_RUNS 1 /* A/B: 0 = every batch through execute_window_batch (rounds 1-5) */
+#endif
+#ifndef NVCOMP_LZW_RUN_MIN
+#define NVCOMP_LZW_RUN_MIN 4 /* fewer leading sequences of the shape (and fewer than 256 bytes): not worth the fixed cost of this path */
+#endif
+constexpr uint32_t kRunMin = NVCOMP_LZW_RUN_MIN;
+#ifndef NVCOMP_LZW_RUN_MIN_BYTES
+#define NVCOMP_LZW_RUN_MIN_BYTES 2048 /* a batch of runs smaller than this (a batch of the window): not worth it -- the path's
+                                        * fixed cost is ~450 instructions, the window's batch of 2 KiB costs ~1 000 all in (measured:
+                                        * Snappy's int32 column, whose 64 elements a refill are ~9 runs or 2-4 KB, lost 10 % here) */
+#endif
+constexpr uint32_t kRunMinBytes = NVCOMP_LZW_RUN_MIN_BYTES;
+
+/* When the decoders try execute_run_batch (the loops that hold it: lz4w::decode_chunk<., ., true>). A batch of the window
+ * that was cut by its size with fewer than 24 sequences -- long sequences -- turns the attempts on for the batches behind
+ * it. An attempt that finds the first sequences not of the shape at all (liblz4's fast compressor on the sorted-key column:
+ * every other sequence is a 6-byte match far back) spaces the next ones out, 2, 4, 8, 16 batches of the window between them;
+ * an attempt declined for a short run among the first sequences or a small batch does not (the int32 column: one run in
+ * twenty is shorter than 16 bytes; 1 500 GB/s with those counted, 1 830 without: gpurun r6v, r6w). */
+#ifndef NVCOMP_LZW_RUN_GATE
+#define NVCOMP_LZW_RUN_GATE 1 /* A/B: 0 = every batch is tried */
+#endif
+/* One uniform word (as a struct of three the compiler kept it in scratch memory): bit 0 = the last batch of the window took
+ * few, long sequences (set at the start: the loops that hold the path get the chunks that shrank 8 x, their first batch is
+ * tried); bits 4-6 = attempts in a row that found other shapes; bits 8-15 = batches of the window to let pass before the
+ * next attempt. */
+typedef uint32_t RunGate;
+constexpr RunGate kRunGateInit = 1u;
+__device__ __forceinline__ bool run_gate_open(RunGate g)
+{
+  return NVCOMP_LZW_RUNS && (!NVCOMP_LZW_RUN_GATE || (g & 0xff01u) == 1u);
+}
+__device__ __forceinline__ RunGate run_gate_tried(RunGate g, uint32_t take, bool misfit)
+{
+  if (take) {
+    return g & ~0x70u;
+  }
+  if (!misfit) {
+    return g;
+  }
+  const uint32_t m = (g >> 4) & 7u, m1 = m < 4 ? m + 1 : 4u;
+  return (g & 1u) | (m1 << 4) | ((1u << m1) << 8);
+}
+__device__ __forceinline__ RunGate run_gate_window_took(RunGate g, uint32_t take, uint32_t count)
+{
+  const uint32_t skip = g >> 8;
+  return (g & 0x70u) | (take < 24u && take < count ? 1u : 0u) | ((skip ? skip - 1u : 0u) << 8);
+}
+
+constexpr uint32_t kRunMax = 60; /* sequences a batch: 32 bytes of joint a lane + the table of the sweep = the window's LDS */
+constexpr bool kRunFits = kRunMax * 32 + 64 * 4 <= kOutLds; /* its slots and table live in the window's LDS (the callers assert it) */
+
+/* mask of the low n bytes of a dword, n clamped to 0 .. 4 */
+__device__ __forceinline__ uint32_t low_bytes_mask(int32_t n)
+{
+  const uint32_t c = n < 0 ? 0u : n > 4 ? 4u : (uint32_t)n;
+  return c == 4 ? ~0u : (1u << (8u * c)) - 1u;
+}
+
+/* x as a ring of 16 bytes, rotated so that byte j moves to byte (j + sft) & 15 */
+__device__ __forceinline__ void rotate16(uint32_t (&x)[4], uint32_t sft)
+{
+  const uint32_t bs = sft & 3u, ws = sft >> 2;
+  uint32_t t[4];
+#pragma unroll
+  for (uint32_t d = 0; d < 4; ++d) {
+    t[d] = bs ? wave::align_bytes(x[d], x[(d + 3) & 3], 4u - bs) : x[d];
+  }
+#pragma unroll
+  for (uint32_t d = 0; d < 4; ++d) {
+    x[d] = ws == 0 ? t[d] : ws == 1 ? t[(d + 3) & 3] : ws == 2 ? t[(d + 2) & 3] : t[(d + 1) & 3];
+  }
+}
+
+/* the last `off` bytes of the 16-byte value x (off = 1, 2, 4, 8, 16: uniform), repeated over all 16 */
+__device__ __forceinline__ void repeat_tail16(uint32_t (&x)[4], uint32_t off)
+{
+  if (off == 8) {
+    x[0] = x[2], x[1] = x[3];
+  } else if (off <= 4) {
+    uint32_t v = x[3];
+    if (off == 2) {
+      v = (v & 0xffff0000u) | (v >> 16);
+    } else if (off == 1) {
+      v >>= 24;
+      v |= v << 8;
+      v |= v << 16;
+    }
+    x[0] = v, x[1] = v, x[2] = v, x[3] = v;
+  }
+}
+
+template <bool CHECKED>
+__device__ __forceinline__ uint32_t execute_run_batch(
+    const InRing& ir, OutWindow& ow, uint32_t out_cap, uint32_t& op, uint32_t n, const lz::Seq& s, bool& misfit)
+{
+  misfit = true; /* declined because the first sequences are not of this shape at all (RunGate spaces the attempts out) */
+  /* uniform tests on the first sequence and the window: what a batch of any other kind of data pays for this path */
+  uint32_t off = wave::read_lane(s.match_off, 0);
+  if (off == 0 && n > 1) {
+    off = wave::read_lane(s.match_off, 1); /* Snappy: the literals are an element of their own in front of the copy */
+  }
+  if (off - 1u >= 16u || (off & (off - 1u)) != 0) {
+    LZ_STAT("run_decl_period", 1);
+    return 0;
+  }
+  /* the joints are whole aligned blocks: everything in front of the window's tail block must be in HBM (not so at the
+   * start of a chunk whose buffer is not 16-byte aligned: the first batch goes through the window) */
+  if (((ow.flushed + ow.align) & 15u) != 0 || op - ow.flushed >= 16u) {
+    LZ_STAT("run_decl_window", 1);
+    return 0;
+  }
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
+  /* the leading sequences of this shape: the period of the first one, at most 16 literals (resident in the ring); a
+   * sequence may be literals only (Snappy's literal elements; the run is then what follows it) or nothing at all (the
+   * followers of a merged copy train) */
+  const bool weak = lane < n && (s.match_len == 0 || (s.match_off == off && s.match_len < kStreamMatch))
+                    && (s.lit_len == 0 || (s.lit_len <= 16u && s.lit_src - ir.lo + s.lit_len <= ir.hi - ir.lo));
+  const uint64_t not_weak = ~wave::ballot(weak) | (1ull << kRunMax);
+  const uint32_t r0 = wave::ctz64(not_weak);
+  if (r0 < kRunMin) {
+    LZ_STAT("run_decl_lead", 1);
+    return 0;
+  }
+  misfit = false; /* what declines from here on is this batch's bad luck: a short run among the first, a small batch */
+  const bool in0 = lane < r0;
+  const uint32_t len = in0 ? s.lit_len + s.match_len : 0u;
+  const uint32_t incl = wave::scan_add_inclusive(len);
+  /* a sequence without literals goes on with the run in front of it: heads are the others; a head's run ends where the
+   * next head's literals start */
+  const bool head = in0 && (lane == 0 || s.lit_len != 0);
+  uint64_t heads = wave::ballot(head);
+  const uint64_t hx = heads | (1ull << r0);
+  const uint64_t above = lane < 63 ? hx >> (lane + 1) : 0ull;
+  const uint32_t next_head = above ? lane + 1 + wave::ctz64(above) : r0;
+  const uint32_t L = op + incl - len;      /* where the sequence's literals go */
+  const uint32_t M = L + s.lit_len;        /* where its match starts */
+  const uint32_t E = op + wave::shuffle(incl, next_head - 1u); /* heads: where the (merged) run ends */
+  /* every run holds a 16-byte boundary, so that no block belongs to two joints: the batch ends in front of a shorter one */
+  const uint64_t short_run = wave::ballot(head && E - M < 16u);
+  const uint32_t R = short_run ? wave::ctz64(short_run) : r0;
+  if (R < kRunMin) {
+    LZ_STAT("run_decl_short", 1);
+    return 0;
+  }
+  heads &= (1ull << R) - 1ull;
+  const uint32_t total = wave::read_lane(incl, R - 1);
+  {
+    /* the batch's end is the only output test; the first match must have its period in front of it (every other one
+     * has a run of 16 bytes or more there), in the window if the literals do not cover it */
+    const uint32_t m0 = op + wave::read_lane(s.lit_len, 0);
+    if (op + total > out_cap || m0 < off || (m0 - op < off && m0 - off < ow.valid_lo)) {
+      LZ_STAT("run_decl_first", 1);
+    return 0;
+    }
+    /* short runs and small batches are as well off in the window */
+    if (total < 64u * wave::popc64(heads) || total < kRunMinBytes) {
+      LZ_STAT("run_decl_small", 1);
+    return 0;
+    }
+  }
+  LZW_T(4);
+  LZ_STAT("run_batches", 1);
+  LZ_STAT("run_seqs", R);
+  LZ_STAT("run_heads", wave::popc64(heads));
+  LZ_STAT("run_bytes", total);
+
+  /* the 16 bytes in front of the batch by address residue: the window's tail block up to op, the block before behind it */
+  uint32_t qi[4];
+  {
+    const uint32_t cop = op + ow.align; /* "coordinates": position + align, congruent to the address modulo 16; window index = coordinate - wbase */
+    const uint32_t fl = cop & ~15u, t = cop & 15u;
+    const wave::u32x4 w1 = *(const wave::u32x4*)(ow.win + (fl - ow.wbase));
+    wave::u32x4 w0 = {0, 0, 0, 0};
+    if (fl - ow.wbase >= 16u) {
+      w0 = *(const wave::u32x4*)(ow.win + (fl - 16u - ow.wbase));
+    }
+    const uint32_t a1[4] = {w1.x, w1.y, w1.z, w1.w}, a0[4] = {w0.x, w0.y, w0.z, w0.w};
+#pragma unroll
+    for (uint32_t d = 0; d < 4; ++d) {
+      const uint32_t m = low_bytes_mask((int32_t)t - (int32_t)(4 * d));
+      qi[d] = (a1[d] & m) | (a0[d] & ~m);
+    }
+  }
+  /* a lane's contribution: its last 16 literal bytes (those it has: the others masked out), their last `off` repeated,
+   * rotated to the address residues of the bytes in front of its match */
+  uint32_t q[4], qm[4];
+  {
+    const uint32_t e = s.lit_src + s.lit_len;
+#pragma unroll
+    for (uint32_t d = 0; d < 4; ++d) {
+      q[d] = ld32(ir.ring + ((e - 16u + 4u * d) & (kInRing - 1)));
+      qm[d] = ~low_bytes_mask(16 - (int32_t)(4 * d) - (int32_t)s.lit_len);
+    }
+    repeat_tail16(q, off);
+    repeat_tail16(qm, off);
+    const uint32_t sft = (M + ow.align) & 15u;
+    rotate16(q, sft);
+    rotate16(qm, sft);
+    if (lane == 0) {
+      /* the first sequence inherits from the output in front of the batch: its last `off` bytes, repeated like a run */
+      uint32_t h[4] = {qi[0], qi[1], qi[2], qi[3]};
+      const uint32_t t = (op + ow.align) & 15u;
+      rotate16(h, (16u - t) & 15u); /* byte j = position op - 16 + j */
+      repeat_tail16(h, off);
+      rotate16(h, t);
+#pragma unroll
+      for (uint32_t d = 0; d < 4; ++d) {
+        q[d] = (q[d] & qm[d]) | (h[d] & ~qm[d]);
+        qm[d] = ~0u;
+      }
+    }
+#pragma unroll
+    for (uint32_t d = 0; d < 4; ++d) {
+      wave::scan_last_writer(q[d], qm[d]);
+    }
+  }
+  LZW_T(16); /* runs: the patterns */
+  /* ---- joints ---- */
+  uint8_t* const gbase = ow.out - ow.align; /* coordinate 0 */
+  const bool jlane = wave::lane_in(heads);
+  {
+    uint32_t qp[4];
+#pragma unroll
+    for (uint32_t d = 0; d < 4; ++d) {
+      const uint32_t below = wave::prev_lane(q[d]);
+      qp[d] = lane == 0 ? qi[d] : below;
+    }
+    const uint32_t a = (L + ow.align) & 15u; /* where the literals start in the joint's first block */
+    const uint32_t mm = a + s.lit_len;       /* where the run starts: 0 .. 31 */
+    const uint32_t nj = jlane ? (mm + 15u) >> 4 : 0u;
+    wave::u32x4 b0, b1;
+    {
+      uint32_t x[4];
+#pragma unroll
+      for (uint32_t d = 0; d < 4; ++d) {
+        const uint32_t m = low_bytes_mask((int32_t)a - (int32_t)(4 * d));
+        x[d] = (qp[d] & m) | (q[d] & ~m);
+      }
+      b0.x = x[0], b0.y = x[1], b0.z = x[2], b0.w = x[3];
+      b1.x = q[0], b1.y = q[1], b1.z = q[2], b1.w = q[3];
+    }
+    wave::sync(); /* the window's blocks have been read */
+    uint8_t* slot = ow.win + 32u * lane;
+    *(wave::u32x4*)slot = b0;
+    *(wave::u32x4*)(slot + 16) = b1;
+    wave::sync();
+    if (jlane && s.lit_len >= 4) {
+      const uint32_t last = s.lit_len - 4;
+      uint32_t data[4];
+#pragma unroll
+      for (uint32_t i = 0; i < 4; ++i) {
+        const uint32_t o = 4 * i < last ? 4 * i : last;
+        data[i] = ld32(ir.ring + ((s.lit_src + o) & (kInRing - 1)));
+      }
+#pragma unroll
+      for (uint32_t i = 0; i < 4; ++i) {
+        const uint32_t o = 4 * i < last ? 4 * i : last;
+        lz::st_u32(slot + a + o, data[i]);
+      }
+    } else if (jlane && s.lit_len != 0) {
+      slot[a] = ir.ring[s.lit_src & (kInRing - 1)];
+      if (s.lit_len > 1) {
+        slot[a + 1] = ir.ring[(s.lit_src + 1) & (kInRing - 1)];
+      }
+      if (s.lit_len > 2) {
+        slot[a + 2] = ir.ring[(s.lit_src + 2) & (kInRing - 1)];
+      }
+    }
+    /* the table of the sweep: one word a run, in address order -- its first block's number in the batch, how many of
+     * its blocks are joint blocks, its lane; unused entries compare above every block */
+    uint32_t* tab = (uint32_t*)(ow.win + 32u * kRunMax);
+    tab[lane] = ~0u;
+    wave::sync();
+    if (jlane) {
+      const uint32_t blk = (((L + ow.align) & ~15u) - ((op + ow.align) & ~15u)) >> 4;
+      tab[wave::prefix_popc(heads)] = (blk << 8) | (nj << 6) | lane;
+    }
+    wave::sync();
+  }
+  LZW_T(17); /* runs: the joints */
+  /* ---- the sweep: every whole block of the batch, in address order, 1 KiB a store instruction. A lane finds the run its
+   * block belongs to (binary search of the table) and takes the block from that run's joint slot or its pattern from
+   * that run's lane. (Stores run by run -- a run's ~25 blocks an instruction, the joints scattered -- left the memory
+   * pipe the bound: 2 550 GB/s on the sorted-key column, two thirds of the time in that loop: gpurun r6q, r6r.) ---- */
+  {
+    const uint32_t* tab = (const uint32_t*)(ow.win + 32u * kRunMax);
+    const uint32_t c0 = (op + ow.align) & ~15u;
+    const uint32_t nblk = (((op + total + ow.align) & ~15u) - c0) >> 4;
+    for (uint32_t base = 0; base < nblk; base += 64) {
+      const uint32_t bi = base + lane;
+      uint32_t lo = 0;
+#pragma unroll
+      for (uint32_t step = 32; step != 0; step >>= 1) {
+        const uint32_t c = lo + step;
+        lo = (tab[c] >> 8) <= bi ? c : lo;
+      }
+      const uint32_t key = tab[lo];
+      const uint32_t k = key & 63u, jb = bi - (key >> 8);
+      const bool joint = jb < ((key >> 6) & 3u);
+      wave::u32x4 x;
+      x.x = wave::shuffle(q[0], k), x.y = wave::shuffle(q[1], k), x.z = wave::shuffle(q[2], k), x.w = wave::shuffle(q[3], k);
+      if (joint) {
+        x = *(const wave::u32x4*)(ow.win + 32u * k + 16u * jb);
+      }
+      if (bi < nblk) {
+        wave::gstore_u32x4_aligned(gbase + c0 + 16u * bi, x);
+      }
+    }
+  }
+  LZW_T(18); /* runs: the bodies */
+  /* ---- the window restarts behind the batch: the last run's pattern is its history, its last partial block the tail
+   * that waits for the next flush ---- */
+  {
+    wave::u32x4 ql;
+    ql.x = wave::read_lane(q[0], R - 1), ql.y = wave::read_lane(q[1], R - 1);
+    ql.z = wave::read_lane(q[2], R - 1), ql.w = wave::read_lane(q[3], R - 1);
+    wave::sync();
+    op += total;
+    const uint32_t nbase = (op - 16u) & ~15u;
+    const uint32_t fl = (op + ow.align) & ~15u;
+    const uint32_t i0 = fl - 16u - nbase; /* 0 or 16 */
+    if (lane == 0) {
+      *(wave::u32x4*)(ow.win + i0) = ql;
+      *(wave::u32x4*)(ow.win + i0 + 16) = ql;
+    }
+    wave::sync(); /* and later far reads of this wave see the stores above */
+    ow.wbase = nbase;
+    ow.valid_lo = op - 16u;
+    ow.flushed = fl - ow.align;
+  }
+  LZW_T(19); /* runs: the window restart */
+  return R;
 }
 
 /*

@@ -315,6 +315,30 @@ __device__ __forceinline__ uint32_t scan_max_inclusive(uint32_t v)
   return v;
 }
 
+/* Inclusive "last writer" scan across the wave, bit by bit: lane k ends up with, for every bit position, the value bit
+ * of the highest lane j <= k whose mask has that bit set, and with the OR of the masks of lanes 0 .. k. Value bits are
+ * kept zero where the mask is zero. Same DPP ladder as the sums (the operator is associative, not commutative: a lane
+ * combines what it receives from below with its own). The run executor of the LZ decoders carries the 16-byte pattern
+ * of a run from sequence to sequence with it (common/lz_window.hip.h: execute_run_batch). */
+__device__ __forceinline__ void scan_last_writer(uint32_t& val, uint32_t& mask)
+{
+  val &= mask;
+#define NVCOMP_WAVE_LW_STEP(ctrl, rows)                                                                      \
+  {                                                                                                          \
+    const uint32_t pm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mask, ctrl, rows, 0xf, false);         \
+    const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)val, ctrl, rows, 0xf, false);          \
+    val = (val & mask) | (pv & ~mask);                                                                       \
+    mask |= pm;                                                                                              \
+  }
+  NVCOMP_WAVE_LW_STEP(0x111, 0xf) /* row_shr:1 */
+  NVCOMP_WAVE_LW_STEP(0x112, 0xf) /* row_shr:2 */
+  NVCOMP_WAVE_LW_STEP(0x114, 0xf) /* row_shr:4 */
+  NVCOMP_WAVE_LW_STEP(0x118, 0xf) /* row_shr:8 */
+  NVCOMP_WAVE_LW_STEP(0x142, 0xa) /* row_bcast:15 */
+  NVCOMP_WAVE_LW_STEP(0x143, 0xc) /* row_bcast:31 */
+#undef NVCOMP_WAVE_LW_STEP
+}
+
 __device__ __forceinline__ uint32_t reduce_add(uint32_t v)
 {
   return read_lane(scan_add_inclusive(v), 63);

@@ -388,7 +388,11 @@ struct TeamFrontEnd
 /* Decode one chunk with the calling wave; `lds` is this wave's kLdsPerWave bytes. */
 /* ABLATE (profiling builds only, results are wrong by construction): 1 = stop after the
  * token chase, 2 = after the parse, 0 = the real decoder. */
-template <bool CHECKED, int ABLATE = 0>
+/* RUNS: the loop tries lzw::execute_run_batch (sorted keys, typed columns). Its mere presence in the loop costs every
+ * other kind of data 1.5-2 % (block placement and register allocation of the batch executor around it: gpurun r6u, r6v --
+ * the same with the attempts gated off at run time), so the kernels instantiate the loop twice and pick per chunk by what
+ * the stream shrank to (decode_one: runs only pay from 8 x on). */
+template <bool CHECKED, int ABLATE = 0, bool RUNS = false>
 __device__ __forceinline__ uint32_t decode_chunk(
     const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_cap, uint8_t* lds, uint32_t& err,
     uint8_t* index_scratch = nullptr)
@@ -427,6 +431,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
 #define NVCOMP_LZ4W_KEEP_PARSED 1 /* measured: headline 498 vs 500 GB/s (noise), mortgage-like column 545 vs 442 */
 #endif
   constexpr uint32_t kRefillBelow = 24;
+  lzw::RunGate gate = lzw::kRunGateInit;
   lz::Seq s;
   s.lit_src = 0;
   s.lit_len = 0;
@@ -480,10 +485,23 @@ __device__ __forceinline__ uint32_t decode_chunk(
         return 0;
       }
     }
-    bool big;
-    uint32_t take = lzw::execute_window_batch<CHECKED, false>(ir, ow, out_cap, op, count, s, err, big, [&ix]() { lzx::settle(ix); });
-    if (CHECKED && err) {
-      return 0;
+    bool big = false;
+    /* runs (sorted keys, typed columns) are executed 60 at a time, straight to the output: lzw::execute_run_batch */
+    static_assert(!NVCOMP_LZW_RUNS || lzw::kRunFits, "the run executor needs 2 176 bytes of window LDS");
+    uint32_t take = 0;
+    if (RUNS && lzw::run_gate_open(gate)) {
+      bool misfit;
+      take = lzw::execute_run_batch<CHECKED>(ir, ow, out_cap, op, count, s, misfit);
+      gate = wave::uniform(lzw::run_gate_tried(gate, take, misfit));
+    }
+    if (take == 0) {
+      take = lzw::execute_window_batch<CHECKED, false>(ir, ow, out_cap, op, count, s, err, big, [&ix]() { lzx::settle(ix); });
+      if (CHECKED && err) {
+        return 0;
+      }
+      if (RUNS) {
+        gate = wave::uniform(lzw::run_gate_window_took(gate, take, count));
+      }
     }
     if (big) {
       /* the first sequence in hand has a long literal run or a long match, or is larger than a batch: straight to HBM */
@@ -570,7 +588,7 @@ __device__ __forceinline__ void produce(const uint8_t* __restrict__ in, uint32_t
   }
 }
 
-template <bool CHECKED>
+template <bool CHECKED, bool RUNS = false>
 __device__ __forceinline__ uint32_t consume(
     const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_cap, uint8_t* lds, uint32_t& err)
 {
@@ -583,6 +601,7 @@ __device__ __forceinline__ uint32_t consume(
   uint32_t op = 0;
   uint32_t count = 0;
   uint32_t k = 0;
+  lzw::RunGate gate = lzw::kRunGateInit;
   lz::Seq s;
   s.lit_src = 0, s.lit_len = 0, s.match_off = 0, s.match_len = 0;
   for (;;) {
@@ -620,8 +639,19 @@ __device__ __forceinline__ uint32_t consume(
       const uint32_t newest = wave::read_lane(s.lit_src, count - 1);
       lzw::in_ensure(ir, oldest, (newest & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
     }
-    bool big;
-    uint32_t take = lzw::execute_window_batch<CHECKED>(ir, ow, out_cap, op, count, s, err, big);
+    bool big = false;
+    uint32_t take = 0;
+    if (RUNS && lzw::run_gate_open(gate)) {
+      bool misfit;
+      take = lzw::execute_run_batch<CHECKED>(ir, ow, out_cap, op, count, s, misfit);
+      gate = wave::uniform(lzw::run_gate_tried(gate, take, misfit));
+    }
+    if (take == 0) {
+      take = lzw::execute_window_batch<CHECKED>(ir, ow, out_cap, op, count, s, err, big);
+      if (RUNS) {
+        gate = wave::uniform(lzw::run_gate_window_took(gate, take, count));
+      }
+    }
     if (CHECKED && err) {
       if (lane == 0) {
         wave::lds_store_release(sh.abort, 1u);

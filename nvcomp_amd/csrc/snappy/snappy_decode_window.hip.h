@@ -360,7 +360,12 @@ struct TeamFrontEnd
   }
 };
 
-template <bool CHECKED>
+/* RUNS: lz4_decode_window.hip.h: decode_chunk. No caller turns it on for Snappy: a refill's 64 elements are ~9 runs (a
+ * literal element and a train of 64-byte copies each), 2-4 KB a batch, where the run executor's fixed cost is not earned
+ * back (int32 column 1 308 -> 1 210 GB/s with every batch tried, gpurun r6t), and libsnappy spells the sorted-key column
+ * with a 6-byte copy from far back in every run, which ends a batch (1 454 -> 1 021). The executor itself takes Snappy's
+ * shapes (literal-only elements, the empty followers of a merged train). */
+template <bool CHECKED, bool RUNS = false>
 __device__ __forceinline__ uint32_t decode_chunk(
     const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_cap, uint8_t* lds, uint32_t& err)
 {
@@ -393,6 +398,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
   /* parsed elements stay in registers until they are executed; chase and parse run only when few are left
    * (lz4_decode_window.hip.h: decode_chunk) */
   constexpr uint32_t kRefillBelow = 24;
+  lzw::RunGate gate = lzw::kRunGateInit;
   lz::Seq s;
   s.lit_src = 0;
   s.lit_len = 0;
@@ -430,10 +436,23 @@ __device__ __forceinline__ uint32_t decode_chunk(
     LZW_T(15); /* copy trains merged */
     LZ_STAT("sn_rounds", 1);
     LZ_STAT("sn_rounds_with_train", train ? 1 : 0);
-    bool big;
-    uint32_t take = lzw::execute_window_batch<CHECKED>(ir, ow, limit, op, count, s, err, big);
-    if (CHECKED && err) {
-      return 0;
+    bool big = false;
+    /* runs (typed columns: a literal element, then copies of period 1 .. 16) straight to the output: lzw::execute_run_batch */
+    static_assert(!NVCOMP_LZW_RUNS || lzw::kRunFits, "the run executor needs 2 176 bytes of window LDS");
+    uint32_t take = 0;
+    if (RUNS && lzw::run_gate_open(gate)) {
+      bool misfit;
+      take = lzw::execute_run_batch<CHECKED>(ir, ow, limit, op, count, s, misfit);
+      gate = wave::uniform(lzw::run_gate_tried(gate, take, misfit));
+    }
+    if (take == 0) {
+      take = lzw::execute_window_batch<CHECKED>(ir, ow, limit, op, count, s, err, big);
+      if (CHECKED && err) {
+        return 0;
+      }
+      if (RUNS) {
+        gate = wave::uniform(lzw::run_gate_window_took(gate, take, count));
+      }
     }
     if (big) {
       /* the first sequence in hand has a long literal run or a long match, or is larger than a batch: straight to HBM */
@@ -518,7 +537,7 @@ __device__ __forceinline__ void produce(const uint8_t* __restrict__ in, uint32_t
   }
 }
 
-template <bool CHECKED>
+template <bool CHECKED, bool RUNS = false>
 __device__ __forceinline__ uint32_t consume(
     const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_cap, uint8_t* lds, uint32_t& err)
 {
@@ -542,6 +561,7 @@ __device__ __forceinline__ uint32_t consume(
   uint32_t op = 0;
   uint32_t count = 0;
   uint32_t k = 0;
+  lzw::RunGate gate = lzw::kRunGateInit;
   lz::Seq s;
   s.lit_src = 0, s.lit_len = 0, s.match_off = 0, s.match_len = 0;
   for (;;) {
@@ -582,8 +602,19 @@ __device__ __forceinline__ uint32_t consume(
         lzw::in_ensure(ir, lo, (hi & ~(lzw::kInBlock - 1)) + 2 * lzw::kInBlock);
       }
     }
-    bool big;
-    uint32_t take = lzw::execute_window_batch<CHECKED>(ir, ow, limit, op, count, s, err, big);
+    bool big = false;
+    uint32_t take = 0;
+    if (RUNS && lzw::run_gate_open(gate)) {
+      bool misfit;
+      take = lzw::execute_run_batch<CHECKED>(ir, ow, limit, op, count, s, misfit);
+      gate = wave::uniform(lzw::run_gate_tried(gate, take, misfit));
+    }
+    if (take == 0) {
+      take = lzw::execute_window_batch<CHECKED>(ir, ow, limit, op, count, s, err, big);
+      if (RUNS) {
+        gate = wave::uniform(lzw::run_gate_window_took(gate, take, count));
+      }
+    }
     if (CHECKED && err) {
       if (lane == 0) {
         wave::lds_store_release(sh.abort, 1u);

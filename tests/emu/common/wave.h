@@ -18,7 +18,7 @@ struct u32x4
   uint32_t x, y, z, w;
 };
 
-enum OpId { kBallot = 1, kReadLane, kUniform, kShuffle, kScan, kMax, kSync };
+enum OpId { kBallot = 1, kReadLane, kUniform, kShuffle, kScan, kMax, kSync, kLastWriter };
 
 inline int lane_id() { return emu::cur()->lane; }
 inline int fresh_lane_id() { return emu::cur()->lane; }
@@ -219,6 +219,19 @@ inline uint32_t scan_max_inclusive(uint32_t v)
     m = umax(m, (uint32_t)emu::peer(i).a);
   }
   return m;
+}
+
+inline void scan_last_writer(uint32_t& val, uint32_t& mask)
+{
+  emu::wave_rendezvous(kLastWriter, val & mask, mask);
+  uint32_t v = 0, m = 0;
+  for (int i = 0; i <= lane_id(); ++i) {
+    const uint32_t pv = (uint32_t)emu::peer(i).a, pm = (uint32_t)emu::peer(i).b;
+    v = (pv & pm) | (v & ~pm);
+    m |= pm;
+  }
+  val = v;
+  mask = m;
 }
 
 inline uint32_t reduce_add(uint32_t v)

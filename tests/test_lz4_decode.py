@@ -189,6 +189,73 @@ def test_streamed_long_runs(backend, lz_path, oracle):
         check_roundtrip(backend, oracle, raws, blocks, base_misalign=mis)
 
 
+def _run_blocks(rng, n_seqs, offs, lit_choices, mlen_choices, first_lit=16):
+    """A chain of run sequences: (a few literals, a match of period `off`), the shapes lzw::execute_run_batch takes."""
+    seqs = [(rng.randint(0, 256, size=first_lit).astype(np.uint8).tobytes(), offs[0], 20)]
+    for j in range(n_seqs):
+        off = offs[j % len(offs)]
+        nlit = lit_choices[rng.randint(len(lit_choices))]
+        mlen = mlen_choices[rng.randint(len(mlen_choices))]
+        seqs.append((rng.randint(0, 256, size=nlit).astype(np.uint8).tobytes(), off, mlen))
+    return seqs
+
+
+def test_run_batches(backend, lz_path, oracle):
+    """Sequences of "a few literals, then a match of period 1, 2, 4, 8 or 16" -- sorted key columns, typed columns -- are
+    executed up to 64 at a time straight to the output buffer (common/lz_window.hip.h: execute_run_batch): every period,
+    0 .. 16 literals (17 and more end the batch), runs from 16 bytes on (shorter ones end it), sequences without literals
+    that continue the run in front of them (merged), a period that changes, batches at every alignment of the output
+    buffer, at the start and at the end of a chunk, and behind / in front of ordinary sequences."""
+    rng = np.random.RandomState(606)
+    blocks, raws = [], []
+    few = backend.name == "emu"
+    lits_all = list(range(0, 17))
+    for off in (1, 2, 4, 8, 16):
+        # the column shape: one period, short literals, long runs
+        for lit_choices, mlen_choices in (([2], [142, 254, 398, 542, 654]), ([1], [15, 16, 17, 59, 139, 275, 583]),
+                                          (lits_all, [16, 17, 30, 31, 32, 33, 47, 48, 100, 1000, 1549, 4000]),
+                                          ([0, 0, 1, 2, 3], [4, 5, 6, 7, 12, 15, 16, 200, 392, 616]),
+                                          ([0, 4, 8, 15, 16, 17, 20], [16, 64, 300])):
+            seqs = _run_blocks(rng, 40 if few else 150, [off], lit_choices, mlen_choices, first_lit=max(off, 3) + rng.randint(14))
+            tail = rng.randint(0, 256, size=5 + rng.randint(9)).astype(np.uint8).tobytes()
+            blocks.append(_lz4_block(seqs, tail))
+            raws.append(_lz4_expand(seqs, tail))
+    # the period changes inside a chain, ordinary sequences (other offsets, short matches) in between
+    for k in range(3 if few else 10):
+        seqs = [(rng.randint(0, 256, size=40).astype(np.uint8).tobytes(), 5, 9)]
+        for j in range(100 if few else 300):
+            kind = rng.randint(10)
+            if kind < 7:
+                off = (1, 2, 4, 8, 16)[(j // 13 + k) % 5]
+                seqs.append((rng.randint(0, 256, size=rng.randint(0, 5)).astype(np.uint8).tobytes(), off, 16 + rng.randint(500)))
+            elif kind < 9:
+                seqs.append((rng.randint(0, 256, size=rng.randint(0, 20)).astype(np.uint8).tobytes(), 1 + rng.randint(40), 4 + rng.randint(40)))
+            else:
+                seqs.append((b"", (1, 2, 4, 8, 16)[(j // 13 + k) % 5], 4 + rng.randint(12)))
+        tail = rng.randint(0, 256, size=5 + k).astype(np.uint8).tobytes()
+        blocks.append(_lz4_block(seqs, tail))
+        raws.append(_lz4_expand(seqs, tail))
+    # a chunk that starts with runs (the first match needs its period among the first literals), and one that is only runs
+    for off in (1, 8, 16):
+        seqs = [(rng.randint(0, 256, size=off).astype(np.uint8).tobytes(), off, 300)]
+        seqs += [(rng.randint(0, 256, size=2).astype(np.uint8).tobytes(), off, 100 + 7 * j) for j in range(70)]
+        blocks.append(_lz4_block(seqs, b"12345"))
+        raws.append(_lz4_expand(seqs, b"12345"))
+    # the real thing: the sorted key column and the int32 column through liblz4 (default and HC)
+    for name in ("mortgage_col0_like", "int32"):
+        gen = getattr(datasets, name) if hasattr(datasets, name) else datasets.CLASSES[name]
+        data = gen(65536 + 4096, 3)
+        for c in datasets.split_chunks(data):
+            for hc in ((0, 12) if oracle.have_ref() else (0,)):
+                blocks.append(cpu_compress(oracle, [c], hc=hc)[0])
+                raws.append(c)
+    for cc, c in zip(blocks, raws):
+        rc, ref = oracle.lz4_decompress(cc, c.size)
+        assert rc == 0 and np.array_equal(ref, c), "the hand-built block is not what the oracle reads"
+    for mis in ((0, 7) if few else range(16)):
+        check_roundtrip(backend, oracle, raws, blocks, base_misalign=mis)
+
+
 def test_two_byte_length_fields(backend, lz_path, oracle):
     """Lengths that take a second, third, ... extension byte -- matches of 274 bytes and more, literal runs of 270 and more
     -- are what a sorted key column compressed by liblz4 consists of (two literals, 170 .. 680 bytes at offset 8, 165 times

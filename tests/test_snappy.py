@@ -212,6 +212,74 @@ def test_copy_trains(backend, lz_path, oracle):
     check_decode(backend, oracle, chunks, comp, checked=False)
 
 
+def test_column_runs(backend, lz_path, oracle):
+    """Typed columns in Snappy's spelling: a literal element of a few bytes, then a train of copies of period 1, 2, 4, 8
+    or 16: every period, literal elements of 1 .. 17 bytes, trains from 4 bytes to 2 000, mixed element encodings, a
+    period that changes, ordinary elements in between, every output alignment; and the int32 / sorted-key columns through
+    libsnappy. (The shape of LZ4's run batches, tests/test_lz4_decode.py::test_run_batches; Snappy's decoders leave the
+    run executor off -- snappy_decode_window.hip.h -- and merge the trains instead.)"""
+    rng = np.random.RandomState(909)
+    few = backend.name == "emu"
+    streams, raws = [], []
+
+    def build(program):
+        body, raw = b"", bytearray()
+        for op in program:
+            if op[0] == "lit":
+                blk = rng.randint(0, 256, size=op[1]).astype(np.uint8).tobytes()
+                body += _lit(blk)
+                raw += blk
+            else:
+                _, off, total = op
+                assert 0 < off <= len(raw)
+                while total:
+                    ln = min(total, int(rng.choice([64, 64, 64, 60, 33, 11, 4])))
+                    if 4 <= ln <= 11 and rng.rand() < 0.5:
+                        body += bytes([1 | ((ln - 4) << 2) | ((off >> 8) << 5), off & 255])
+                    else:
+                        body += bytes([2 | ((ln - 1) << 2)]) + off.to_bytes(2, "little")
+                    for _ in range(ln):
+                        raw.append(raw[-off])
+                    total -= ln
+        streams.append(_varint(len(raw)) + body)
+        raws.append(bytes(raw))
+
+    for off in (1, 2, 4, 8, 16):
+        for lit_choices, run_choices in (([3], [57, 64, 200, 505, 1000]), (list(range(1, 18)), [16, 17, 31, 32, 33, 48, 100, 400, 2000]),
+                                         ([1, 2], [4, 9, 15, 16, 64, 300]), ([1, 4, 16, 17, 30], [64, 128])):
+            prog = [("lit", max(off, 3) + int(rng.randint(14)))]
+            for _ in range(25 if few else 120):
+                prog.append(("copy", off, int(rng.choice(run_choices))))
+                prog.append(("lit", int(rng.choice(lit_choices))))
+            build(prog)
+    for k in range(2 if few else 8):
+        prog = [("lit", 40)]
+        for j in range(60 if few else 250):
+            kind = rng.randint(10)
+            off = (1, 2, 4, 8, 16)[(j // 11 + k) % 5]
+            if kind < 7:
+                prog += [("lit", int(rng.randint(1, 5))), ("copy", off, 16 + int(rng.randint(500)))]
+            elif kind < 9:
+                prog += [("lit", int(rng.randint(1, 20))), ("copy", 1 + int(rng.randint(30)), 4 + int(rng.randint(40)))]
+            else:
+                prog += [("copy", off, 4 + int(rng.randint(12)))]
+        build(prog)
+    chunks = [np.frombuffer(r, dtype=np.uint8) for r in raws]
+    comp = [np.frombuffer(s, dtype=np.uint8) for s in streams]
+    for name in ("mortgage_col0_like", "int32"):
+        gen = getattr(datasets, name) if hasattr(datasets, name) else datasets.CLASSES[name]
+        cs = datasets.split_chunks(gen(65536 + 4096, 3))
+        chunks += cs
+        comp += cpu_compress(oracle, cs)
+    if oracle.have_ref():
+        for s, r in zip(comp, chunks):
+            rc, out = oracle.ref_snappy_decompress(s, max(r.size, 1))
+            assert rc == 0 and np.array_equal(out, r), "hand-built stream is not legal snappy"
+    for mis in ((0, 5) if few else range(16)):
+        check_decode(backend, oracle, chunks, comp, base_misalign=mis)
+    check_decode(backend, oracle, chunks, comp, checked=False)
+
+
 def test_corrupt_streams(backend, lz_path, oracle):
     rng = np.random.RandomState(23)
     chunks = datasets.split_chunks(datasets.table_rows(24000, 4), 4000)
