@@ -42,6 +42,9 @@ constexpr unsigned kWideWaves = NVCOMP_LZMW_WAVES_PER_BLOCK;
 #define NVCOMP_LZMW_WAVES_PER_SIMD 4 /* what the wave's LDS allows (15-16 waves per CU): a budget of 128 registers */
 #endif
 using lzl::kMaxOutCap;
+#ifndef NVCOMP_LZ4_PAIR_RUNS
+#define NVCOMP_LZ4_PAIR_RUNS 0 /* the two-wave kernel's consumer with the run executor (A/B) */
+#endif
 #ifndef NVCOMP_LZ4_RUNS_RATIO
 #define NVCOMP_LZ4_RUNS_RATIO 8
 #endif
@@ -163,8 +166,8 @@ __global__ void __launch_bounds__(128, 4) lz4_decompress_pair_kernel(const lzl::
   uint32_t err = too_long ? lz::kErrInput : lz::kErrNone;
   uint32_t produced = 0;
   if (work) {
-    /* (without the run executor: two instances of the consumer cost this kernel its eighth wave per SIMD -- 102 scalar registers) */
-    produced = lz4w::pair::consume<CHECKED, false>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err);
+    /* (one instance of the consumer: two cost this kernel its eighth wave per SIMD -- 102 scalar registers) */
+    produced = lz4w::pair::consume<CHECKED, NVCOMP_LZ4_PAIR_RUNS != 0>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err);
   }
   if (wave::lane_id() == 0) {
     if (b.actual_bytes != nullptr) {

@@ -1083,6 +1083,9 @@ __device__ __forceinline__ void coop_match(OutWindow& ow, uint32_t hw, uint32_t 
 #ifndef NVCOMP_LZW_RUNS
 #define NVCOMP_LZW_RUNS 1 /* A/B: 0 = every batch through execute_window_batch (rounds 1-5) */
 #endif
+#ifndef NVCOMP_LZW_RUN_NT
+#define NVCOMP_LZW_RUN_NT 0 /* A/B: the sweep's stores non-temporal */
+#endif
 #ifndef NVCOMP_LZW_RUN_MIN
 #define NVCOMP_LZW_RUN_MIN 4 /* fewer leading sequences of the shape (and fewer than 256 bytes): not worth the fixed cost of this path */
 #endif
@@ -1180,8 +1183,10 @@ __device__ __forceinline__ uint32_t execute_run_batch(
   misfit = true; /* declined because the first sequences are not of this shape at all (RunGate spaces the attempts out) */
   /* uniform tests on the first sequence and the window: what a batch of any other kind of data pays for this path */
   uint32_t off = wave::read_lane(s.match_off, 0);
-  if (off == 0 && n > 1) {
-    off = wave::read_lane(s.match_off, 1); /* Snappy: the literals are an element of their own in front of the copy */
+  if ((off - 1u >= 16u || (off & (off - 1u)) != 0) && n > 1) {
+    /* the second sequence's instead: Snappy's literals are an element of their own in front of the copy; liblz4's fast
+     * compressor starts a run of equal keys with a short match from far back (below: speculated) */
+    off = wave::read_lane(s.match_off, 1);
   }
   if (off - 1u >= 16u || (off & (off - 1u)) != 0) {
     LZ_STAT("run_decl_period", 1);
@@ -1197,7 +1202,10 @@ __device__ __forceinline__ uint32_t execute_run_batch(
   /* the leading sequences of this shape: the period of the first one, at most 16 literals (resident in the ring); a
    * sequence may be literals only (Snappy's literal elements; the run is then what follows it) or nothing at all (the
    * followers of a merged copy train) */
-  const bool weak = lane < n && (s.match_len == 0 || (s.match_off == off && s.match_len < kStreamMatch))
+  /* ... and a match whose distance is a MULTIPLE of the period is taken for what it mostly is on such data -- the same
+   * bytes the run would have produced there (equal keys: the new key's unchanged bytes copied from an earlier key) -- and
+   * checked against the patterns further down */
+  const bool weak = lane < n && (s.match_len == 0 || ((s.match_off & (off - 1u)) == 0 && s.match_off != 0 && s.match_len < kStreamMatch))
                     && (s.lit_len == 0 || (s.lit_len <= 16u && s.lit_src - ir.lo + s.lit_len <= ir.hi - ir.lo));
   const uint64_t not_weak = ~wave::ballot(weak) | (1ull << kRunMax);
   const uint32_t r0 = wave::ctz64(not_weak);
@@ -1218,16 +1226,16 @@ __device__ __forceinline__ uint32_t execute_run_batch(
   const uint32_t next_head = above ? lane + 1 + wave::ctz64(above) : r0;
   const uint32_t L = op + incl - len;      /* where the sequence's literals go */
   const uint32_t M = L + s.lit_len;        /* where its match starts */
-  const uint32_t E = op + wave::shuffle(incl, next_head - 1u); /* heads: where the (merged) run ends */
+  uint32_t E = op + wave::shuffle(incl, next_head - 1u); /* where the sequence's (merged) run ends */
   /* every run holds a 16-byte boundary, so that no block belongs to two joints: the batch ends in front of a shorter one */
   const uint64_t short_run = wave::ballot(head && E - M < 16u);
-  const uint32_t R = short_run ? wave::ctz64(short_run) : r0;
+  uint32_t R = short_run ? wave::ctz64(short_run) : r0;
   if (R < kRunMin) {
     LZ_STAT("run_decl_short", 1);
     return 0;
   }
   heads &= (1ull << R) - 1ull;
-  const uint32_t total = wave::read_lane(incl, R - 1);
+  uint32_t total = wave::read_lane(incl, R - 1);
   {
     /* the batch's end is the only output test; the first match must have its period in front of it (every other one
      * has a run of 16 bytes or more there), in the window if the literals do not cover it */
@@ -1296,6 +1304,82 @@ __device__ __forceinline__ uint32_t execute_run_batch(
 #pragma unroll
     for (uint32_t d = 0; d < 4; ++d) {
       wave::scan_last_writer(q[d], qm[d]);
+    }
+  }
+  /* ---- the speculated matches (distance a multiple of the period, not the period): each one's source bytes must be what
+   * the run's pattern gives at its destination. The source lies in a run of this batch (then its bytes are that run's
+   * pattern: compare the two patterns at the residues the match covers) or, up to 16 bytes, in the output in front of the
+   * batch (one 16-byte load). A match that fails, or whose source is anywhere else, ends the batch in front of it: every
+   * pattern below it is right whatever comes behind (the scan runs upwards), and nothing has been written yet. ---- */
+  {
+    const bool spec = lane < R && s.match_len != 0 && s.match_off != off;
+    if (wave::ballot(spec)) {
+      const uint32_t sp = M - s.match_off; /* wraps for an offset beyond the output: fails every test below */
+      const uint32_t m = s.match_len;
+      const uint32_t sft = (M + ow.align) & 15u;
+      /* (a) in this batch: the sequence t whose output holds sp (the L are ascending; lanes behind the batch hold its end) */
+      uint32_t t = 0;
+#pragma unroll
+      for (uint32_t step = 32; step != 0; step >>= 1) {
+        const uint32_t c = t + step;
+        t = wave::shuffle(L, c) <= sp ? c : t;
+      }
+      const uint32_t mt = wave::shuffle(M, t), et = wave::shuffle(E, t);
+      bool ok = spec && sp >= op && sp + off >= mt && sp + m <= et;
+      {
+        uint32_t cover[4];
+#pragma unroll
+        for (uint32_t d = 0; d < 4; ++d) {
+          cover[d] = low_bytes_mask((int32_t)m - (int32_t)(4 * d)); /* the first min(m, 16) bytes ... */
+        }
+        rotate16(cover, sft); /* ... at the residues of the match's destination */
+        uint32_t diff = 0;
+#pragma unroll
+        for (uint32_t d = 0; d < 4; ++d) {
+          diff |= (wave::shuffle(q[d], t) ^ q[d]) & cover[d];
+        }
+        ok = ok && diff == 0;
+      }
+      /* (b) in HBM in front of the batch, 16 bytes at most, the load inside the chunk's buffer */
+      const bool hbm = spec && !ok && m <= 16u && sp <= ow.flushed && m <= ow.flushed - sp && out_cap >= 16u && sp <= out_cap - 16u;
+      if (wave::ballot(hbm)) {
+        uint32_t want[4] = {q[0], q[1], q[2], q[3]};
+        rotate16(want, (16u - sft) & 15u); /* byte i = the pattern's byte at the destination's position M + i */
+        wave::u32x4 got = {0, 0, 0, 0};
+        if (hbm) {
+          got = wave::gload_u32x4(ow.out + sp);
+        }
+        const uint32_t g[4] = {got.x, got.y, got.z, got.w};
+        uint32_t diff = 0;
+#pragma unroll
+        for (uint32_t d = 0; d < 4; ++d) {
+          diff |= (g[d] ^ want[d]) & low_bytes_mask((int32_t)m - (int32_t)(4 * d));
+        }
+        ok = ok || (hbm && diff == 0);
+      }
+      const uint64_t failed = wave::ballot(spec && !ok);
+      LZ_STAT("run_spec", wave::popc64(wave::ballot(spec)));
+      LZ_STAT("run_spec_failed", wave::popc64(failed));
+      if (failed) {
+        /* the batch ends in front of the first one; its last run may have become short, the batch small */
+        const uint32_t r1 = wave::ctz64(failed);
+        const uint32_t nh = next_head < r1 ? next_head : r1;
+        E = op + wave::shuffle(incl, (nh - 1u) & 63u);
+        const uint64_t cut_short = wave::ballot(head && lane < r1 && E - M < 16u);
+        R = cut_short ? wave::ctz64(cut_short) : r1;
+        if (R < kRunMin) {
+          misfit = true;
+          LZ_STAT("run_decl_spec", 1);
+          return 0;
+        }
+        heads &= (1ull << R) - 1ull;
+        total = wave::read_lane(incl, R - 1);
+        if (total < 64u * wave::popc64(heads) || total < kRunMinBytes) {
+          misfit = true;
+          LZ_STAT("run_decl_spec", 1);
+          return 0;
+        }
+      }
     }
   }
   LZW_T(16); /* runs: the patterns */
@@ -1387,7 +1471,11 @@ __device__ __forceinline__ uint32_t execute_run_batch(
         x = *(const wave::u32x4*)(ow.win + 32u * k + 16u * jb);
       }
       if (bi < nblk) {
+#if NVCOMP_LZW_RUN_NT
+        wave::gstore_u32x4_aligned_nt(gbase + c0 + 16u * bi, x);
+#else
         wave::gstore_u32x4_aligned(gbase + c0 + 16u * bi, x);
+#endif
       }
     }
   }

@@ -256,6 +256,68 @@ def test_run_batches(backend, lz_path, oracle):
         check_roundtrip(backend, oracle, raws, blocks, base_misalign=mis)
 
 
+def test_run_batches_speculated_matches(backend, lz_path, oracle):
+    """liblz4's fast compressor starts a run of equal keys with a short match from far back -- the new key's unchanged bytes,
+    copied from an earlier key, at a distance that is a multiple of the period. The run executor takes such a match for
+    bytes the run would have produced anyway and checks that against the patterns (common/lz_window.hip.h:
+    execute_run_batch): matches that hold and matches that do not (the key's high bytes changed in between), sources in
+    this batch, in front of it, across a run boundary and inside literals, short and long ones, periods 4, 8 and 16; the
+    real column through liblz4; and a distance beyond the output, which must come back as an error, not as bytes."""
+    rng = np.random.RandomState(1234)
+    few = backend.name == "emu"
+    blocks, raws = [], []
+    for off in (4, 8, 16):
+        for variant in range(3 if few else 8):
+            seqs = [(rng.randint(0, 256, size=16).astype(np.uint8).tobytes(), off, 100 + 8 * variant)]
+            produced = 116 + 8 * variant
+            for j in range(60 if few else 220):
+                kind = rng.randint(10)
+                far = off * int(rng.randint(2, 1 + max(2, min(produced // off, 120))))
+                if kind < 4:  # the fast compressor's pair: literals + a short match from a key further back, then the run
+                    nlit = int(rng.randint(1, 4))
+                    mlen = int(rng.randint(4, max(5, off - nlit + 1))) if off > 4 else 4
+                    seqs.append((rng.randint(0, 256, size=nlit).astype(np.uint8).tobytes(), far, mlen))
+                    seqs.append((b"", off, 20 + int(rng.randint(600))))
+                elif kind < 6:  # a clean run
+                    seqs.append((rng.randint(0, 256, size=int(rng.randint(0, 4))).astype(np.uint8).tobytes(), off, 16 + int(rng.randint(500))))
+                elif kind < 7:  # a whole new key: the bytes further back no longer fit
+                    seqs.append((rng.randint(0, 256, size=off).astype(np.uint8).tobytes(), off, 16 + int(rng.randint(300))))
+                elif kind < 9:  # a long match from far back (a multiple of the period), with and without literals
+                    seqs.append((rng.randint(0, 256, size=int(rng.randint(0, 3))).astype(np.uint8).tobytes(), far, 4 + int(rng.randint(60))))
+                    seqs.append((b"", off, 16 + int(rng.randint(100))))
+                else:  # a short match from far back in front of more literals
+                    seqs.append((b"", far, 4 + int(rng.randint(8))))
+                    seqs.append((rng.randint(0, 256, size=2).astype(np.uint8).tobytes(), off, 40 + int(rng.randint(200))))
+                produced = sum(len(l) + m for l, _, m in seqs)
+            tail = rng.randint(0, 256, size=5 + variant).astype(np.uint8).tobytes()
+            blocks.append(_lz4_block(seqs, tail))
+            raws.append(_lz4_expand(seqs, tail))
+    data = datasets.mortgage_col0_like(2 * 65536 + 1000, 5)
+    for c in datasets.split_chunks(data):
+        blocks.append(cpu_compress(oracle, [c], hc=0)[0])
+        raws.append(c)
+    for cc, c in zip(blocks, raws):
+        rc, ref = oracle.lz4_decompress(cc, c.size)
+        assert rc == 0 and np.array_equal(ref, c), "the hand-built block is not what the oracle reads"
+    for mis in ((0, 9) if few else range(16)):
+        check_roundtrip(backend, oracle, raws, blocks, base_misalign=mis)
+    # a distance beyond what has been produced, among runs: an error, whatever path looked at it first
+    bad = []
+    for where in (0, 1, 5, 30):
+        seqs = [(rng.randint(0, 256, size=16).astype(np.uint8).tobytes(), 8, 100)]
+        for j in range(40):
+            far = 8 * 4000 if j == where else 8
+            seqs.append((rng.randint(0, 256, size=2).astype(np.uint8).tobytes(), far, 6 if far != 8 else 200))
+            seqs.append((b"", 8, 300))
+        bad.append(_lz4_block(seqs, b"12345"))
+    codec = backend.codec("LZ4")
+    outs, actual, status = codec.decompress(bad, [65536] * len(bad))
+    for i, b in enumerate(bad):
+        rc, _ = oracle.lz4_decompress(b, 65536)
+        assert rc != 0
+        assert status[i] != NvcompStatus.Success and actual[i] == 0
+
+
 def test_two_byte_length_fields(backend, lz_path, oracle):
     """Lengths that take a second, third, ... extension byte -- matches of 274 bytes and more, literal runs of 270 and more
     -- are what a sorted key column compressed by liblz4 consists of (two literals, 170 .. 680 bytes at offset 8, 165 times
