@@ -416,7 +416,7 @@ def run_case(args, ctx):
     }
     if rank == 0:
         kernel = (f"{args.algo}_decompress_kernel" if own_format or args.algo == "deflate" else lz_decode_kernel(args.algo, n))
-        result["roofline"] = roofline_block(kernel, algorithmic, kernel_ms, args.algo, "decompress", args.dataset, n)
+        result["roofline"] = roofline_block(kernel, algorithmic, kernel_ms, args.algo, "decompress", args.dataset, n, producer)
     if rank == 0 and world == 1 and not args.no_extras:
         # compress leg on the GPU (ratio + compress GB/s of the metric string); not part of `value`
         from nvcomp_amd.batched import empty_batch
@@ -613,7 +613,7 @@ VALU_CYCLES, SALU_CYCLES = 4.1, 4.17  # profiles/r06_valu_issue_*.jsonl
 SCLK_HZ = 2.3e9  # measured under load (profiles/r06_valu_issue_*.jsonl: memtime_ghz 2.2-2.4; PMC pass of the decoder: 2.24)
 
 
-def replayed_counters(algo, kind, dataset, chunks):
+def replayed_counters(algo, kind, dataset, chunks, producer=None):
     """Counters are PMC measurements (separate rocprofv3 --pmc passes, scripts/gpu_traffic.sh): they cannot be taken
     inside this run, so the committed record is REPLAYED -- only for the same kernel, the same workload AND the same
     kernel sources; otherwise null. Returns (record or None, "r" | "stale" | "none": NOTES["traffic_src"])."""
@@ -628,17 +628,19 @@ def replayed_counters(algo, kind, dataset, chunks):
     stale = False
     for rec in records:
         if rec.get("algo") == algo and rec.get("kind") == kind and rec.get("dataset") == dataset and rec.get("chunks_per_gpu") == chunks:
+            if kind == "decompress" and producer is not None and rec.get("producer") not in (None, producer):
+                continue  # the same data through another compressor is another stream (round 6: the sorted-key column, HC and default)
             if rec.get("lib_source_digest") == digest:
                 return rec, "r"
             stale = True
     return None, ("stale" if stale else "none")
 
 
-def roofline_block(kernel, algorithmic, kernel_ms, algo, kind, dataset, chunks):
+def roofline_block(kernel, algorithmic, kernel_ms, algo, kind, dataset, chunks, producer=None):
     """The `roofline` object of a line: useful bytes against the HBM peak, the replayed fabric traffic, and the issue side
     (for the LZ kernels it is vector issue, not bytes, that binds). What the fields mean is said once, in `notes`."""
     achieved = algorithmic / (kernel_ms * 1e-3) / 1e9
-    rec, source = replayed_counters(algo, kind, dataset, chunks)
+    rec, source = replayed_counters(algo, kind, dataset, chunks, producer)
     block = {
         "bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_launch": int(algorithmic),
@@ -1022,6 +1024,13 @@ def main():
         # ratio 38.9, A100 decompress 320.7 GB/s): long matches and runs -- the data that CAN approach the roofline
         result["extras"]["lz4_mortgage_like"] = rider(args, ctx, "lz4", dataset="mortgage_col0_like",
                                                       mib_per_gpu=min(args.mib_per_gpu, 1024), unique_mib=min(args.unique_mib, 64))
+        # ... the same column through liblz4's DEFAULT compressor (every run starts with a 6-byte match from an earlier key:
+        # the run executor's speculated matches, common/lz_window.hip.h), and an int32 column (runs of period 4, one in twenty
+        # shorter than 16 bytes)
+        result["extras"]["lz4_mortgage_like_default"] = rider(args, ctx, "lz4", dataset="mortgage_col0_like", producer="fast",
+                                                              mib_per_gpu=min(args.mib_per_gpu, 1024), unique_mib=min(args.unique_mib, 64))
+        result["extras"]["lz4_int32"] = rider(args, ctx, "lz4", dataset="int32", producer="fast",
+                                              mib_per_gpu=min(args.mib_per_gpu, 1024), unique_mib=min(args.unique_mib, 32))
         # The headline batch is the size where the tail of the last round of persistent waves vanishes; the reference's own
         # programs run 1 ... 8 192 chunks (benchmarks/benchmark_lz4_synth.cpp:64-72) and 5 021 (doc/Benchmarks.md:88-95):
         # the same mix, producer and checks at 16 384, 4 096 and 256 chunks (persistent waves / two waves per chunk / a

@@ -21,6 +21,8 @@ KERNELS = {
     "ans": [("ans_decompress_kernel", "ans", "decompress"), ("ans_compress_kernel", "ans", "compress")],
     "bitcomp": [("bitcomp_decompress_kernel", "bitcomp", "decompress"), ("bitcomp_compress_kernel", "bitcomp", "compress")],
     "lz4_mortgage": [("lz4_decompress_window_kernel", "lz4", "decompress")],
+    "lz4_mortgage_default": [("lz4_decompress_window_kernel", "lz4", "decompress")],
+    "lz4_int32": [("lz4_decompress_window_kernel", "lz4", "decompress")],
     # the batch-size riders of the driver's line
     "lz4_16384": [("lz4_decompress_window_kernel", "lz4", "decompress")],
     "lz4_4096": [("lz4_decompress_pair_kernel", "lz4", "decompress")],
@@ -90,6 +92,7 @@ def main():
             uncounted = fetch
             records.append({
                 "algo": algo, "kind": kind, "kernel": substr, "dataset": cfg["dataset"], "chunks_per_gpu": cfg["chunks_per_gpu"],
+                "producer": cfg.get("producer") if kind == "decompress" else None,
                 "lib_source_digest": bench.library_source_digest(algo),
                 "fetch_bytes_counted": int(fetch), "write_bytes_counted": int(write),
                 "hbm_bytes_per_launch": int(fetch + uncounted + write),

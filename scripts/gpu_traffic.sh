@@ -26,6 +26,8 @@ run cascaded --algo cascaded --dataset example_float_columns --mib-per-gpu 1024 
 run ans --algo ans --dataset silesia_style --mib-per-gpu 1024 --unique-mib 32
 run bitcomp --algo bitcomp --dataset float_columns --mib-per-gpu 1024 --unique-mib 32
 run lz4_mortgage --no-extras --dataset mortgage_col0_like --mib-per-gpu 1024 --unique-mib 64
+run lz4_mortgage_default --no-extras --dataset mortgage_col0_like --producer fast --mib-per-gpu 1024 --unique-mib 64
+run lz4_int32 --no-extras --dataset int32 --producer fast --mib-per-gpu 1024 --unique-mib 32
 run lz4_16384 --no-extras --mib-per-gpu 1024
 run lz4_4096 --no-extras --mib-per-gpu 256
 run lz4_256 --no-extras --mib-per-gpu 16 --unique-mib 16
@@ -41,7 +43,7 @@ if [ -n "${ONLY:-}" ]; then # the other codecs' records stay as committed (their
   python - "$OUT/pmc_traffic_r06.json" <<'PY'
 import json, sys
 new = json.load(open(sys.argv[1])); old = json.load(open("profiles/pmc_traffic_r06.json"))
-key = lambda r: (r["algo"], r["kind"], r["dataset"], r["chunks_per_gpu"])
+key = lambda r: (r["algo"], r["kind"], r["dataset"], r["chunks_per_gpu"], r.get("producer"))
 fresh = {key(r) for r in new}
 json.dump([r for r in old if key(r) not in fresh] + new, open(sys.argv[1], "w"), indent=1)
 PY
