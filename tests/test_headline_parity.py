@@ -16,9 +16,16 @@ UNIQUE_MIB = 64
 REPLICAS = 16  # 16 x 1 024 chunks = 16 384 chunks, 1 GiB of output, every replica in device memory of its own
 
 
+# (format, dataset, producer): the headline mix; and, since round 6, the columns the run executor takes (common/lz_window.hip.h:
+# execute_run_batch) -- the sorted-key column through liblz4 HC (clean runs) and through its default compressor (every run
+# starts with a match from far back: the speculated matches), the int32 column -- at the same batch size
+CASES = [("LZ4", "silesia_style", "hc"), ("Snappy", "silesia_style", "snappy"), ("LZ4", "mortgage_col0_like", "hc"),
+         ("LZ4", "mortgage_col0_like", "fast"), ("LZ4", "int32", "fast"), ("Snappy", "int32", "snappy")]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("fmt", ["LZ4", "Snappy"])
-def test_headline_batch_against_the_cpu_decoder(gpu, oracle, fmt):
+@pytest.mark.parametrize("fmt,dataset,producer", CASES, ids=[f"{f}-{d}-{p}" for f, d, p in CASES])
+def test_headline_batch_against_the_cpu_decoder(gpu, oracle, fmt, dataset, producer):
     import torch
 
     from nvcomp_amd.batched import BatchedCodec, DeviceBatch
@@ -27,11 +34,12 @@ def test_headline_batch_against_the_cpu_decoder(gpu, oracle, fmt):
         pytest.skip("oracle/_ref (liblz4 / libsnappy shim) is not built")
     dev = gpu.dev
     threads = len(os.sched_getaffinity(0))
-    data = datasets.silesia_style(UNIQUE_MIB << 20, 0)
+    gen = getattr(datasets, dataset) if hasattr(datasets, dataset) else datasets.CLASSES[dataset]
+    data = gen(UNIQUE_MIB << 20, 0)
     chunks = datasets.split_chunks(data, CHUNK)
     n_u = len(chunks)
     if fmt == "LZ4":
-        enc, dec = oracle.LZ4_ENC_HC, oracle.LZ4_DEC
+        enc, dec = (oracle.LZ4_ENC_HC if producer == "hc" else oracle.LZ4_ENC), oracle.LZ4_DEC
         caps = [oracle.lz4_bound(c.size) + 64 for c in chunks]
     else:
         enc, dec = oracle.SNAPPY_ENC, oracle.SNAPPY_DEC
