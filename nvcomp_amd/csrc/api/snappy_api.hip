@@ -42,6 +42,13 @@ constexpr unsigned kWideWaves = NVCOMP_LZMW_WAVES_PER_BLOCK;
 #define NVCOMP_LZMW_WAVES_PER_SIMD 4 /* what the wave's LDS allows (15-16 waves per CU): a budget of 128 registers */
 #endif
 using lzl::kMaxOutCap;
+#ifndef NVCOMP_SNAPPY_RUNS
+#define NVCOMP_SNAPPY_RUNS 1 /* A/B: 0 = no run executor in the Snappy decoder */
+#endif
+#ifndef NVCOMP_SNAPPY_RUNS_RATIO
+#define NVCOMP_SNAPPY_RUNS_RATIO 8
+#endif
+constexpr size_t kRunsRatio = NVCOMP_SNAPPY_RUNS_RATIO;
 
 /* Decode chunk `chunk` of the batch with the calling wave and report its size and status. */
 template <bool CHECKED, class BatchPtr>
@@ -59,7 +66,12 @@ __device__ __forceinline__ void decode_one(BatchPtr b, size_t chunk, uint8_t* ld
   if (in_len64 > 0xffffffffull - 64) {
     err = lz::kErrInput;
   } else {
-    produced = snappyw::decode_chunk<CHECKED>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err);
+    /* a chunk that shrank 8 x or more takes the instance of the loop that tries the run executor (snappyw::decode_chunk) */
+    if (NVCOMP_LZW_RUNS && NVCOMP_SNAPPY_RUNS && in_len64 * kRunsRatio <= cap64) {
+      produced = snappyw::decode_chunk<CHECKED, true>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err);
+    } else {
+      produced = snappyw::decode_chunk<CHECKED, false>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err);
+    }
   }
   if (wave::lane_id() == 0) {
     size_t* actual_bytes = b->actual_bytes;

@@ -260,6 +260,13 @@ __device__ __forceinline__ uint32_t shuffle(uint32_t v, uint32_t src_lane)
   return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
 }
 
+/* Per-lane scatter: lane i's v goes to lane dst_lane(i) (ds_permute_b32). dst_lane must be a permutation of the wave (a lane
+ * that nobody writes to reads as 0 on the hardware; the callers do not rely on it). */
+__device__ __forceinline__ uint32_t permute_to(uint32_t v, uint32_t dst_lane)
+{
+  return (uint32_t)__builtin_amdgcn_ds_permute((int)(dst_lane << 2), (int)v);
+}
+
 /* v of the lane below (lane 0: 0): one DPP move across the whole wave (wave_shr:1), no LDS crossbar round trip. */
 __device__ __forceinline__ uint32_t prev_lane(uint32_t v)
 {

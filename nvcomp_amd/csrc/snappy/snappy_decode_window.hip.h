@@ -360,11 +360,10 @@ struct TeamFrontEnd
   }
 };
 
-/* RUNS: lz4_decode_window.hip.h: decode_chunk. No caller turns it on for Snappy: a refill's 64 elements are ~9 runs (a
- * literal element and a train of 64-byte copies each), 2-4 KB a batch, where the run executor's fixed cost is not earned
- * back (int32 column 1 308 -> 1 210 GB/s with every batch tried, gpurun r6t), and libsnappy spells the sorted-key column
- * with a 6-byte copy from far back in every run, which ends a batch (1 454 -> 1 021). The executor itself takes Snappy's
- * shapes (literal-only elements, the empty followers of a merged train). */
+/* RUNS: lz4_decode_window.hip.h: decode_chunk -- the instance of the loop that tries the run executor, for the chunks that
+ * shrank 8 x (snappy_api.hip: decode_one). A refill's 64 elements are only ~9 runs here, 2-4 KB, which does not earn the
+ * executor's fixed cost back (int32 column 1 308 -> 1 210 GB/s with every batch tried as it came, gpurun r6t): this loop
+ * squeezes the empty followers of the merged trains out and tops the sequences in hand up first (below). */
 template <bool CHECKED, bool RUNS = false>
 __device__ __forceinline__ uint32_t decode_chunk(
     const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_cap, uint8_t* lds, uint32_t& err)
@@ -432,7 +431,55 @@ __device__ __forceinline__ uint32_t decode_chunk(
       }
       LZW_T(3);
     }
-    const uint64_t train = merge_trains(s, count);
+    uint64_t train = merge_trains(s, count);
+    if (RUNS && lzw::run_gate_open(gate)) {
+      /* The run executor takes 60 sequences a batch, and a refill's 64 elements of a typed column are ~9 runs -- a literal
+       * element and a train of 64-byte copies each, the followers of a train EMPTY sequences behind its head: the empty
+       * ones are squeezed out and more elements taken in, until 48 sequences are in hand (or the stream, or the ring, ends). */
+      for (uint32_t topup = 0; topup < 12; ++topup) {
+        const bool live = lane < count && (s.lit_len | s.match_len) != 0;
+        const uint64_t lm = wave::ballot(live);
+        const uint32_t n_live = wave::popc64(lm);
+        if (n_live != count) {
+          const uint32_t below = wave::prefix_popc(lm);
+          const uint32_t to = live ? below : n_live + (lane - below); /* a permutation: the others, empty, behind the live ones */
+          seqpos = wave::permute_to(live ? seqpos : 0u, to);
+          s.lit_src = wave::permute_to(live ? s.lit_src : 0u, to);
+          s.lit_len = wave::permute_to(live ? s.lit_len : 0u, to);
+          s.match_off = wave::permute_to(live ? s.match_off : 0u, to);
+          s.match_len = wave::permute_to(live ? s.match_len : 0u, to);
+          count = n_live;
+          train = 0;
+          LZ_STAT("sn_compactions", 1);
+        }
+        if (count >= 48 || c.q >= ir.vend) {
+          break;
+        }
+        const uint32_t oldest = count ? wave::read_lane(seqpos, 0) : c.q;
+        if (c.q + lzw::kChaseWin + DeltaFn::kReach - (oldest & ~(lzw::kInBlock - 1)) > lzw::kInRing) {
+          break; /* the elements in hand hold the ring: the next chase window would reach past what can be resident */
+        }
+        lzw::in_ensure(ir, oldest, (c.q & ~(lzw::kInBlock - 1)) + 3 * lzw::kInBlock);
+        const uint32_t before = count;
+        count = lzw::chase_tokens(c, ir, seqpos, count, DeltaFn(), SlowFn());
+        if (count <= before) {
+          break;
+        }
+        lz::Seq fresh;
+        bool bad;
+        if (!parse_fast(ir, seqpos, before, count, fresh, bad)) {
+          parse(ir, seqpos, lane >= before && lane < count, fresh, bad);
+        }
+        if (lane >= before) {
+          s = fresh;
+        }
+        if (wave::ballot(bad)) {
+          err |= lz::kErrInput;
+          return 0;
+        }
+        train = merge_trains(s, count);
+      }
+    }
     LZW_T(15); /* copy trains merged */
     LZ_STAT("sn_rounds", 1);
     LZ_STAT("sn_rounds_with_train", train ? 1 : 0);

@@ -183,6 +183,24 @@ inline uint32_t shuffle(uint32_t v, uint32_t src_lane)
   return (uint32_t)emu::peer((int)(src_lane & 63)).a;
 }
 
+inline uint32_t permute_to(uint32_t v, uint32_t dst_lane)
+{
+  emu::wave_rendezvous(kShuffle, v, dst_lane);
+  uint32_t r = 0;
+  int writers = 0;
+  for (int i = 0; i < 64; ++i) {
+    if (((uint32_t)emu::peer(i).b & 63u) == (uint32_t)lane_id()) {
+      r = (uint32_t)emu::peer(i).a;
+      ++writers;
+    }
+  }
+  if (writers != 1) {
+    fprintf(stderr, "emu: permute_to with destinations that are not a permutation\n");
+    abort();
+  }
+  return r;
+}
+
 inline uint32_t next_lane(uint32_t v)
 {
   const uint32_t r = shuffle(v, (uint32_t)(lane_id() + 1) & 63u);
