@@ -1226,10 +1226,26 @@ __device__ __forceinline__ uint32_t execute_run_batch(
   const uint32_t next_head = above ? lane + 1 + wave::ctz64(above) : r0;
   const uint32_t L = op + incl - len;      /* where the sequence's literals go */
   const uint32_t M = L + s.lit_len;        /* where its match starts */
-  uint32_t E = op + wave::shuffle(incl, next_head - 1u); /* where the sequence's (merged) run ends */
-  /* every run holds a 16-byte boundary, so that no block belongs to two joints: the batch ends in front of a shorter one */
-  const uint64_t short_run = wave::ballot(head && E - M < 16u);
-  uint32_t R = short_run ? wave::ctz64(short_run) : r0;
+  uint32_t E = 0; /* where the sequence's (merged) run ends */
+  /* How many of the r1 leading sequences a batch can be. Every run must hold a 16-byte boundary of the output, so that no
+   * block belongs to two joints (a run of 16 bytes always does, one of r < 16 in (r + 1) of 16 positions): the batch ends in
+   * front of the first that does not. And the last run must be 16 bytes long: the window restarts with its pattern as the
+   * last 16 bytes of the output. */
+  auto settle = [&](uint32_t r1) -> uint32_t {
+    const uint32_t nh = next_head < r1 ? next_head : r1;
+    E = op + wave::shuffle(incl, (nh - 1u) & 63u);
+    const uint64_t no_boundary = wave::ballot(head && lane < r1 && ((E + ow.align) & ~15u) < ((M + ow.align + 15u) & ~15u));
+    uint32_t r = no_boundary ? wave::ctz64(no_boundary) : r1;
+    for (uint32_t i = 0; i < 4 && r >= kRunMin; ++i) {
+      const uint32_t last_head = 63u - (uint32_t)__builtin_clzll(heads & ((1ull << r) - 1ull)); /* lane 0 is a head */
+      if (wave::read_lane(E - M, last_head) >= 16u) {
+        return r;
+      }
+      r = last_head;
+    }
+    return 0;
+  };
+  uint32_t R = settle(r0);
   if (R < kRunMin) {
     LZ_STAT("run_decl_short", 1);
     return 0;
@@ -1238,7 +1254,7 @@ __device__ __forceinline__ uint32_t execute_run_batch(
   uint32_t total = wave::read_lane(incl, R - 1);
   {
     /* the batch's end is the only output test; the first match must have its period in front of it (every other one
-     * has a run of 16 bytes or more there), in the window if the literals do not cover it */
+     * starts behind it), in the window if the literals do not cover it */
     const uint32_t m0 = op + wave::read_lane(s.lit_len, 0);
     if (op + total > out_cap || m0 < off || (m0 - op < off && m0 - off < ow.valid_lo)) {
       LZ_STAT("run_decl_first", 1);
@@ -1362,11 +1378,7 @@ __device__ __forceinline__ uint32_t execute_run_batch(
       LZ_STAT("run_spec_failed", wave::popc64(failed));
       if (failed) {
         /* the batch ends in front of the first one; its last run may have become short, the batch small */
-        const uint32_t r1 = wave::ctz64(failed);
-        const uint32_t nh = next_head < r1 ? next_head : r1;
-        E = op + wave::shuffle(incl, (nh - 1u) & 63u);
-        const uint64_t cut_short = wave::ballot(head && lane < r1 && E - M < 16u);
-        R = cut_short ? wave::ctz64(cut_short) : r1;
+        R = settle(wave::ctz64(failed));
         if (R < kRunMin) {
           misfit = true;
           LZ_STAT("run_decl_spec", 1);
