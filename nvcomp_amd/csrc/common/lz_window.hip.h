@@ -1227,15 +1227,14 @@ __device__ __forceinline__ uint32_t execute_run_batch(
   const uint32_t L = op + incl - len;      /* where the sequence's literals go */
   const uint32_t M = L + s.lit_len;        /* where its match starts */
   uint32_t E = 0; /* where the sequence's (merged) run ends */
-  /* How many of the r1 leading sequences a batch can be. Every run must hold a 16-byte boundary of the output, so that no
-   * block belongs to two joints (a run of 16 bytes always does, one of r < 16 in (r + 1) of 16 positions): the batch ends in
-   * front of the first that does not. And the last run must be 16 bytes long: the window restarts with its pattern as the
-   * last 16 bytes of the output. */
+  /* How many of the r1 leading sequences a batch can be: its last run must be 16 bytes long -- the window restarts with its
+   * pattern as the last 16 bytes of the output. (Runs in between may be of any length: the joints of sequences that meet in
+   * one block share it, below. The first versions ended a batch at a run shorter than 16 bytes, then at one without a block
+   * boundary in it: int32 column 1 750-1 810, then 2 370-2 570 GB/s.) */
   auto settle = [&](uint32_t r1) -> uint32_t {
     const uint32_t nh = next_head < r1 ? next_head : r1;
     E = op + wave::shuffle(incl, (nh - 1u) & 63u);
-    const uint64_t no_boundary = wave::ballot(head && lane < r1 && ((E + ow.align) & ~15u) < ((M + ow.align + 15u) & ~15u));
-    uint32_t r = no_boundary ? wave::ctz64(no_boundary) : r1;
+    uint32_t r = r1;
     for (uint32_t i = 0; i < 4 && r >= kRunMin; ++i) {
       const uint32_t last_head = 63u - (uint32_t)__builtin_clzll(heads & ((1ull << r) - 1ull)); /* lane 0 is a head */
       if (wave::read_lane(E - M, last_head) >= 16u) {
@@ -1395,73 +1394,132 @@ __device__ __forceinline__ uint32_t execute_run_batch(
     }
   }
   LZW_T(16); /* runs: the patterns */
-  /* ---- joints ---- */
+  /* ---- joints: the blocks that are not all one run, assembled on a canvas in LDS (the window's, which nothing else needs
+   * meanwhile). A head's joint are the blocks from its first literal to the first whole block of its run, two at most;
+   * when its run is too short to reach the next block boundary the next head's joint starts in the same block, and the
+   * two (or more) share that block of the canvas. Every byte of the canvas has one writer -- the head whose literals or
+   * whose run it belongs to (a run's bytes: its pattern, masked) -- so the writes are ORs into a zeroed canvas and plain
+   * stores of the literals. ---- */
   uint8_t* const gbase = ow.out - ow.align; /* coordinate 0 */
   const bool jlane = wave::lane_in(heads);
   {
-    uint32_t qp[4];
-#pragma unroll
-    for (uint32_t d = 0; d < 4; ++d) {
-      const uint32_t below = wave::prev_lane(q[d]);
-      qp[d] = lane == 0 ? qi[d] : below;
-    }
-    const uint32_t a = (L + ow.align) & 15u; /* where the literals start in the joint's first block */
-    const uint32_t mm = a + s.lit_len;       /* where the run starts: 0 .. 31 */
-    const uint32_t nj = jlane ? (mm + 15u) >> 4 : 0u;
-    wave::u32x4 b0, b1;
-    {
+    const uint32_t cl = L + ow.align, cm = M + ow.align; /* coordinates of the literals and of the run */
+    const uint32_t a = cl & 15u;                         /* where the literals start in the joint's first block */
+    const uint32_t b0 = cl >> 4, b1 = (cm + 15u) >> 4;   /* the joint's blocks [b0, b1) */
+    const uint32_t nj = jlane ? b1 - b0 : 0u;
+    /* a head whose first block is the last block of the joint below shares it (the b1 are ascending: the running maximum is
+     * the nearest one below) */
+    const uint32_t below_b1 = wave::prev_lane(wave::scan_max_inclusive(nj ? b1 : 0u));
+    const uint32_t shared = nj != 0 && below_b1 == b0 + 1u ? 1u : 0u;
+    /* The common batch (the sorted-key column: every run hundreds of bytes) has no shared block and no run that ends inside
+     * its own joint: every head then owns the two blocks at 2 x its lane, writes them whole -- the pattern below up to its
+     * literals, its own pattern behind -- and its literals over them: a sixth of the instructions of the general case. */
+    const bool plain = wave::ballot(jlane && (shared != 0 || ((E + ow.align) >> 4) < b1)) == 0;
+    const uint32_t cv = plain ? 2u * lane : wave::scan_add_inclusive(nj - shared) - nj; /* the joint's first block on the canvas */
+    uint32_t* const canvas = (uint32_t*)ow.win;
+    wave::sync(); /* the window's blocks have been read */
+    if (plain) {
+      wave::u32x4 w0, w1;
       uint32_t x[4];
 #pragma unroll
       for (uint32_t d = 0; d < 4; ++d) {
+        const uint32_t below = wave::prev_lane(q[d]);
         const uint32_t m = low_bytes_mask((int32_t)a - (int32_t)(4 * d));
-        x[d] = (qp[d] & m) | (q[d] & ~m);
+        x[d] = ((lane == 0 ? qi[d] : below) & m) | (q[d] & ~m);
       }
-      b0.x = x[0], b0.y = x[1], b0.z = x[2], b0.w = x[3];
-      b1.x = q[0], b1.y = q[1], b1.z = q[2], b1.w = q[3];
+      w0.x = x[0], w0.y = x[1], w0.z = x[2], w0.w = x[3];
+      w1.x = q[0], w1.y = q[1], w1.z = q[2], w1.w = q[3];
+      if (lane < kRunMax) {
+        *(wave::u32x4*)(ow.win + 32u * lane) = w0;
+        *(wave::u32x4*)(ow.win + 32u * lane + 16) = w1;
+      }
+    } else {
+      const wave::u32x4 zero = {0, 0, 0, 0};
+      if (lane < kRunMax) {
+        *(wave::u32x4*)(ow.win + 32u * lane) = zero;
+        *(wave::u32x4*)(ow.win + 32u * lane + 16) = zero;
+      }
     }
-    wave::sync(); /* the window's blocks have been read */
-    uint8_t* slot = ow.win + 32u * lane;
-    *(wave::u32x4*)slot = b0;
-    *(wave::u32x4*)(slot + 16) = b1;
     wave::sync();
-    if (jlane && s.lit_len >= 4) {
-      const uint32_t last = s.lit_len - 4;
-      uint32_t data[4];
+    const uint32_t next_cv = plain ? 0u : wave::shuffle(cv, next_head & 63u); /* where the next head's joint starts */
+    if (jlane && !plain) {
+      /* my run's bytes inside my own joint: from the run's start to the joint's end or the run's, whichever is first */
+      const uint32_t run_lo = a + s.lit_len;          /* relative to my first block: 0 .. 31 */
+      const uint32_t run_hi = E + ow.align - 16u * b0; /* where my run ends, relative to my first block */
+      const uint32_t hi = run_hi < 16u * nj ? run_hi : 16u * nj;
 #pragma unroll
-      for (uint32_t i = 0; i < 4; ++i) {
-        const uint32_t o = 4 * i < last ? 4 * i : last;
-        data[i] = ld32(ir.ring + ((s.lit_src + o) & (kInRing - 1)));
+      for (uint32_t d = 0; d < 8; ++d) {
+        const uint32_t m = low_bytes_mask((int32_t)hi - (int32_t)(4 * d)) & ~low_bytes_mask((int32_t)run_lo - (int32_t)(4 * d));
+        if (m != 0 && 4 * d < 16u * nj) {
+          wave::lds_or(canvas + 4u * cv + d, q[d & 3] & m);
+        }
       }
+      /* ... and in front of the next head's literals, when those start in a block of their own */
+      const uint32_t ce = E + ow.align;
+      if (next_head < R && (ce >> 4) >= b1 && (ce & 15u) != 0) {
 #pragma unroll
-      for (uint32_t i = 0; i < 4; ++i) {
-        const uint32_t o = 4 * i < last ? 4 * i : last;
-        lz::st_u32(slot + a + o, data[i]);
+        for (uint32_t d = 0; d < 4; ++d) {
+          const uint32_t m = low_bytes_mask((int32_t)(ce & 15u) - (int32_t)(4 * d));
+          if (m != 0) {
+            wave::lds_or(canvas + 4u * next_cv + d, q[d] & m);
+          }
+        }
       }
-    } else if (jlane && s.lit_len != 0) {
-      slot[a] = ir.ring[s.lit_src & (kInRing - 1)];
-      if (s.lit_len > 1) {
-        slot[a + 1] = ir.ring[(s.lit_src + 1) & (kInRing - 1)];
-      }
-      if (s.lit_len > 2) {
-        slot[a + 2] = ir.ring[(s.lit_src + 2) & (kInRing - 1)];
+      /* the first joint's first block starts with the output in front of the batch (the window's tail block) */
+      if (lane == 0 && nj != 0) {
+#pragma unroll
+        for (uint32_t d = 0; d < 4; ++d) {
+          const uint32_t m = low_bytes_mask((int32_t)a - (int32_t)(4 * d));
+          if (m != 0) {
+            wave::lds_or(canvas + 4u * cv + d, qi[d] & m);
+          }
+        }
       }
     }
-    /* the table of the sweep: one word a run, in address order -- its first block's number in the batch, how many of
-     * its blocks are joint blocks, its lane; unused entries compare above every block */
+    if (jlane) {
+      /* the literals */
+      uint8_t* at = ow.win + 16u * cv + a;
+      if (s.lit_len >= 4) {
+        const uint32_t last = s.lit_len - 4;
+        uint32_t data[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+          const uint32_t o = 4 * i < last ? 4 * i : last;
+          data[i] = ld32(ir.ring + ((s.lit_src + o) & (kInRing - 1)));
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+          const uint32_t o = 4 * i < last ? 4 * i : last;
+          lz::st_u32(at + o, data[i]);
+        }
+      } else if (s.lit_len != 0) {
+        at[0] = ir.ring[s.lit_src & (kInRing - 1)];
+        if (s.lit_len > 1) {
+          at[1] = ir.ring[(s.lit_src + 1) & (kInRing - 1)];
+        }
+        if (s.lit_len > 2) {
+          at[2] = ir.ring[(s.lit_src + 2) & (kInRing - 1)];
+        }
+      }
+    }
+    /* the table of the sweep: one word a head, in address order -- its first block's number in the batch (14 bits), how many
+     * of its blocks are joint blocks (2), where they are on the canvas (7), its lane (6: whose pattern the blocks behind
+     * the joint hold); unused entries compare above every block. Heads that start in one block have equal block numbers:
+     * the search below takes the last of them, whose canvas block is the shared one and whose run goes on behind it. */
     uint32_t* tab = (uint32_t*)(ow.win + 32u * kRunMax);
     tab[lane] = ~0u;
     wave::sync();
     if (jlane) {
-      const uint32_t blk = (((L + ow.align) & ~15u) - ((op + ow.align) & ~15u)) >> 4;
-      tab[wave::prefix_popc(heads)] = (blk << 8) | (nj << 6) | lane;
+      const uint32_t blk = b0 - ((op + ow.align) >> 4);
+      tab[wave::prefix_popc(heads)] = (blk << 15) | (nj << 13) | (cv << 6) | lane;
     }
     wave::sync();
   }
   LZW_T(17); /* runs: the joints */
-  /* ---- the sweep: every whole block of the batch, in address order, 1 KiB a store instruction. A lane finds the run its
-   * block belongs to (binary search of the table) and takes the block from that run's joint slot or its pattern from
-   * that run's lane. (Stores run by run -- a run's ~25 blocks an instruction, the joints scattered -- left the memory
-   * pipe the bound: 2 550 GB/s on the sorted-key column, two thirds of the time in that loop: gpurun r6q, r6r.) ---- */
+  /* ---- the sweep: every whole block of the batch, in address order, 1 KiB a store instruction. A lane finds the head its
+   * block belongs to (binary search of the table) and takes the block from the canvas or that head's pattern from its
+   * lane. (Stores run by run -- a run's ~25 blocks an instruction, the joints scattered -- left the memory pipe the bound:
+   * 2 550 GB/s on the sorted-key column, two thirds of the time in that loop: gpurun r6q, r6r.) ---- */
   {
     const uint32_t* tab = (const uint32_t*)(ow.win + 32u * kRunMax);
     const uint32_t c0 = (op + ow.align) & ~15u;
@@ -1472,15 +1530,15 @@ __device__ __forceinline__ uint32_t execute_run_batch(
 #pragma unroll
       for (uint32_t step = 32; step != 0; step >>= 1) {
         const uint32_t c = lo + step;
-        lo = (tab[c] >> 8) <= bi ? c : lo;
+        lo = (tab[c] >> 15) <= bi ? c : lo;
       }
       const uint32_t key = tab[lo];
-      const uint32_t k = key & 63u, jb = bi - (key >> 8);
-      const bool joint = jb < ((key >> 6) & 3u);
+      const uint32_t k = key & 63u, jb = bi - (key >> 15);
+      const bool joint = jb < ((key >> 13) & 3u);
       wave::u32x4 x;
       x.x = wave::shuffle(q[0], k), x.y = wave::shuffle(q[1], k), x.z = wave::shuffle(q[2], k), x.w = wave::shuffle(q[3], k);
       if (joint) {
-        x = *(const wave::u32x4*)(ow.win + 32u * k + 16u * jb);
+        x = *(const wave::u32x4*)(ow.win + 16u * (((key >> 6) & 127u) + jb));
       }
       if (bi < nblk) {
 #if NVCOMP_LZW_RUN_NT

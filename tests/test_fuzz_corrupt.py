@@ -80,6 +80,42 @@ def test_corrupt_streams_are_contained(backend, lz_path, oracle, fmt):
         codec.decompress(bad, caps, checked=False, comp_align=align, out_align=align)
 
 
+@pytest.mark.parametrize("fmt", ["LZ4", "Snappy"])
+def test_corrupt_column_streams_are_contained(backend, lz_path, oracle, fmt):
+    """The same on the data the run executor takes (common/lz_window.hip.h: execute_run_batch; chunks that shrank 8 x go
+    through the loop that holds it): sorted-key and int32 columns through liblz4 (default and HC) / libsnappy, damaged --
+    offsets that stop being multiples of the period, lengths that overshoot the chunk, periods that change under a run,
+    a speculated match whose source moved. Canaries behind every slot; an accepted stream decodes like the CPU oracle's."""
+    rng = np.random.RandomState(77 if fmt == "LZ4" else 78)
+    n = 120 if backend.name == "gpu" else 30
+    gens = [datasets.mortgage_col0_like, datasets.int32_column]
+    chunks = [gens[i % 2](65536 if i % 3 else int(rng.choice([9000, 30000])), i) for i in range(n)]
+    if fmt == "LZ4":
+        good = [(oracle.ref_lz4_compress(c, 12 if i % 4 == 0 else 0) if oracle.have_ref() else oracle.lz4_compress(c)) for i, c in enumerate(chunks)]
+        dec = oracle.lz4_decompress
+    else:
+        good = [(oracle.ref_snappy_compress(c) if oracle.have_ref() else oracle.snappy_compress(c)) for c in chunks]
+        dec = oracle.snappy_decompress
+    bad = [damage(rng, g) if i % 8 else g for i, g in enumerate(good)]  # one in eight stays valid
+    caps = [c.size for c in chunks]
+    codec = backend.codec(fmt)
+    outs, actual, status = codec.decompress(bad, caps)  # canaries checked inside
+    accepted = 0
+    for i, (b, cap) in enumerate(zip(bad, caps)):
+        rc, ref = dec(b, cap)
+        if status[i] == NvcompStatus.Success:
+            accepted += 1
+            assert actual[i] <= cap
+            if rc == 0:
+                assert actual[i] == ref.size and np.array_equal(outs[i][: ref.size], ref), f"{fmt} chunk {i}"
+        else:
+            assert actual[i] == 0
+            assert rc != 0, f"{fmt} chunk {i}: rejected a stream the CPU oracle reads"
+        if i % 8 == 0:
+            assert status[i] == NvcompStatus.Success and np.array_equal(outs[i], chunks[i]), f"{fmt} chunk {i}: a valid stream"
+    assert 0 < accepted < n
+
+
 @pytest.mark.parametrize("fmt", ["Deflate", "Gzip"])
 def test_corrupt_deflate_streams_are_contained(backend, fmt):
     """The same for DEFLATE / gzip against zlib: what zlib accepts must decode to the same bytes; what it rejects may be
