@@ -592,7 +592,7 @@ def lz_decode_kernel(algo, chunks):
     common/lz_launch.hip.h: a workgroup per chunk / two waves per chunk / persistent waves)."""
     if chunks <= 512:  # NVCOMP_LZ_TEAM_MAX_BATCH (tests/test_abi.py keeps the two in step)
         return f"{algo}_decompress_team_kernel"
-    return f"{algo}_decompress_pair_kernel" if chunks <= 4096 else f"{algo}_decompress_window_kernel"
+    return f"{algo}_decompress_pair_kernel" if chunks <= 4096 else f"{algo}_decompress_window_kernel"  # NVCOMP_LZ_PAIR_MAX_BATCH
 
 
 PMC_RECORD = "pmc_traffic_r06.json"
@@ -1031,6 +1031,10 @@ def main():
                                                               mib_per_gpu=min(args.mib_per_gpu, 1024), unique_mib=min(args.unique_mib, 64))
         result["extras"]["lz4_int32"] = rider(args, ctx, "lz4", dataset="int32", producer="fast",
                                               mib_per_gpu=min(args.mib_per_gpu, 1024), unique_mib=min(args.unique_mib, 32))
+        # ... and the sorted-key column at the batch size of the reference's published run (5 021 chunks: 5 120 here)
+        if args.mib_per_gpu > 320:
+            result["extras"]["lz4_mortgage_like_5120"] = rider(args, ctx, "lz4", dataset="mortgage_col0_like", mib_per_gpu=320,
+                                                               unique_mib=min(args.unique_mib, 32))
         # The headline batch is the size where the tail of the last round of persistent waves vanishes; the reference's own
         # programs run 1 ... 8 192 chunks (benchmarks/benchmark_lz4_synth.cpp:64-72) and 5 021 (doc/Benchmarks.md:88-95):
         # the same mix, producer and checks at 16 384, 4 096 and 256 chunks (persistent waves / two waves per chunk / a

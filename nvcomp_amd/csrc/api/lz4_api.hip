@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(64 * kDecWaves, NVCOMP_LZW_WAVES_PER_SIMD) lz4
 
 /* Small batches: two waves per chunk, a producer (chase + parse) and a consumer (execute), lz4w::pair. */
 template <bool CHECKED>
-__global__ void __launch_bounds__(128, 4) lz4_decompress_pair_kernel(const lzl::Batch b)
+__global__ void __launch_bounds__(128, 7) lz4_decompress_pair_kernel(const lzl::Batch b)
 {
   __shared__ __attribute__((aligned(16))) uint8_t lds[lz4w::pair::kLdsPerChunk];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
@@ -157,16 +157,24 @@ __global__ void __launch_bounds__(128, 4) lz4_decompress_pair_kernel(const lzl::
   }
   const bool too_long = in_len64 > 0xffffffffull - 64;
   const bool work = !too_long && in_len64 != 0;
+  /* A chunk that shrank 8 x or more is decoded by the second wave ALONE, with the one-wave loop that holds the run
+   * executor (lz4w::decode_chunk<., ., true>; the first wave leaves): sorted keys and typed columns are 4-5 x faster there
+   * than through producer and consumer (4 096 chunks of the sorted-key column: 840 GB/s here, 5 120 chunks in the
+   * persistent kernel: 3 850). That loop's registers cost this kernel its eighth wave per SIMD (common/lz_launch.hip.h:
+   * the mix does not mind). */
+  static_assert(lzw::kLdsPerWave <= lz4w::pair::kLdsPerChunk, "the lone wave's LDS is the pair's");
+  const bool solo = NVCOMP_LZW_RUNS && NVCOMP_LZ_PAIR_SOLO && work && in_len64 * kRunsRatio <= cap64;
   if (w == 0) {
-    if (work) {
+    if (work && !solo) {
       lz4w::pair::produce(in, (uint32_t)in_len64, lds);
     }
     return;
   }
   uint32_t err = too_long ? lz::kErrInput : lz::kErrNone;
   uint32_t produced = 0;
-  if (work) {
-    /* (one instance of the consumer: two cost this kernel its eighth wave per SIMD -- 102 scalar registers) */
+  if (solo) {
+    produced = lz4w::decode_chunk<CHECKED, 0, true>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err, nullptr);
+  } else if (work) {
     produced = lz4w::pair::consume<CHECKED, NVCOMP_LZ4_PAIR_RUNS != 0>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err);
   }
   if (wave::lane_id() == 0) {
@@ -209,11 +217,19 @@ __global__ void __launch_bounds__(64 * WAVES, 4) lz4_decompress_team_kernel(cons
       produced = lzt::decode_chunk<lz4w::TeamFrontEnd, WAVES>(
           in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err,
           [](uint32_t role, const uint8_t* i, uint32_t n, uint8_t* o, uint32_t cap, uint8_t* scratch, uint32_t& e) -> uint32_t {
+            /* chunks that shrank 8 x (here: mostly the 16 x ones of the team's own test): runs -- one wave with the loop that
+             * holds the run executor, as in the two-wave kernel */
+            const bool solo = NVCOMP_LZW_RUNS && NVCOMP_LZ_PAIR_SOLO && (size_t)n * kRunsRatio <= cap;
             if (role == 0) {
-              lz4w::pair::produce(i, n, scratch);
+              if (!solo) {
+                lz4w::pair::produce(i, n, scratch);
+              }
               return 0u;
             }
-            return lz4w::pair::consume<true, NVCOMP_LZW_RUNS != 0>(i, n, o, cap, scratch, e); /* chunks that shrank 16 x: runs */
+            if (solo) {
+              return lz4w::decode_chunk<true, 0, true>(i, n, o, cap, scratch, e, nullptr);
+            }
+            return lz4w::pair::consume<true, false>(i, n, o, cap, scratch, e);
           });
     }
     a = wave::kernel_args(launch);

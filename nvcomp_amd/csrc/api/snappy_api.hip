@@ -141,9 +141,15 @@ __global__ void __launch_bounds__(64 * WAVES, 4) snappy_decompress_team_kernel(c
       produced = lzt::decode_chunk<snappyw::TeamFrontEnd, WAVES>(
           in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err,
           [](uint32_t role, const uint8_t* i, uint32_t n, uint8_t* o, uint32_t cap, uint8_t* scratch, uint32_t& e) -> uint32_t {
+            const bool solo = NVCOMP_LZW_RUNS && NVCOMP_SNAPPY_RUNS && NVCOMP_LZ_PAIR_SOLO && (size_t)n * kRunsRatio <= cap;
             if (role == 0) {
-              snappyw::pair::produce<true>(i, n, scratch);
+              if (!solo) {
+                snappyw::pair::produce<true>(i, n, scratch);
+              }
               return 0u;
+            }
+            if (solo) {
+              return snappyw::decode_chunk<true, true>(i, n, o, cap, scratch, e); /* api/lz4_api.hip */
             }
             return snappyw::pair::consume<true>(i, n, o, cap, scratch, e);
           });
@@ -174,7 +180,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) snappy_decompress_team_kernel(c
 
 /* Small batches: two waves per chunk, a producer (chase + parse) and a consumer (execute), snappyw::pair. */
 template <bool CHECKED>
-__global__ void __launch_bounds__(128, 4) snappy_decompress_pair_kernel(const lzl::Batch b)
+__global__ void __launch_bounds__(128, 7) snappy_decompress_pair_kernel(const lzl::Batch b)
 {
   __shared__ __attribute__((aligned(16))) uint8_t lds[lzw::pair::kLdsPerChunk];
   const uint32_t w = wave::uniform(threadIdx.x >> 6);
@@ -194,15 +200,20 @@ __global__ void __launch_bounds__(128, 4) snappy_decompress_pair_kernel(const lz
     cap64 = kMaxOutCap;
   }
   const bool work = in_len64 != 0 && in_len64 <= 0xffffffffull - 64; /* an empty stream has no preamble: malformed */
+  /* a chunk that shrank 8 x or more: the second wave alone, with the one-wave loop that holds the run executor (api/lz4_api.hip) */
+  static_assert(lzw::kLdsPerWave <= lzw::pair::kLdsPerChunk, "the lone wave's LDS is the pair's");
+  const bool solo = NVCOMP_LZW_RUNS && NVCOMP_SNAPPY_RUNS && NVCOMP_LZ_PAIR_SOLO && work && in_len64 * kRunsRatio <= cap64;
   if (w == 0) {
-    if (work) {
+    if (work && !solo) {
       snappyw::pair::produce<CHECKED>(in, (uint32_t)in_len64, lds);
     }
     return;
   }
   uint32_t err = work ? lz::kErrNone : lz::kErrInput;
   uint32_t produced = 0;
-  if (work) {
+  if (solo) {
+    produced = snappyw::decode_chunk<CHECKED, true>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err);
+  } else if (work) {
     produced = snappyw::pair::consume<CHECKED>(in, (uint32_t)in_len64, out, (uint32_t)cap64, lds, err);
   }
   if (wave::lane_id() == 0) {

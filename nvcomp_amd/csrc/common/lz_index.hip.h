@@ -127,7 +127,7 @@ __device__ __forceinline__ void walk(
         o = go ? next_o : o;
       } while (go & (o < end_o));
       /* the lane stops for good at a token that nothing will size, at one that a block of its own did not, at a full list */
-      stop = !go & (!ok | (o == 0) | (cnt >= kLaneCap));
+      stop = (!go) & (!ok | (o == 0) | (cnt >= kLaneCap));
       p = bpos + o;
       active = !stop & (p < limit);
     }

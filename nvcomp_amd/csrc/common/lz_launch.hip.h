@@ -27,7 +27,13 @@
 
 #ifndef NVCOMP_LZ_PAIR_MAX_BATCH
 #define NVCOMP_LZ_PAIR_MAX_BATCH 4096 /* two waves per chunk up to here: 319 against 310 GB/s at 4 096 chunks since the pair kernels lost their scratch
-                                        * (round 4, profiles/r04_final_nsweep.jsonl; 3 072 before); 412 against 454 at 8 192 */
+                                        * (round 4, profiles/r04_final_nsweep.jsonl; 3 072 before); 412 against 454 at 8 192. Round 6: the kernels hold
+                                        * the one-wave loop with the run executor for the chunks that shrank 8 x (NVCOMP_LZ_PAIR_SOLO), whose
+                                        * registers cost them the eighth wave per SIMD -- 7 168 resident waves for 8 192 at 4 096 chunks -- and the
+                                        * mix at 4 096 chunks is FASTER so: 328 against 317 GB/s (and 301 in the persistent kernel; gpurun r6ak) */
+#endif
+#ifndef NVCOMP_LZ_PAIR_SOLO
+#define NVCOMP_LZ_PAIR_SOLO 1 /* A/B: 0 = every chunk of the two-wave kernels by producer and consumer */
 #endif
 #ifndef NVCOMP_LZ_TEAM_MAX_BATCH
 #define NVCOMP_LZ_TEAM_MAX_BATCH 512 /* a WORKGROUP per chunk up to this many chunks (common/lz_team.hip.h): 263 us per chunk against 467 (two waves) and 677 (one); from 1 024 chunks on two waves per chunk keep more chunks in flight (profiles/r04_team.jsonl) */

@@ -50,6 +50,12 @@ CASES = {
     "mix320m": ("LZ4", "silesia_style", "hc", 64, 320),
     "mortgage": ("LZ4", "mortgage_col0_like", "fast", 64, 1024),
     "mortgage5k": ("LZ4", "mortgage_col0_like", "fast", 64, 314),
+    "mortgage2k": ("LZ4", "mortgage_col0_like", "hc", 32, 128),
+    "mortgage1k": ("LZ4", "mortgage_col0_like", "hc", 32, 64),
+    "mortgage3584": ("LZ4", "mortgage_col0_like", "hc", 32, 224),
+    "int32_2k": ("LZ4", "int32", "fast", 32, 128),
+    "snappy_int32_2k": ("Snappy", "int32", "snappy", 32, 128),
+    "mix224m": ("LZ4", "silesia_style", "hc", 32, 224),
     "mortgage5120": ("LZ4", "mortgage_col0_like", "fast", 32, 320),  # 5 120 chunks: the reference's published run has 5 021 (doc/Benchmarks.md:88-95)
     "mortgage5120_hc": ("LZ4", "mortgage_col0_like", "hc", 32, 320),
     "mortgage_hc": ("LZ4", "mortgage_col0_like", "hc", 64, 1024),

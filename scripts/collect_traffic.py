@@ -23,6 +23,7 @@ KERNELS = {
     "lz4_mortgage": [("lz4_decompress_window_kernel", "lz4", "decompress")],
     "lz4_mortgage_default": [("lz4_decompress_window_kernel", "lz4", "decompress")],
     "lz4_int32": [("lz4_decompress_window_kernel", "lz4", "decompress")],
+    "lz4_mortgage_5120": [("lz4_decompress_window_kernel", "lz4", "decompress")],
     # the batch-size riders of the driver's line
     "lz4_16384": [("lz4_decompress_window_kernel", "lz4", "decompress")],
     "lz4_4096": [("lz4_decompress_pair_kernel", "lz4", "decompress")],

@@ -28,6 +28,7 @@ run bitcomp --algo bitcomp --dataset float_columns --mib-per-gpu 1024 --unique-m
 run lz4_mortgage --no-extras --dataset mortgage_col0_like --mib-per-gpu 1024 --unique-mib 64
 run lz4_mortgage_default --no-extras --dataset mortgage_col0_like --producer fast --mib-per-gpu 1024 --unique-mib 64
 run lz4_int32 --no-extras --dataset int32 --producer fast --mib-per-gpu 1024 --unique-mib 32
+run lz4_mortgage_5120 --no-extras --dataset mortgage_col0_like --mib-per-gpu 320 --unique-mib 32
 run lz4_16384 --no-extras --mib-per-gpu 1024
 run lz4_4096 --no-extras --mib-per-gpu 256
 run lz4_256 --no-extras --mib-per-gpu 16 --unique-mib 16
