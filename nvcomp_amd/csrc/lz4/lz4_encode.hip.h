@@ -16,6 +16,7 @@
 
 #include "common/lz_match.hip.h"
 #include "common/lz_match_wide.hip.h"
+#include "common/lz_match_runs.hip.h"
 
 namespace lz4 {
 
@@ -133,6 +134,11 @@ __device__ __forceinline__ uint32_t encode_chunk_wide(
     const uint8_t* __restrict__ src, uint32_t n, uint8_t* dst, uint16_t* table, uint8_t* image, uint8_t* scratch)
 {
   const bool any = n > kMfLimit;
+  /* runs (sorted keys, typed columns, zeros) first: common/lz_match_runs.hip.h */
+  const uint32_t as_runs = lzm::runs::encode_chunk<Emitter>(src, n, dst, any ? n - kMfLimit : 0, any ? n - kLastLiterals : 0, any);
+  if (as_runs != lzm::runs::kNotRuns) {
+    return as_runs;
+  }
   return lzm::wide::encode_chunk<Emitter>(
       src, n, dst, table, image, scratch, any ? n - kMfLimit : 0, any ? n - kLastLiterals : 0, any);
 }

@@ -12,6 +12,7 @@
 
 #include "common/lz_match.hip.h"
 #include "common/lz_match_wide.hip.h"
+#include "common/lz_match_runs.hip.h"
 
 namespace snappy {
 
@@ -196,6 +197,11 @@ __device__ __forceinline__ uint32_t encode_chunk_wide(
   /* the wide probe's word check reads 12 bytes at a time (lz_match_wide.hip.h probe_step: a lane without a candidate reads
    * the chunk's first twelve): a chunk of 8 .. 11 bytes is written as literals, never probed */
   const bool any = n >= 12;
+  /* runs (sorted keys, typed columns, zeros) first: common/lz_match_runs.hip.h */
+  const uint32_t as_runs = lzm::runs::encode_chunk<Emitter>(src, n, dst + hdr, any ? n - 4 : 0, n, any);
+  if (as_runs != lzm::runs::kNotRuns) {
+    return hdr + as_runs;
+  }
   return hdr + lzm::wide::encode_chunk<Emitter>(src, n, dst + hdr, table, image, scratch, any ? n - 4 : 0, n, any);
 }
 

@@ -15,7 +15,9 @@ sys.path.insert(0, REPO)
 CHUNK = 1 << 16
 CASES = {"mix": ("LZ4", "silesia_style", 64, 4096), "snappy_mix": ("Snappy", "silesia_style", 64, 4096),
          "mix1g": ("LZ4", "silesia_style", 64, 1024), "int32": ("LZ4", "int32", 32, 1024), "text": ("LZ4", "text", 32, 1024),
-         "mortgage": ("LZ4", "mortgage_col0_like", 64, 1024), "noise": ("LZ4", "noise", 16, 1024)}
+         "mortgage": ("LZ4", "mortgage_col0_like", 64, 1024), "noise": ("LZ4", "noise", 16, 1024),
+         "zeros": ("LZ4", "zeros", 16, 1024), "snappy_int32": ("Snappy", "int32", 32, 1024),
+         "snappy_mortgage": ("Snappy", "mortgage_col0_like", 64, 1024)}
 
 
 def main():

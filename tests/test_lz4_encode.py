@@ -153,6 +153,69 @@ def test_compress_fuzz_structured(backend, oracle, fmt):
 
 
 @pytest.mark.parametrize("fmt", ["LZ4", "Snappy"])
+def test_compress_runs(backend, oracle, fmt):
+    """Chunks that are their own copy from 1, 2, 4 or 8 bytes back -- sorted keys, typed columns, zeros -- take the run
+    compressor (common/lz_match_runs.hip.h: 1 KiB a step, only the mismatches cost work): every period, sizes around its 4 KiB
+    floor and around the 1 KiB steps and 16-byte lanes, changes at every position of a step and right at the chunk's end
+    (the formats' end-of-block rules), stretches of one to three equal bytes (literals, not matches), dense changes, a first
+    KiB of runs in front of noise or text (given up: the match finder starts over), unaligned chunk starts. Every stream
+    decodes with the CPU library to the original; the columns keep the ratio the match finder had on them."""
+    rng = np.random.RandomState(4321)
+    text = datasets.text(1 << 16, 9)
+    chunks = []
+    sizes = [4095, 4096, 4097, 4111, 4112, 5119, 5120, 5121, 6000, 8191, 8192, 20000, 65535, 65536]
+    for period in (1, 2, 4, 8):
+        for n in (sizes if backend.name == "gpu" else sizes[1::3] + [4096, 65536]):
+            # values that change every now and then, in their low bytes
+            nvals = n // period + 2
+            runs = rng.randint(1, 120, size=nvals)
+            vals = np.cumsum(rng.randint(1, 300, size=nvals)).astype(np.uint64) + np.uint64(0x0102030405060708)
+            col = np.repeat(vals, runs)[: n // period + 1]
+            c = col.astype({1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[period]).view(np.uint8)[:n].copy()
+            chunks.append(c)
+    n = 65536
+    base = np.repeat((np.arange(n // 8 + 1) // 50).astype(np.uint64) + np.uint64(10 ** 11), 1).view(np.uint8)[:n].copy()
+    for k in range(12 if backend.name == "gpu" else 5):
+        c = base.copy()
+        kind = k % 6
+        if kind == 0:  # single changed bytes at every position class of a step
+            for p in rng.randint(16, n, size=200):
+                c[p] ^= 0x5a
+        elif kind == 1:  # changes right at the end of the chunk
+            for p in (n - 1, n - 4, n - 5, n - 6, n - 12, n - 13, n - 17):
+                c[p] ^= 0x33
+        elif kind == 2:  # stretches of one to three equal bytes between changes
+            for p in range(3000, 3400, 1 + k % 4 + 1):
+                c[p] ^= 0x11
+        elif kind == 3:  # the first KiB says runs, the rest is noise
+            c[2048:] = rng.randint(0, 256, size=n - 2048)
+        elif kind == 4:  # ... or text
+            c[1500:] = text[: n - 1500]
+        else:  # dense changes everywhere behind the first KiB
+            idx = np.arange(1100, n, 5)
+            c[idx] ^= 0x77
+        chunks.append(c)
+    chunks.append(np.zeros(65536, np.uint8))
+    chunks.append(np.full(4096, 7, np.uint8))
+    codec = backend.codec(fmt)
+    for in_align in (16, 1):
+        comp = codec.compress(chunks, in_align=in_align)
+        for i, (cc, c) in enumerate(zip(comp, chunks)):
+            if fmt == "LZ4":
+                rc, out = (oracle.ref_lz4_decompress if oracle.have_ref() else oracle.lz4_decompress)(cc, c.size)
+            else:
+                rc, out = (oracle.ref_snappy_decompress if oracle.have_ref() else oracle.snappy_decompress)(cc, c.size)
+            assert rc == 0 and np.array_equal(out, c), f"chunk {i} ({c.size} bytes)"
+        assert all(cc.size <= codec.max_compressed_size(max(c.size, 1)) for cc, c in zip(comp, chunks))
+    # the columns: what the match finder made of them in round 5 (LZ4: sorted keys 56.7, int32 37.5)
+    for gen, floor in ((datasets.mortgage_col0_like, 50.0 if fmt == "LZ4" else 15.0), (datasets.int32_column, 33.0 if fmt == "LZ4" else 13.0)):
+        cs = datasets.split_chunks(gen(2 * 65536, 3))
+        comp = codec.compress(cs)
+        ratio = sum(c.size for c in cs) / sum(cc.size for cc in comp)
+        assert ratio >= floor, (gen.__name__, ratio)
+
+
+@pytest.mark.parametrize("fmt", ["LZ4", "Snappy"])
 def test_compress_after_a_quiet_stretch(backend, oracle, fmt):
     """Steps without a single hit switch the match finder to every fourth position (NVCOMP_LZMW_QUIET_STEPS,
     common/lz_match_wide.hip.h). What follows such a stretch must still be found: a repeat of an earlier kilobyte of the

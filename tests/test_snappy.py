@@ -434,3 +434,44 @@ def test_compress_small_chunk_at_the_end_of_a_mapping(emu, oracle, fmt):
         dec = oracle.ref_snappy_decompress if fmt == "Snappy" else oracle.ref_lz4_decompress
         code, back = dec(out[: int(out_sizes[0])], n)
         assert code == 0 and np.array_equal(back, raw), (fmt, n)
+
+
+@pytest.mark.parametrize("fmt", ["Snappy", "LZ4"])
+def test_compress_runs_at_the_end_of_a_mapping(emu, oracle, fmt):
+    """The same for the run compressor (common/lz_match_runs.hip.h: 16-byte lane loads of the chunk and of the bytes in front of
+    it): chunks of runs whose last byte is the last one in front of a PROT_NONE page, sizes around the 1 KiB steps and the
+    16-byte lanes."""
+    import ctypes as C
+    import mmap
+
+    libc = C.CDLL(None, use_errno=True)
+    libc.mmap.restype = C.c_void_p
+    libc.mmap.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_long]
+    libc.mprotect.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    page = mmap.PAGESIZE
+    span = 20 * page
+    base = libc.mmap(None, span + page, mmap.PROT_READ | mmap.PROT_WRITE, mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS, -1, 0)
+    assert base not in (None, C.c_void_p(-1).value)
+    assert libc.mprotect(base + span, page, 0) == 0  # PROT_NONE behind the chunk
+    codec = emu.codec(fmt)
+    lib = emu.lib
+    for n in (4096, 4097, 4111, 4112, 4113, 5119, 5120, 5121, 8191, 65535, 65536):
+        raw = np.repeat((np.arange(n // 8 + 1) // 37).astype(np.uint64) + np.uint64(10 ** 11), 1).view(np.uint8)[:n].copy()
+        C.memmove(base + span - n, raw.ctypes.data, n)
+        in_ptrs = np.array([base + span - n], dtype=np.uint64)
+        in_sizes = np.array([n], dtype=np.uint64)
+        max_out = codec.max_compressed_size(65536)
+        out = np.zeros(max_out, dtype=np.uint8)
+        out_ptrs = np.array([out.ctypes.data], dtype=np.uint64)
+        out_sizes = np.zeros(1, dtype=np.uint64)
+        tb = codec.compress_temp_size(1, 65536)
+        temp = np.zeros(max(tb, 1), dtype=np.uint8)
+        fn = getattr(lib, f"nvcompBatched{fmt}CompressAsync")
+        rc = fn(in_ptrs.ctypes.data, in_sizes.ctypes.data, 65536, 1, temp.ctypes.data, tb, out_ptrs.ctypes.data,
+                out_sizes.ctypes.data, codec.opts, None)
+        assert rc == 0
+        dec = oracle.ref_snappy_decompress if fmt == "Snappy" else oracle.ref_lz4_decompress
+        code, back = dec(out[: int(out_sizes[0])], n)
+        assert code == 0 and np.array_equal(back, raw), (fmt, n)
+        assert int(out_sizes[0]) * 8 < n, "the run compressor's ratio"
+
