@@ -124,6 +124,11 @@ __device__ __forceinline__ uint32_t encode_chunk(
     const uint8_t* __restrict__ src, uint32_t n, uint8_t* dst, uint16_t* table, uint8_t* image)
 {
   const bool any = n > kMfLimit;
+  /* runs first (common/lz_match_runs.hip.h): typed columns are what the data_type option is for */
+  const uint32_t as_runs = lzm::runs::encode_chunk<Emitter>(src, n, dst, any ? n - kMfLimit : 0, any ? n - kLastLiterals : 0, any);
+  if (as_runs != lzm::runs::kNotRuns) {
+    return as_runs;
+  }
   return lzm::encode_chunk<Emitter, STRIDE>(
       src, n, dst, table, image, any ? n - kMfLimit : 0, any ? n - kLastLiterals : 0, any);
 }
