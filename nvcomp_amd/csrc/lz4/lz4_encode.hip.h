@@ -109,6 +109,35 @@ struct Emitter
   {
     return emit_sequence(dst, lit, lit_len, offset, match_len);
   }
+  /* the same written by ONE lane (common/lz_match_runs.hip.h: 64 sequences at a time, literal runs of at most 64 bytes);
+   * seq_size() bytes */
+  static __device__ __forceinline__ void emit_lane(uint8_t* dst, const uint8_t* lit, uint32_t lit_len, uint32_t offset, uint32_t match_len)
+  {
+    const uint32_t ml = match_len - kMinMatch;
+    dst[0] = (uint8_t)(((lit_len < 15 ? lit_len : 15u) << 4) | (ml < 15 ? ml : 15u));
+    uint32_t pos = 1;
+    if (lit_len >= 15) {
+      uint32_t v = lit_len - 15;
+      for (; v >= 255; v -= 255) {
+        dst[pos++] = 255;
+      }
+      dst[pos++] = (uint8_t)v;
+    }
+    for (uint32_t i = 0; i < lit_len; ++i) {
+      dst[pos + i] = lit[i];
+    }
+    pos += lit_len;
+    dst[pos] = (uint8_t)(offset & 255u);
+    dst[pos + 1] = (uint8_t)(offset >> 8);
+    pos += 2;
+    if (ml >= 15) {
+      uint32_t v = ml - 15;
+      for (; v >= 255; v -= 255) {
+        dst[pos++] = 255;
+      }
+      dst[pos++] = (uint8_t)v;
+    }
+  }
   static __device__ __forceinline__ uint32_t tail(uint8_t* dst, const uint8_t* lit, uint32_t lit_len)
   {
     return emit_sequence(dst, lit, lit_len, 0, 0);
@@ -125,7 +154,8 @@ __device__ __forceinline__ uint32_t encode_chunk(
 {
   const bool any = n > kMfLimit;
   /* runs first (common/lz_match_runs.hip.h): typed columns are what the data_type option is for */
-  const uint32_t as_runs = lzm::runs::encode_chunk<Emitter>(src, n, dst, any ? n - kMfLimit : 0, any ? n - kLastLiterals : 0, any);
+  static_assert(lzm::kTableU16 * 2 >= lzm::runs::kListBytes, "the run compressor's list lives in the hash table's LDS");
+  const uint32_t as_runs = lzm::runs::encode_chunk<Emitter>(src, n, dst, (uint32_t*)table, any ? n - kMfLimit : 0, any ? n - kLastLiterals : 0, any);
   if (as_runs != lzm::runs::kNotRuns) {
     return as_runs;
   }
@@ -140,7 +170,8 @@ __device__ __forceinline__ uint32_t encode_chunk_wide(
 {
   const bool any = n > kMfLimit;
   /* runs (sorted keys, typed columns, zeros) first: common/lz_match_runs.hip.h */
-  const uint32_t as_runs = lzm::runs::encode_chunk<Emitter>(src, n, dst, any ? n - kMfLimit : 0, any ? n - kLastLiterals : 0, any);
+  static_assert(lzm::wide::kEntries * 2 >= lzm::runs::kListBytes, "the run compressor's list lives in the hash table's LDS");
+  const uint32_t as_runs = lzm::runs::encode_chunk<Emitter>(src, n, dst, (uint32_t*)table, any ? n - kMfLimit : 0, any ? n - kLastLiterals : 0, any);
   if (as_runs != lzm::runs::kNotRuns) {
     return as_runs;
   }

@@ -159,6 +159,50 @@ struct Emitter
   {
     return emit_literal(dst, lit, lit_len);
   }
+  /* match() written by ONE lane (common/lz_match_runs.hip.h: 64 sequences at a time, literal runs of at most 64 bytes);
+   * seq_size() bytes: the same pieces as emit_copy */
+  static __device__ __forceinline__ void emit_lane(uint8_t* dst, const uint8_t* lit, uint32_t lit_len, uint32_t offset, uint32_t match_len)
+  {
+    uint32_t pos = 0;
+    if (lit_len != 0) {
+      const uint32_t n = lit_len - 1;
+      if (n < 60) {
+        dst[pos++] = (uint8_t)(n << 2);
+      } else {
+        dst[pos++] = (uint8_t)(60u << 2);
+        dst[pos++] = (uint8_t)n;
+      }
+      for (uint32_t i = 0; i < lit_len; ++i) {
+        dst[pos + i] = lit[i];
+      }
+      pos += lit_len;
+    }
+    uint32_t len = match_len;
+    while (len >= 68) {
+      dst[pos] = (uint8_t)(2u | (63u << 2));
+      dst[pos + 1] = (uint8_t)(offset & 255u);
+      dst[pos + 2] = (uint8_t)(offset >> 8);
+      pos += 3;
+      len -= 64;
+    }
+    for (;;) {
+      const uint32_t piece = len > 64 ? 60u : len;
+      if (piece >= 4 && piece < 12 && offset < 2048) {
+        dst[pos] = (uint8_t)(1u | ((piece - 4) << 2) | ((offset >> 8) << 5));
+        dst[pos + 1] = (uint8_t)(offset & 255u);
+        pos += 2;
+      } else {
+        dst[pos] = (uint8_t)(2u | ((piece - 1) << 2));
+        dst[pos + 1] = (uint8_t)(offset & 255u);
+        dst[pos + 2] = (uint8_t)(offset >> 8);
+        pos += 3;
+      }
+      len -= piece;
+      if (len == 0) {
+        break;
+      }
+    }
+  }
 };
 
 /* preamble: varint32 of n. Returns its length. */
@@ -198,7 +242,8 @@ __device__ __forceinline__ uint32_t encode_chunk_wide(
    * the chunk's first twelve): a chunk of 8 .. 11 bytes is written as literals, never probed */
   const bool any = n >= 12;
   /* runs (sorted keys, typed columns, zeros) first: common/lz_match_runs.hip.h */
-  const uint32_t as_runs = lzm::runs::encode_chunk<Emitter>(src, n, dst + hdr, any ? n - 4 : 0, n, any);
+  static_assert(lzm::wide::kEntries * 2 >= lzm::runs::kListBytes, "the run compressor's list lives in the hash table's LDS");
+  const uint32_t as_runs = lzm::runs::encode_chunk<Emitter>(src, n, dst + hdr, (uint32_t*)table, any ? n - 4 : 0, n, any);
   if (as_runs != lzm::runs::kNotRuns) {
     return hdr + as_runs;
   }
