@@ -65,6 +65,22 @@ __device__ __forceinline__ uint32_t emit_sequence(
   return pos;
 }
 
+/* The same as a function of its own, for the match finder's rare whole-wave emissions (a sequence no single lane can write):
+ * inlined into its loop these cost the kernel 10-12 spilled registers; the chunk's tail (one call, and for incompressible
+ * data the whole chunk: through a call its copies lose their address space, -6 %) stays inlined. */
+#ifndef NVCOMP_LZ4_EMIT_NOINLINE
+#define NVCOMP_LZ4_EMIT_NOINLINE 1
+#endif
+#if NVCOMP_LZ4_EMIT_NOINLINE
+__device__ __attribute__((noinline)) uint32_t emit_sequence_call(
+#else
+__device__ __forceinline__ uint32_t emit_sequence_call(
+#endif
+    uint8_t* dst, const uint8_t* lit, uint32_t lit_len, uint32_t offset, uint32_t match_len)
+{
+  return emit_sequence(dst, lit, lit_len, offset, match_len);
+}
+
 struct Emitter
 {
   static constexpr bool kStream = false;   /* sequences start at byte boundaries: lzm writes them where they go */
@@ -107,7 +123,7 @@ struct Emitter
   static __device__ __forceinline__ uint32_t match(
       uint8_t* dst, const uint8_t* lit, uint32_t lit_len, uint32_t offset, uint32_t match_len)
   {
-    return emit_sequence(dst, lit, lit_len, offset, match_len);
+    return emit_sequence_call(dst, lit, lit_len, offset, match_len);
   }
   /* the same written by ONE lane (common/lz_match_runs.hip.h: 64 sequences at a time, literal runs of at most 64 bytes);
    * seq_size() bytes */
