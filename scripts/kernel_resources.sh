@@ -5,7 +5,8 @@ cd "$(dirname "$0")/.."
 FLAGS=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do FLAGS+=("$1"); shift; done; [ "${1:-}" = "--" ] && shift
 FILES=${*:-lz4_api snappy_api deflate_api}
 for f in $FILES; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Invcomp_amd/csrc -Wno-unused-function "${FLAGS[@]}" \
+  SCHED=(); case $f in lz4_api|snappy_api) SCHED=(-mllvm -amdgpu-sched-strategy=max-ilp);; esac # as nvcomp_amd/csrc/Makefile (LZ_SCHED)
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Invcomp_amd/csrc -Wno-unused-function "${SCHED[@]}" "${FLAGS[@]}" \
     -Rpass-analysis=kernel-resource-usage -c nvcomp_amd/csrc/api/$f.hip -o /dev/null 2>&1 |
     python3 -c "
 import re, sys
