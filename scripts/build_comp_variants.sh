@@ -11,7 +11,7 @@ REST=$(ls $OBJ/api/*.o $OBJ/hlif/*.o | grep -v "api/lz4_api.o\|api/snappy_api.o"
 build() { # tag, flags...
   local tag=$1; shift
   for f in lz4_api snappy_api; do
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Invcomp_amd/csrc -Wno-unused-function -mllvm -amdgpu-sched-strategy=max-ilp "$@" \
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Invcomp_amd/csrc -Wno-unused-function ${LZ_SCHED--mllvm -amdgpu-sched-strategy=max-ilp} "$@" \
       -c nvcomp_amd/csrc/api/$f.hip -o /tmp/cvariants/${tag}_$f.o 2>/tmp/cvariants/${tag}_$f.log &
   done
   wait
