@@ -427,13 +427,30 @@ __device__ __forceinline__ uint8_t* out_at(const OutWindow& w, uint32_t pos)
   return w.win + (pos - w.wbase + w.align);
 }
 
-/* Slide the window so that at least kBatchMax bytes fit after position op. */
-__device__ __forceinline__ void out_make_room(OutWindow& w, uint32_t op)
+/* Slide the window so that the batch's `need` bytes (at most kBatchMax) fit after position op. (Until round 6 it made room for
+ * kBatchMax whatever the batch produced, i.e. slid in front of every batch: a batch of text is ~700 bytes, the slide two
+ * syncs and a copy -- NVCOMP_LZW_ROOM_EXACT = 0 is that behaviour. What stays behind without a slide is history: a match into
+ * it is an LDS copy instead of a load from memory.) */
+#ifndef NVCOMP_LZW_KEEP_MAX
+#define NVCOMP_LZW_KEEP_MAX 0 /* A/B: history kept by a slide when the batch is small (0: kKeep always) */
+#endif
+#ifndef NVCOMP_LZW_ROOM_EXACT
+#define NVCOMP_LZW_ROOM_EXACT 1
+#endif
+__device__ __forceinline__ void out_make_room(OutWindow& w, uint32_t op, uint32_t need)
 {
-  if (op - w.wbase + w.align + kBatchMax <= kOutWin) {
+  if (op - w.wbase + w.align + (NVCOMP_LZW_ROOM_EXACT ? need : kBatchMax) <= kOutWin) {
     return;
   }
-  uint32_t keep_from = op > kKeep ? op - kKeep : 0;
+  /* history kept: kKeep bytes, or -- NVCOMP_LZW_KEEP_MAX -- as much as the batch leaves room for, up to that many (one
+   * pass of the copy loop below moves up to 1 KiB: more history costs no more instructions) */
+  uint32_t keep = kKeep;
+  if (NVCOMP_LZW_KEEP_MAX > NVCOMP_LZW_KEEP) {
+    const uint32_t fits = kOutWin - 32u - need; /* need <= kBatchMax: at least kKeep + 32 */
+    keep = fits < (uint32_t)NVCOMP_LZW_KEEP_MAX ? fits : (uint32_t)NVCOMP_LZW_KEEP_MAX;
+    keep = keep > kKeep ? keep : kKeep;
+  }
+  uint32_t keep_from = op > keep ? op - keep : 0;
   if (keep_from > w.flushed) {
     keep_from = w.flushed; /* the tail that waits for its 16-byte block to fill up always stays (kKeep < 16: no history at all) */
   }
@@ -1638,7 +1655,7 @@ __device__ __forceinline__ uint32_t execute_window_batch(
   LZ_STAT("seqs", take);
   LZ_STAT("bytes", total);
   LZW_T(4);
-  out_make_room(ow, op);
+  out_make_room(ow, op, total);
   LZW_T(5);
 
   /* ---- far matches: sources the window no longer holds, read from HBM ---- */
