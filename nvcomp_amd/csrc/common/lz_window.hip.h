@@ -431,6 +431,10 @@ __device__ __forceinline__ uint8_t* out_at(const OutWindow& w, uint32_t pos)
  * kBatchMax whatever the batch produced, i.e. slid in front of every batch: a batch of text is ~700 bytes, the slide two
  * syncs and a copy -- NVCOMP_LZW_ROOM_EXACT = 0 is that behaviour. What stays behind without a slide is history: a match into
  * it is an LDS copy instead of a load from memory.) */
+#ifndef NVCOMP_LZW_LAZY_FLUSH
+#define NVCOMP_LZW_LAZY_FLUSH 0 /* A/B: 1 = a batch's blocks are written to HBM when the window slides, not at its end. Measured (gpurun r6ay): LZ4 mix
+                                 * 683 -> 686, Snappy mix 501 -> 484, float32 column 412 -> 400: off */
+#endif
 #ifndef NVCOMP_LZW_KEEP_MAX
 #define NVCOMP_LZW_KEEP_MAX 0 /* A/B: history kept by a slide when the batch is small (0: kKeep always) */
 #endif
@@ -1612,7 +1616,11 @@ struct NoHook
 
 /* `after_far`: called once per batch behind the point where the far matches' loads have been waited for (the decoders
  * with a token index settle their prefetched positions there: common/lz_index.hip.h). */
-template <bool CHECKED, bool RING_LITERALS = false, class AfterFar = NoHook>
+/* LAZY_FLUSH: the batch's whole blocks are not written to HBM at its end but when the window has to slide (and at the
+ * chunk's end, and in front of a streamed sequence: out_flush_all) -- every third or fourth batch of text, 2 KiB at a time.
+ * Nothing needs them earlier: a match into bytes the window still holds is copied in LDS, and a far match reads below
+ * `flushed`. (The run executor wants the window's tail block to be the only unflushed one: its loops stay eager.) */
+template <bool CHECKED, bool RING_LITERALS = false, class AfterFar = NoHook, bool LAZY_FLUSH = false>
 __device__ __forceinline__ uint32_t execute_window_batch(
     InRing& ir, OutWindow& ow, uint32_t out_cap, uint32_t& op, uint32_t n, const lz::Seq& s, uint32_t& err, bool& big,
     AfterFar after_far = AfterFar())
@@ -1655,6 +1663,10 @@ __device__ __forceinline__ uint32_t execute_window_batch(
   LZ_STAT("seqs", take);
   LZ_STAT("bytes", total);
   LZW_T(4);
+  if (LAZY_FLUSH && op - ow.wbase + ow.align + total > kOutWin) {
+    out_flush(ow, op); /* the window slides: what it lets go of must be in HBM */
+    wave::sync();
+  }
   out_make_room(ow, op, total);
   LZW_T(5);
 
@@ -1833,7 +1845,9 @@ __device__ __forceinline__ uint32_t execute_window_batch(
   }
 
   LZW_T(8);
-  out_flush(ow, op + total);
+  if (!LAZY_FLUSH) {
+    out_flush(ow, op + total);
+  }
   LZW_T(9);
   wave::sync(); /* later far reads of this wave must see the flushed bytes */
   op += total;

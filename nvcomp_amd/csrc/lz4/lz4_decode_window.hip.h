@@ -495,7 +495,8 @@ __device__ __forceinline__ uint32_t decode_chunk(
       gate = wave::uniform(lzw::run_gate_tried(gate, take, misfit));
     }
     if (take == 0) {
-      take = lzw::execute_window_batch<CHECKED, false>(ir, ow, out_cap, op, count, s, err, big, [&ix]() { lzx::settle(ix); });
+      auto settle = [&ix]() { lzx::settle(ix); };
+      take = lzw::execute_window_batch<CHECKED, false, decltype(settle), NVCOMP_LZW_LAZY_FLUSH && !RUNS>(ir, ow, out_cap, op, count, s, err, big, settle);
       if (CHECKED && err) {
         return 0;
       }

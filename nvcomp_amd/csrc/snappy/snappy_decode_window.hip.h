@@ -493,7 +493,7 @@ __device__ __forceinline__ uint32_t decode_chunk(
       gate = wave::uniform(lzw::run_gate_tried(gate, take, misfit));
     }
     if (take == 0) {
-      take = lzw::execute_window_batch<CHECKED>(ir, ow, limit, op, count, s, err, big);
+      take = lzw::execute_window_batch<CHECKED, false, lzw::NoHook, NVCOMP_LZW_LAZY_FLUSH && !RUNS>(ir, ow, limit, op, count, s, err, big);
       if (CHECKED && err) {
         return 0;
       }
