@@ -17,8 +17,16 @@
 namespace {
 
 constexpr uint32_t kHeaderBytes = 20;
-/* Decode runs three passes with growing LDS per wave; a sub-chunk's need follows from its actual stream counts
- * (casc::decompress_sub), so compressible data is decoded by the first pass at full occupancy. */
+/* Decode runs up to three passes with growing LDS per wave; a sub-chunk's need follows from its actual stream counts
+ * (casc::decompress_sub), so compressible data is decoded by the first pass at full occupancy. The launches of a call
+ * (round 6; nvcompBatchedCascadedDecompressAsync):
+ *   up to 512 chunks      ONE: a workgroup per chunk at 16 KiB a wave, the last pass folded in (decode_one_chunk: fold)
+ *   up to 4 096 chunks    two: a workgroup per chunk at 5 KiB a wave, then the chunks it flagged, folded as above
+ *   beyond                three: a wave per chunk at 5 KiB, 16 KiB, 64 KiB
+ * and every launch behind the first is as many workgroups as the card holds, looping over the flagged chunks -- not a grid
+ * over the batch whose workgroups read a flag and leave. Float columns, old -> new on one box, alternating
+ * (profiles/r06_ab_cascaded_launches.jsonl): 256 chunks 417 -> 464 GB/s, 1 024 chunks 1 240 -> 1 321, 4 096 chunks
+ * 1 652 -> 1 706, 16 384 chunks 2 094 -> 2 149, 65 536 chunks 2 472 -> 2 496. */
 /* The first pass of each direction: 4 waves per workgroup, its own LDS slice per wave and register budget (workgroups
  * per CU in __launch_bounds__). Swept on hardware in round 3 (profiles/archive/r03_cascaded_passes.jsonl, 1 GiB, compress /
  * decompress GB/s):
@@ -50,6 +58,11 @@ constexpr uint32_t kMidBudget = 8 * 1024 + 512;   /* compress: a worst case up t
 constexpr uint32_t kFastBudget = 16 * 1024;       /* decode pass 1: 4 waves per workgroup (two value buffers + pools + marks: sub-chunks with
                                                      long runs; short-run ones expand in place inside pass 0, casc::rle_expand_inplace) */
 constexpr uint32_t kBigBudget = 64 * 1024;        /* last pass: one wave per workgroup; also the compressor's limit */
+#ifndef NVCOMP_CASC_CUS
+#define NVCOMP_CASC_CUS 256 /* the passes behind the first are launched with the workgroups the card HOLDS (tests/emu models a card of four) */
+#endif
+constexpr size_t kCus = NVCOMP_CASC_CUS;
+constexpr size_t kLdsPerCu = 160 * 1024;
 
 void clear_stale_error()
 {
@@ -71,28 +84,21 @@ bool opts_ok(const nvcompBatchedCascadedOpts_t& o)
          && o.chunk_size >= 256 && o.chunk_size <= 16384 && o.chunk_size % w == 0;
 }
 
-__global__ void __launch_bounds__(256, NVCOMP_CASC_COMP_WGS) cascaded_compress_kernel(
+/* One chunk, by the calling wave. */
+__device__ __forceinline__ void compress_one_chunk(
+    size_t chunk,
+    uint32_t wv,
+    uint8_t* lds,
     const void* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
-    size_t batch_size,
     void* const* __restrict__ out_ptrs,
     size_t* out_bytes,
-    casc::Params p,
+    const casc::Params& p,
     uint32_t* todo,
     uint32_t pass,
     uint32_t last_pass,
-    uint32_t lds_per_wave,
-    uint32_t waves_per_block)
+    uint32_t lds_per_wave)
 {
-  WAVE_DYNAMIC_LDS(lds);
-  const uint32_t wv = wave::uniform(threadIdx.x >> 6);
-  const size_t chunk = (size_t)blockIdx.x * waves_per_block + wv;
-  if (chunk >= batch_size) {
-    return;
-  }
-  if (pass != 0 && wave::uniform(todo[chunk]) != pass) {
-    return;
-  }
   const uint8_t* src = wave::uniform_ptr((const uint8_t*)in_ptrs[chunk]);
   uint8_t* dst = wave::uniform_ptr((uint8_t*)out_ptrs[chunk]);
   const uint32_t n_bytes = (uint32_t)wave::uniform64(in_bytes[chunk]);
@@ -156,6 +162,45 @@ __global__ void __launch_bounds__(256, NVCOMP_CASC_COMP_WGS) cascaded_compress_k
   }
 }
 
+/* `later` = false: the grid covers the batch, a chunk per wave (pass 0, and the one launch of a call without flag words).
+ * `later` = true, the passes behind it: as many workgroups as the card holds at their LDS size, wave g of G takes the chunks
+ * g, g + G, ... whose todo word names the pass -- the scheme of cascaded_decompress_kernel below, for the same reason: on
+ * the bench's columns the passes behind the first find nothing to do. */
+template <bool later>
+__global__ void __launch_bounds__(256, later ? 4 : NVCOMP_CASC_COMP_WGS) cascaded_compress_kernel(
+    const void* const* __restrict__ in_ptrs,
+    const size_t* __restrict__ in_bytes,
+    size_t batch_size,
+    void* const* __restrict__ out_ptrs,
+    size_t* out_bytes,
+    casc::Params p,
+    uint32_t* todo,
+    uint32_t pass,
+    uint32_t last_pass,
+    uint32_t lds_per_wave,
+    uint32_t waves_per_block)
+{
+  WAVE_DYNAMIC_LDS(lds);
+  const uint32_t wv = wave::uniform(threadIdx.x >> 6);
+  const size_t first = (size_t)blockIdx.x * waves_per_block + wv;
+  if (!later) {
+    if (first < batch_size) {
+      compress_one_chunk(first, wv, lds, in_ptrs, in_bytes, out_ptrs, out_bytes, p, todo, pass, last_pass, lds_per_wave);
+    }
+    return;
+  }
+  const uint32_t lane = (uint32_t)wave::lane_id();
+  const size_t stride = (size_t)gridDim.x * waves_per_block;
+  for (size_t base = first; base < batch_size; base += 64 * stride) {
+    const size_t mine = base + lane * stride;
+    const uint64_t work = wave::ballot(mine < batch_size && todo[mine] == pass);
+    for (uint64_t m = work; m != 0; m &= m - 1) {
+      compress_one_chunk(base + wave::ctz64(m) * stride, wv, lds, in_ptrs, in_bytes, out_ptrs, out_bytes, p, todo, pass, last_pass,
+                         lds_per_wave);
+    }
+  }
+}
+
 /* pass p decodes the chunks with todo == p (pass 0: all) whose streams fit its LDS budget and hands the others
  * on by setting todo = p + 1.
  * `team` (round 4, batches of up to kDecTeamMaxBatch chunks): a WORKGROUP per chunk. The sub-chunks of a chunk are independent
@@ -165,13 +210,22 @@ __global__ void __launch_bounds__(256, NVCOMP_CASC_COMP_WGS) cascaded_compress_k
  * waves' verdicts (error, "needs the next pass") meet in two LDS words. Large batches keep a chunk per wave: with the
  * card full, four waves each paying a chunk's header round trips for four sub-chunks are slower than one paying them for
  * sixteen (16 384 chunks: 1 426 against 1 673; profiles/r04_cascaded_ab.jsonl). */
-template <bool team> /* true: the workgroup's waves share ONE chunk; false: a chunk per wave */
-__global__ void __launch_bounds__(256, NVCOMP_CASC_DEC_WGS) cascaded_decompress_kernel(
+/* One chunk, by the calling wave (team: by the calling workgroup, every wave with the same arguments).
+ * `fold` (team only): a chunk the waves' slices are too small for is not handed to another launch -- the workgroup's first
+ * wave decodes it again, alone, with the slices of all four as its one (the last pass's 64 KiB: the launches that fold give
+ * their waves 16 KiB each). For the batches that are decoded a workgroup per chunk the launches ARE the time: 256 chunks of
+ * the float columns took 38 us in three launches, two of which found nothing to do. */
+template <bool team, bool fold = false>
+__device__ __forceinline__ void decode_one_chunk(
+    size_t chunk,
+    uint32_t wv,
+    uint32_t lane,
+    uint8_t* lds,
+    uint32_t* verdict,
     const void* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes,
     const size_t* out_caps,
     size_t* actual_bytes,
-    size_t batch_size,
     void* const* __restrict__ out_ptrs,
     nvcompStatus_t* statuses,
     uint32_t* todo,
@@ -179,24 +233,11 @@ __global__ void __launch_bounds__(256, NVCOMP_CASC_DEC_WGS) cascaded_decompress_
     uint32_t lds_per_wave,
     uint32_t waves_per_block)
 {
-  WAVE_DYNAMIC_LDS(lds);
-  /* team: err bits of the chunk's waves | any wave deferred, BEHIND the waves' slices (the launch adds 16 bytes for them: as
-   * a static array they cost the chunk-per-wave launch its eighth workgroup per CU -- 8 x (4 x 5 KiB + 16 B) > 160 KiB --
-   * and 8 % of its speed) */
-  uint32_t* verdict = (uint32_t*)(lds + (size_t)waves_per_block * lds_per_wave);
-  const uint32_t wv = wave::uniform(threadIdx.x >> 6);
-  const size_t chunk = team ? (size_t)blockIdx.x : (size_t)blockIdx.x * waves_per_block + wv;
-  if (chunk >= batch_size) {
-    return;
-  }
-  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
-  if (pass != 0 && wave::uniform(todo[chunk]) != pass) {
-    return; /* (team: the whole workgroup) */
-  }
   const uint32_t first_sub = team ? wv : 0u, sub_stride = team ? waves_per_block : 1u;
   if (team) {
-    if (threadIdx.x < 2) {
-      verdict[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { /* the thread that read the words of the workgroup's last chunk (a later pass takes several) */
+      verdict[0] = 0;
+      verdict[1] = 0;
     }
     __syncthreads();
   }
@@ -318,6 +359,17 @@ __global__ void __launch_bounds__(256, NVCOMP_CASC_DEC_WGS) cascaded_decompress_
       atomicOr(verdict + 1, deferred ? 1u : 0u);
     }
     __syncthreads();
+    if (fold) {
+      /* (every thread reads the words: the caller gives consecutive chunks of a workgroup different ones, so that the reset
+       * for the next chunk does not meet these reads) */
+      if (wave::uniform(verdict[0]) == 0 && wave::uniform(verdict[1]) != 0) {
+        if (wv == 0) { /* (the other waves wait at the next chunk's first barrier, or leave) */
+          decode_one_chunk<false>(chunk, 0u, lane, lds, nullptr, comp_ptrs, comp_bytes, out_caps, actual_bytes, out_ptrs, statuses, todo,
+                                  2u, waves_per_block * lds_per_wave, 1u);
+        }
+        return;
+      }
+    }
   }
   if (team ? threadIdx.x == 0 : lane == 0) {
     const uint32_t all_err = team ? verdict[0] : err;
@@ -334,6 +386,56 @@ __global__ void __launch_bounds__(256, NVCOMP_CASC_DEC_WGS) cascaded_decompress_
                           : (all_err & casc::kErrAlign) ? nvcompErrorAlignment
                                                         : nvcompErrorCannotDecompress;
       }
+    }
+  }
+}
+
+/* `later` = false, pass 0: the grid covers the batch, a chunk per wave (team: per workgroup). `later` = true, passes 1 and 2:
+ * as many workgroups as the card holds at this pass's LDS size, whatever the batch -- wave g of G takes the chunks g, g + G,
+ * ... whose todo word names this pass, and reads up to 64 of its todo words with ONE load (lane j: its j-th chunk's). On data
+ * the first pass decodes -- the float columns, every column of the bench -- both later passes find nothing: as grids over the
+ * batch (16 384 workgroups holding 64 KiB of LDS each for the last one) they took 4.9 + 8.4 us of a 1 GiB call's 510 and
+ * 17.5 + 33 us of a 4 GiB call's 1 900 (profiles/r06_final_kernel_stats_cascaded_*.csv) to read one word per chunk and leave. */
+/* (the later passes' workgroups hold 64 KiB of LDS: two per CU, and registers to match) */
+template <bool team, bool later, bool fold = false> /* team: the workgroup's waves share ONE chunk; otherwise a chunk per wave */
+__global__ void __launch_bounds__(256, (later || fold) ? 2 : NVCOMP_CASC_DEC_WGS) cascaded_decompress_kernel(
+    const void* const* __restrict__ comp_ptrs,
+    const size_t* __restrict__ comp_bytes,
+    const size_t* out_caps,
+    size_t* actual_bytes,
+    size_t batch_size,
+    void* const* __restrict__ out_ptrs,
+    nvcompStatus_t* statuses,
+    uint32_t* todo,
+    uint32_t pass,
+    uint32_t lds_per_wave,
+    uint32_t waves_per_block)
+{
+  WAVE_DYNAMIC_LDS(lds);
+  /* team: err bits of the chunk's waves | any wave deferred, BEHIND the waves' slices (the launch adds 16 bytes for them: as
+   * a static array they cost the chunk-per-wave launch its eighth workgroup per CU -- 8 x (4 x 5 KiB + 16 B) > 160 KiB --
+   * and 8 % of its speed) */
+  uint32_t* verdict = (uint32_t*)(lds + (size_t)waves_per_block * lds_per_wave);
+  const uint32_t wv = wave::uniform(threadIdx.x >> 6);
+  const size_t first = team ? (size_t)blockIdx.x : (size_t)blockIdx.x * waves_per_block + wv;
+  const uint32_t lane = (uint32_t)wave::fresh_lane_id();
+  static_assert(team || !fold, "folding is the workgroup-per-chunk launches'");
+  if (!later) {
+    if (first < batch_size) {
+      decode_one_chunk<team, fold>(first, wv, lane, lds, verdict, comp_ptrs, comp_bytes, out_caps, actual_bytes, out_ptrs, statuses,
+                                   todo, pass, lds_per_wave, waves_per_block);
+    }
+    return;
+  }
+  const size_t stride = team ? (size_t)gridDim.x : (size_t)gridDim.x * waves_per_block;
+  uint32_t pair = 0; /* the verdict words alternate between two pairs (see decode_one_chunk: fold) */
+  for (size_t base = first; base < batch_size; base += 64 * stride) {
+    const size_t mine = base + lane * stride;
+    const uint64_t work = wave::ballot(mine < batch_size && todo[mine] == pass);
+    for (uint64_t m = work; m != 0; m &= m - 1) { /* (team: the same words in every wave of the workgroup) */
+      decode_one_chunk<team, fold>(base + wave::ctz64(m) * stride, wv, lane, lds, verdict + pair, comp_ptrs, comp_bytes, out_caps,
+                                   actual_bytes, out_ptrs, statuses, todo, pass, lds_per_wave, waves_per_block);
+      pair ^= 2u;
     }
   }
 }
@@ -434,24 +536,29 @@ nvcompStatus_t nvcompBatchedCascadedCompressAsync(
   uint32_t* todo = (uint32_t*)device_temp_ptr;
   if (todo == nullptr || temp_bytes < 4 * batch_size || per_wave <= kCompSmallBudget) {
     /* no flag words (or nothing to gain): one launch sized for the worst case */
-    hipLaunchKernelGGL(cascaded_compress_kernel, dim3(grid), dim3(64 * waves), per_wave * waves, stream,
+    hipLaunchKernelGGL(cascaded_compress_kernel<false>, dim3(grid), dim3(64 * waves), per_wave * waves, stream,
                        device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
                        device_compressed_bytes, p, (uint32_t*)nullptr, 0u, 0u, per_wave, waves);
     return launch_status();
   }
   /* pass 0: a small LDS slice at full occupancy; chunks whose streams overflow it are flagged and compressed again by
-   * the next pass; the last pass holds the worst case */
+   * the next pass; the last pass holds the worst case. The passes behind the first: the workgroups the card holds at their
+   * LDS size, looping (see the kernel) */
+  auto resident = [](size_t wgs, size_t lds_bytes) -> unsigned {
+    const size_t fit = kCus * (kLdsPerCu / lds_bytes);
+    return (unsigned)(wgs < fit ? wgs : fit);
+  };
   const uint32_t last = per_wave > kMidBudget ? 2u : 1u;
-  hipLaunchKernelGGL(cascaded_compress_kernel, dim3((unsigned)((batch_size + 3) / 4)), dim3(256), 4 * kCompSmallBudget, stream,
+  hipLaunchKernelGGL(cascaded_compress_kernel<false>, dim3((unsigned)((batch_size + 3) / 4)), dim3(256), 4 * kCompSmallBudget, stream,
                      device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
                      device_compressed_bytes, p, todo, 0u, last, kCompSmallBudget, 4u);
   if (last == 2) {
-    hipLaunchKernelGGL(cascaded_compress_kernel, dim3((unsigned)((batch_size + 3) / 4)), dim3(256), 4 * kMidBudget, stream,
-                       device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
+    hipLaunchKernelGGL(cascaded_compress_kernel<true>, dim3(resident((batch_size + 3) / 4, 4 * kMidBudget)), dim3(256), 4 * kMidBudget,
+                       stream, device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
                        device_compressed_bytes, p, todo, 1u, last, kMidBudget, 4u);
   }
-  hipLaunchKernelGGL(cascaded_compress_kernel, dim3(grid), dim3(64 * waves), per_wave * waves, stream,
-                     device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
+  hipLaunchKernelGGL(cascaded_compress_kernel<true>, dim3(resident(grid, (size_t)per_wave * waves)), dim3(64 * waves), per_wave * waves,
+                     stream, device_uncompressed_ptrs, device_uncompressed_bytes, batch_size, device_compressed_ptrs,
                      device_compressed_bytes, p, todo, last, last, per_wave, waves);
   return launch_status();
 }
@@ -489,31 +596,44 @@ nvcompStatus_t nvcompBatchedCascadedDecompressAsync(
   }
   uint32_t* todo = (uint32_t*)device_temp_ptr;
   clear_stale_error();
+  /* passes 1 and 2: the workgroups the card holds at 64 KiB of LDS each (two per CU), looping (see the kernel) */
+  const size_t kLaterGrid = kCus * (kLdsPerCu / kBigBudget);
   if (batch_size <= kDecTeamMaxBatch) {
-    const dim3 grid((unsigned)batch_size);
-    const unsigned extra = 16; /* the team's two verdict words */
+    /* a workgroup per chunk, and the last pass folded into the one before it (decode_one_chunk: fold); batches the card
+     * holds at 64 KiB of LDS a workgroup start there: ONE launch */
+    const dim3 grid((unsigned)batch_size), later((unsigned)(batch_size < kLaterGrid ? batch_size : kLaterGrid));
+    const unsigned extra = 16; /* the team's verdict words, two pairs */
     (void)extra;               /* (the host emulation's launch macro has no LDS size) */
-    hipLaunchKernelGGL(cascaded_decompress_kernel<true>, grid, dim3(256), 4 * kDecSmallBudget + extra,
+    if (batch_size <= kLaterGrid) {
+      hipLaunchKernelGGL((cascaded_decompress_kernel<true, false, true>), grid, dim3(256), 4 * kFastBudget + extra,
+                         stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
+                         device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 1u,
+                         kFastBudget, 4u);
+      return launch_status();
+    }
+    hipLaunchKernelGGL((cascaded_decompress_kernel<true, false>), grid, dim3(256), 4 * kDecSmallBudget + extra,
                        stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
                        device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 0u,
                        kDecSmallBudget, 4u);
-    hipLaunchKernelGGL(cascaded_decompress_kernel<true>, grid, dim3(256), 4 * kFastBudget + extra,
+    hipLaunchKernelGGL((cascaded_decompress_kernel<true, true, true>), later, dim3(256), 4 * kFastBudget + extra,
                        stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
                        device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 1u,
                        kFastBudget, 4u);
+    return launch_status();
   } else {
-    const dim3 grid((unsigned)((batch_size + 3) / 4));
-    hipLaunchKernelGGL(cascaded_decompress_kernel<false>, grid, dim3(256), 4 * kDecSmallBudget,
+    const size_t wgs = (batch_size + 3) / 4;
+    const dim3 grid((unsigned)wgs), later((unsigned)(wgs < kLaterGrid ? wgs : kLaterGrid));
+    hipLaunchKernelGGL((cascaded_decompress_kernel<false, false>), grid, dim3(256), 4 * kDecSmallBudget,
                        stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
                        device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 0u,
                        kDecSmallBudget, 4u);
-    hipLaunchKernelGGL(cascaded_decompress_kernel<false>, grid, dim3(256), 4 * kFastBudget,
+    hipLaunchKernelGGL((cascaded_decompress_kernel<false, true>), later, dim3(256), 4 * kFastBudget,
                        stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
                        device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 1u,
                        kFastBudget, 4u);
   }
-  hipLaunchKernelGGL(cascaded_decompress_kernel<false>, dim3((unsigned)batch_size), dim3(64), kBigBudget, stream,
-                     device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
+  hipLaunchKernelGGL((cascaded_decompress_kernel<false, true>), dim3((unsigned)(batch_size < kLaterGrid ? batch_size : kLaterGrid)),
+                     dim3(64), kBigBudget, stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
                      device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 2u,
                      kBigBudget, 1u);
   return launch_status();

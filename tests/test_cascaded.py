@@ -147,6 +147,60 @@ def test_sub_chunk_sizes(backend, oracle):
     roundtrip(backend, oracle, chunks, (16384, 6, 2, 1, 1))
 
 
+def test_later_passes_over_many_chunks(backend, oracle):
+    """The passes behind the first are launched with the workgroups the card holds, not with a grid over the batch: a wave
+    (small batches: a workgroup) takes every G-th chunk and finds its work in ONE load of up to 64 flag words
+    (api/cascaded_api.hip: cascaded_{de,}compress_kernel<later>). Batches in which every third / every chunk / one chunk in
+    seven needs the second or the third pass, of more chunks than those launches have waves (several chunks a wave, in the
+    workgroup-per-chunk launch and in the wave-per-chunk launch), and -- on the card -- of more than 64 chunks a wave (the
+    second round of flag words). Streams from different option sets share a decode batch, as the decoder allows."""
+    few = backend.name == "emu"
+    rng = np.random.RandomState(77)
+
+    def runs_of(n, w, lengths):
+        dt = {1: np.uint8, 4: np.uint32, 8: np.uint64}[w]
+        k = n // w
+        vals = np.cumsum(rng.randint(1, 9, size=k)).astype(np.uint64).astype(dt)
+        return np.repeat(vals, rng.choice(lengths, size=k))[:k].view(np.uint8)
+
+    # compress: (16384, 6, 2, 1, 1) has three passes (the worst case of its slice is beyond the middle one), (4096, 4, 2, 1, 1)
+    # two; a run per element or two overflows the first pass's pools, long runs and smooth values do not
+    kinds8 = [runs_of(16384, 8, [1, 1, 1, 2]), runs_of(16384, 8, [300, 500]), runs_of(16384, 8, [1]), datasets.noise(16384, 1)]
+    kinds4 = [runs_of(8192, 4, [1, 1, 2]), runs_of(8192, 4, [40, 300]), datasets.float32_column(2048, 3), runs_of(8192, 4, [1])]
+    n_comp = 150 if few else 2600  # (the card: 650 workgroups in the first pass, 512 / 1 024 resident behind it)
+    for opts, kinds, pattern in (((16384, 6, 2, 1, 1), kinds8, (0, 1, 2)), ((16384, 6, 2, 1, 1), kinds8, (0, 0, 3, 0)),
+                                 ((4096, 4, 2, 1, 1), kinds4, (0, 1, 2, 3, 1, 1, 1))):
+        chunks = [kinds[pattern[i % len(pattern)]] for i in range(n_comp if opts[0] == 4096 or not few else 40)]
+        codec = backend.codec("Cascaded", opts)
+        comp = codec.compress(chunks, in_align=8)
+        refs = [oracle.cascaded_compress(k, *opts) for k in kinds]
+        for i, cc in enumerate(comp):
+            ref = refs[pattern[i % len(pattern)]]
+            assert cc.size == ref.size and np.array_equal(cc, ref), f"{opts}: chunk {i}: compressed bytes differ from the CPU model"
+    # decode: streams of the first pass (smooth int32), of the second (long runs: pools and marks) and of the third (8 192
+    # one-byte elements a sub-chunk; 16 384-byte sub-chunks of int64 runs)
+    pool = []
+    for opts, c in (((4096, 4, 2, 1, 1), datasets.int32_column(2048, 1)), ((4096, 4, 2, 1, 1), runs_of(8192, 4, [1, 2, 300])),
+                    ((8192, 0, 1, 1, 1), runs_of(8192, 1, [1, 1, 3, 70])), ((16384, 6, 2, 1, 1), runs_of(16384, 8, [1, 2, 90])),
+                    ((4096, 4, 2, 1, 1), datasets.float32_column(1024, 2))):
+        cc = backend.codec("Cascaded", opts).compress([c], in_align=8)[0]
+        rc, out = oracle.cascaded_decompress(cc, c.size)
+        assert rc == 0 and np.array_equal(out, c)
+        pool.append((cc, c))
+    codec = backend.codec("Cascaded", (4096, 4, 2, 1, 1))
+    sizes = (700,) if few else (700, 4096, 5000, 40000)
+    for n in sizes:
+        for pattern in ((0, 1, 2, 3, 4), (2, 3), (0, 0, 0, 4, 0, 0, 3), (1,)):
+            if n == 40000 and pattern != (2, 3):
+                continue
+            picks = [pool[pattern[i % len(pattern)]] for i in range(n)]
+            outs, actual, status = codec.decompress([cc for cc, _ in picks], [c.size for _, c in picks], comp_align=8, out_align=8)
+            assert (status == NvcompStatus.Success).all(), (n, pattern, np.flatnonzero(status != NvcompStatus.Success)[:8])
+            assert actual.tolist() == [c.size for _, c in picks]
+            wrong = [i for i, (o, (_, c)) in enumerate(zip(outs, picks)) if not np.array_equal(o, c)]
+            assert not wrong, f"{n} {pattern} {len(wrong)} {wrong[:80]}"
+
+
 def test_benchmark_config_ratio(backend, oracle):
     """config 4 of BASELINE.json: int32 columnar data, default opts, 64 KiB user chunks."""
     data = datasets.int32_column(4 * 65536, 5)
