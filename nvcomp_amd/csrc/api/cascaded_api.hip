@@ -623,6 +623,7 @@ nvcompStatus_t nvcompBatchedCascadedDecompressAsync(
   } else {
     const size_t wgs = (batch_size + 3) / 4;
     const dim3 grid((unsigned)wgs), later((unsigned)(wgs < kLaterGrid ? wgs : kLaterGrid));
+    /* (four waves a workgroup: one and two measured the same, profiles/r06_ab_cascaded_launches.jsonl r6cascw) */
     hipLaunchKernelGGL((cascaded_decompress_kernel<false, false>), grid, dim3(256), 4 * kDecSmallBudget,
                        stream, device_compressed_ptrs, device_compressed_bytes, device_uncompressed_bytes,
                        device_actual_uncompressed_bytes, batch_size, device_uncompressed_ptrs, device_statuses, todo, 0u,

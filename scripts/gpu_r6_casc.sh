@@ -6,16 +6,16 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=gpurun_out/${1:-r6casc}; mkdir -p "$OUT"
-timeout 900 python -m pytest tests/test_cascaded.py tests/test_cascaded_pins.py tests/test_golden_decode.py tests/test_programs.py -m gpu -q -x 2>&1 | tail -3 | tee "$OUT/pytest.log"
+[ "${TESTS:-1}" = 1 ] && timeout 900 python -m pytest tests/test_cascaded.py tests/test_cascaded_pins.py tests/test_golden_decode.py tests/test_programs.py -m gpu -q -x 2>&1 | tail -3 | tee "$OUT/pytest.log"
 line() { python -c "
 import json,sys; r=json.loads(sys.stdin.read()); e=r.get('extras',{}); print('$1', 'dec', r['value'], 'frac', r['roofline']['frac'], 'kernel_ms', r['roofline'].get('kernel_ms'), 'ms_per_step', r['ms_per_step'], 'comp', e.get('gpu_compress_GBps'))"; }
-OLD=$PWD/nvcomp_amd/lib/cab/libnvcomp_cascold.so
+# VARIANTS: tags of builds under nvcomp_amd/lib/cab (scripts/build_casc_variant.sh), each timed in turn with the shipped one ("new")
 for rep in 1 2 3; do
-  for which in new old; do
-    if [ $which = old ]; then export NVCOMP_AMD_LIB=$OLD; else unset NVCOMP_AMD_LIB; fi
+  for which in new ${VARIANTS:-cascold}; do
+    if [ $which != new ]; then export NVCOMP_AMD_LIB=$PWD/nvcomp_amd/lib/cab/libnvcomp_$which.so; else unset NVCOMP_AMD_LIB; fi
     python bench.py --algo cascaded --mib-per-gpu 1024 --unique-mib 32 --no-cpu-baseline 2>/dev/null | tee -a "$OUT/lines_${which}.jsonl" | line "$which 1GiB"
     python bench.py --algo cascaded --no-cpu-baseline 2>/dev/null | tee -a "$OUT/lines_${which}.jsonl" | line "$which 4GiB"
-    for mib in 16 64 256; do
+    for mib in ${SMALL:-16 64 256}; do
       python bench.py --algo cascaded --mib-per-gpu $mib --unique-mib 16 --no-cpu-baseline 2>/dev/null | tee -a "$OUT/lines_${which}.jsonl" | line "$which ${mib}MiB"
     done
   done
