@@ -136,6 +136,17 @@ __device__ __forceinline__ T last_lane(T v)
   return (T)wave::read_lane((uint32_t)v, 63);
 }
 
+/* the value of the lane below (lane 0: unspecified) */
+template <class T>
+__device__ __forceinline__ T lane_below(T v)
+{
+  if (sizeof(T) == 8) {
+    const uint64_t x = (uint64_t)v;
+    return (T)(((uint64_t)wave::prev_lane((uint32_t)(x >> 32)) << 32) | wave::prev_lane((uint32_t)x));
+  }
+  return (T)wave::prev_lane((uint32_t)v);
+}
+
 __device__ __forceinline__ uint32_t pad4(uint32_t n)
 {
   return (n + 3u) & ~3u;
@@ -209,64 +220,116 @@ __device__ __forceinline__ uint32_t encode_chunk(const uint8_t* __restrict__ src
   constexpr uint32_t kBlock = kRowElems * kRows;
   using Z = typename PackedRow<T>::type; /* a lane's values of one row: the element itself, or E small ones in a dword */
   uint32_t op = kHeaderBytes;
+  Z before = 0; /* whole blocks: the last row's last lane of the block before (its element, or its dword of E elements) */
   for (uint32_t base = 0; base < nelem; base += kBlock) {
     const uint32_t count = nelem - base < kBlock ? nelem - base : kBlock;
     const uint32_t rows = (count + kRowElems - 1) / kRowElems;
     Z z[kRows];
     uint32_t widths = 0; /* lane r: width of row r */
+    if (count == kBlock) {
+      /* A whole block: its 32 rows are requested at once, and an element's predecessor comes from the lane below (the
+       * first lane's: from the row before) instead of from memory. Row by row -- a load or two, their wait, the row's
+       * maximum -- a block was 32 round trips to memory, one after the other, and they were the compressor's time: 256 a
+       * chunk, 223 us a chunk at eight waves a SIMD (round 6). */
 #pragma unroll
-    for (uint32_t r = 0; r < kRows; ++r) {
-      z[r] = 0;
-      if (r < rows) {
-        const uint32_t i = base + kRowElems * r + E * lane;
-        uint32_t width_here = 0;
+      for (uint32_t r = 0; r < kRows; ++r) {
+        z[r] = load_elem<Z>(src + (size_t)(base + kRowElems * r + E * lane) * S);
+      }
+#pragma unroll
+      for (uint32_t r = 0; r < kRows; ++r) {
+        const Z raw = z[r];
+        uint32_t width_here;
         if (E == 1) {
-          if (i < nelem) {
-            const T e = load_elem<T>(src + (size_t)i * S);
-            if (DELTA) {
-              const T prev = i ? load_elem<T>(src + (size_t)(i - 1) * S) : (T)0;
-              z[r] = (Z)zigzag<T>((T)(e - prev));
-            } else {
-              z[r] = (Z)e;
-            }
+          if (DELTA) {
+            const Z up = lane_below<Z>(raw); /* (every lane takes part: not inside the choice below) */
+            const Z prev = lane == 0 ? before : up;
+            z[r] = (Z)zigzag<T>((T)(raw - prev));
           }
           width_here = bit_width<T>((T)z[r]);
         } else {
-          /* E elements from one dword; their predecessors from the dword one element earlier */
-          uint32_t packed = 0;
-          if (i + E <= nelem) {
-            const uint32_t v = load_elem<uint32_t>(src + (size_t)i * S);
-            uint32_t pv = 0;
-            if (DELTA) {
-              pv = i ? load_elem<uint32_t>(src + (size_t)(i - 1) * S) : v << (8 * S);
-            }
+          uint32_t packed = (uint32_t)raw;
+          if (DELTA) {
+            /* the dword one element earlier: this one's low elements behind the last element of the dword below */
+            const uint32_t up = lane_below<uint32_t>((uint32_t)raw);
+            const uint32_t below = lane == 0 ? (uint32_t)before : up;
+            const uint32_t pv = ((uint32_t)raw << (8 * S)) | (below >> (32 - 8 * S));
+            packed = 0;
 #pragma unroll
             for (uint32_t k = 0; k < E; ++k) {
-              const T e = (T)(v >> (8 * S * k));
-              const T zz = DELTA ? zigzag<T>((T)(e - (T)(pv >> (8 * S * k)))) : e;
+              const T zz = zigzag<T>((T)((T)((uint32_t)raw >> (8 * S * k)) - (T)(pv >> (8 * S * k))));
               packed |= (uint32_t)zz << (8 * S * k);
-            }
-          } else {
-#pragma unroll
-            for (uint32_t k = 0; k < E; ++k) {
-              if (i + k < nelem) {
-                const T e = load_elem<T>(src + (size_t)(i + k) * S);
-                const T prev = (DELTA && i + k) ? load_elem<T>(src + (size_t)(i + k - 1) * S) : (T)0;
-                const T zz = DELTA ? zigzag<T>((T)(e - prev)) : e;
-                packed |= (uint32_t)zz << (8 * S * k);
-              }
             }
           }
           z[r] = (Z)packed;
-          uint32_t any = packed; /* the OR of the E values has the width of the largest */
+          uint32_t any = packed;
 #pragma unroll
           for (uint32_t k = 1; k < E; ++k) {
             any |= packed >> (8 * S * k);
           }
           width_here = bit_width<T>((T)any);
         }
+        before = last_lane<Z>(raw);
         const uint32_t w = wave::reduce_max(width_here);
         widths = lane == r ? w : widths;
+        if (E > 1 && DELTA) {
+          wave::sched_fence(); /* (the rows' E-element bodies interleaved: 100 spilled registers for one-byte elements) */
+        }
+      }
+    } else {
+#pragma unroll
+      for (uint32_t r = 0; r < kRows; ++r) {
+        z[r] = 0;
+        if (r < rows) {
+          const uint32_t i = base + kRowElems * r + E * lane;
+          uint32_t width_here = 0;
+          if (E == 1) {
+            if (i < nelem) {
+              const T e = load_elem<T>(src + (size_t)i * S);
+              if (DELTA) {
+                const T prev = i ? load_elem<T>(src + (size_t)(i - 1) * S) : (T)0;
+                z[r] = (Z)zigzag<T>((T)(e - prev));
+              } else {
+                z[r] = (Z)e;
+              }
+            }
+            width_here = bit_width<T>((T)z[r]);
+          } else {
+            /* E elements from one dword; their predecessors from the dword one element earlier */
+            uint32_t packed = 0;
+            if (i + E <= nelem) {
+              const uint32_t v = load_elem<uint32_t>(src + (size_t)i * S);
+              uint32_t pv = 0;
+              if (DELTA) {
+                pv = i ? load_elem<uint32_t>(src + (size_t)(i - 1) * S) : v << (8 * S);
+              }
+#pragma unroll
+              for (uint32_t k = 0; k < E; ++k) {
+                const T e = (T)(v >> (8 * S * k));
+                const T zz = DELTA ? zigzag<T>((T)(e - (T)(pv >> (8 * S * k)))) : e;
+                packed |= (uint32_t)zz << (8 * S * k);
+              }
+            } else {
+#pragma unroll
+              for (uint32_t k = 0; k < E; ++k) {
+                if (i + k < nelem) {
+                  const T e = load_elem<T>(src + (size_t)(i + k) * S);
+                  const T prev = (DELTA && i + k) ? load_elem<T>(src + (size_t)(i + k - 1) * S) : (T)0;
+                  const T zz = DELTA ? zigzag<T>((T)(e - prev)) : e;
+                  packed |= (uint32_t)zz << (8 * S * k);
+                }
+              }
+            }
+            z[r] = (Z)packed;
+            uint32_t any = packed; /* the OR of the E values has the width of the largest */
+#pragma unroll
+            for (uint32_t k = 1; k < E; ++k) {
+              any |= packed >> (8 * S * k);
+            }
+            width_here = bit_width<T>((T)any);
+          }
+          const uint32_t w = wave::reduce_max(width_here);
+          widths = lane == r ? w : widths;
+        }
       }
     }
     if (wave::ballot(widths != 0) == 0) { /* constant run (algo 0) / all zero (algo 1) */
@@ -331,6 +394,14 @@ __device__ __forceinline__ uint32_t decode_body(
   const uint32_t nelem = n / S;
   uint32_t ip = kHeaderBytes;
   T carry = 0;
+  /* A block's first bytes (its marker and its row widths, a byte a lane) are requested while the block before it is
+   * unpacked, and its payload eight dwords a lane at a time with the next eight under way: a block used to be three
+   * dependent round trips to memory (the widths, then each group of eight dwords) with nothing in flight meanwhile -- at
+   * eight waves a SIMD a third of a wave's time (round 6). Bytes behind the input are not read. */
+  auto first_bytes = [&](uint32_t at) -> uint32_t {
+    return at < in_len && in_len - at > lane && lane < kRows ? (uint32_t)in[at + lane] : 0u;
+  };
+  uint32_t ahead = first_bytes(ip);
   for (uint32_t base = 0; base < nelem; base += kBlock) {
     const uint32_t count = nelem - base < kBlock ? nelem - base : kBlock;
     const uint32_t rows = (count + kRowElems - 1) / kRowElems;
@@ -338,13 +409,14 @@ __device__ __forceinline__ uint32_t decode_body(
       err = kErrInput;
       return 0;
     }
-    const bool zero_block = wave::uniform((uint32_t)in[ip]) == 0xFFu;
+    const uint32_t bytes = ahead;
+    const bool zero_block = wave::read_lane(bytes, 0) == 0xFFu;
     const uint32_t wbytes = zero_block ? 4u : pad4(rows);
     if (CHECKED && in_len - ip < wbytes) {
       err = kErrInput;
       return 0;
     }
-    const uint32_t widths = !zero_block && lane < rows ? (uint32_t)in[ip + lane] : 0u;
+    const uint32_t widths = !zero_block && lane < rows ? bytes : 0u;
     if (CHECKED && wave::ballot(widths > W)) {
       err = kErrInput;
       return 0;
@@ -357,6 +429,9 @@ __device__ __forceinline__ uint32_t decode_body(
       return 0;
     }
     ip += wbytes + dwords * 256u;
+    if (base + kBlock < nelem) {
+      ahead = first_bytes(ip);
+    }
 
     uint64_t acc = 0;
     uint32_t fill = 0;   /* uniform */
@@ -455,15 +530,28 @@ __device__ __forceinline__ uint32_t decode_body(
       }
     };
 
-    for (uint32_t kb = 0; kb < dwords; kb += 8) {
-      uint32_t d[8];
+    uint32_t d[8], e[8];
+    auto fetch = [&](uint32_t kb, uint32_t (&to)[8]) {
 #pragma unroll
       for (uint32_t j = 0; j < 8; ++j) {
-        d[j] = 0;
+        to[j] = 0;
         if (kb + j < dwords) {
-          d[j] = load_u32(payload + (64u * (kb + j) + lane) * 4u);
+          to[j] = load_u32(payload + (64u * (kb + j) + lane) * 4u);
         }
       }
+    };
+    fetch(0, e);
+    for (uint32_t kb = 0; kb < dwords; kb += 8) {
+      /* ONE wait a group: loads and stores share the counter (vmcnt) and the compiler, unable to tell their completions apart,
+       * waits for EVERYTHING in flight in front of the first use of every loaded register -- a dword at a time that was a wait
+       * for the stores of the rows just written, ten times a block. All eight are "used" here, before the next group's loads and
+       * this group's stores are issued. */
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j) {
+        wave::touch(e[j]);
+        d[j] = e[j];
+      }
+      fetch(kb + 8, e);
 #pragma unroll
       for (uint32_t j = 0; j < 8; ++j) {
         if (kb + j < dwords) {

@@ -123,6 +123,13 @@ __device__ __forceinline__ void touch(uint32_t& v)
   asm volatile("" : "+v"(v));
 }
 
+/* Nothing is scheduled across this point: unrolled bodies stay one after the other instead of being interleaved (and their
+ * temporaries live all at once). */
+__device__ __forceinline__ void sched_fence()
+{
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 /* Is the calling lane's bit set in the wave-uniform mask? (v_cndmask with the mask as its condition: no 1ull << lane) */
 __device__ __forceinline__ bool lane_in(uint64_t mask)
 {

@@ -23,6 +23,7 @@ enum OpId { kBallot = 1, kReadLane, kUniform, kShuffle, kScan, kMax, kSync, kLas
 inline int lane_id() { return emu::cur()->lane; }
 inline int fresh_lane_id() { return emu::cur()->lane; }
 inline void touch(uint32_t&) {}
+inline void sched_fence() {}
 inline bool lane_in(uint64_t mask) { return ((mask >> emu::cur()->lane) & 1) != 0; }
 
 inline uint64_t ballot(bool pred)

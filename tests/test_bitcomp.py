@@ -70,6 +70,30 @@ def test_ragged_sizes_and_tails(backend, oracle):
             roundtrip(backend, oracle, chunks, algo, typ)
 
 
+def test_whole_blocks_take_predecessors_from_the_lane_below(backend, oracle):
+    """The compressor requests a whole block's 32 rows at once and takes an element's predecessor from the lane below -- the
+    first lane's from the row before, the first row's from the block before (bitcomp.hip.h: encode_chunk). Blocks whose
+    first element differs from the last of the block before; a block of one repeated value in between (stored as a marker:
+    the block behind it still needs ITS last element); a partial block behind whole ones; every element width, both
+    algorithms; walks that wrap around the element's range."""
+    rng = np.random.RandomState(42)
+    for typ in (0, 1, 2, 3, 4, 5, 6, 7):
+        w = WIDTH[typ]
+        dt = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[w]
+        block = 2048 * (4 // w if w < 4 else 1)
+        def walk(n, step):
+            return (np.cumsum(rng.randint(-step, step + 1, size=n)).astype(np.int64) + int(rng.randint(0, 1 << 30))).astype(dt)
+        chunks = []
+        a, b, c = walk(block, 3), walk(block, 40000), walk(block + 77, 9)
+        chunks.append(np.concatenate([a, b]).view(np.uint8))                                   # two whole blocks, a jump between them
+        chunks.append(np.concatenate([a, np.full(block, a[-1] + 5, dtype=dt), b]).view(np.uint8))  # a constant block in the middle
+        chunks.append(np.concatenate([np.full(block, 7, dtype=dt), a, c]).view(np.uint8))      # constant first, partial last
+        chunks.append(np.concatenate([np.zeros(block, dtype=dt), np.zeros(block, dtype=dt), b]).view(np.uint8))
+        chunks.append(rng.randint(0, 256, size=3 * block * w).astype(np.uint8))                # full-width rows
+        for algo in (0, 1):
+            roundtrip(backend, oracle, chunks, algo, typ)
+
+
 def test_unaligned_pointers(backend, oracle):
     chunks = [datasets.int32_column(30000, 2), datasets.float32_column(8192, 1), datasets.lowcard(7777, 3)]
     roundtrip(backend, oracle, chunks, 0, 5, comp_align=1, out_align=1)
